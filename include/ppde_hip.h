@@ -1,0 +1,166 @@
+/*
+ * ppde_hip.h — C ABI of the MI355X (gfx950) PPDE sampler hot path.
+ *
+ * The reference (pemami4911/ppde) has no FFI: its boundary for this path is the duck-typed Python API
+ *   ppde/base_sampler.py:8-15            BaseSampler.run(...)
+ *   ppde/protein_samplers/ppde.py:24-192 PPDE_PAS.run(...)
+ *   ppde/energy.py:97-140                ProteinProductOfExperts.get_energy / get_energy_and_grads / ...
+ * This header is what a ctypes/cffi binding of that API calls (ppde_amd/_hip.py is that binding; the stub a
+ * maintainer of the reference would add is shown in INTEGRATION.md). Each entry point names the reference
+ * code it replaces.
+ *
+ * Conventions
+ *   - every function returns 0 on success and a negative ppde_status otherwise; ppde_last_error() returns a
+ *     thread-local human-readable message for the last failure; nothing throws across the ABI;
+ *   - "host" pointers are ordinary host memory owned by the caller; "dev" pointers are device memory on the
+ *     model's device (e.g. torch tensors' data_ptr()); the library owns every device buffer it allocates;
+ *   - states are residue indices, one byte per residue (alphabet ACDEFGHIKLMNPQRSTVWY -> 0..19,
+ *     ppde/third_party/hsu/data_utils.py:48-70); fp32 one-hot [n, L, 20] exists only at the API edge;
+ *   - a ppde_model is immutable after its set_* calls and may be shared by several ppde_chains; a
+ *     ppde_chains owns one HIP stream and is not thread-safe.
+ */
+#ifndef PPDE_HIP_H
+#define PPDE_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PPDE_ABI_VERSION 1
+#define PPDE_ALPHABET 20
+
+typedef enum {
+    PPDE_OK = 0,
+    PPDE_ERR_INVALID = -1,     /* bad argument / shape / state */
+    PPDE_ERR_HIP = -2,         /* a HIP runtime call failed */
+    PPDE_ERR_NOT_ONEHOT = -3,  /* an input row is not a one-hot vector */
+    PPDE_ERR_NUMERIC = -4      /* a proposal row had no finite logit (the reference raises ValueError there) */
+} ppde_status;
+
+typedef struct ppde_model ppde_model;
+typedef struct ppde_chains ppde_chains;
+
+int ppde_abi_version(void);
+const char* ppde_last_error(void);
+/* number of visible HIP devices, or a negative status */
+int ppde_device_count(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * Model = the product of experts' parameters resident on one device.
+ * Replaces the constructors ProteinProductOfExperts.__init__ (ppde/energy.py:72-95),
+ * PottsModel.__init__ (ppde/nets.py:245-262) and EnsembleProtein.__init__ (ppde/nets.py:417-424).
+ * ---------------------------------------------------------------------------------------------- */
+
+/* L = full sequence length; wt_idx host [L] = wild-type residues (energy.py:95 `wt_onehot`). */
+int ppde_model_create(ppde_model** out, int device, int L, const uint8_t* wt_idx);
+int ppde_model_destroy(ppde_model* m);
+
+/* Potts couplings J host [Lp, Lp, 20, 20] and fields h host [Lp, 20] (potts.pkl `J_ij`, `h_i`,
+ * nets.py:247-249); the window covers residues [win_start, win_start + Lp) (nets.py:280).
+ * J need not be symmetric: it is symmetrised on upload, M = (J + J^T)/2, which is what autograd of
+ * nets.py:287-290 yields (energy.py:108). Also evaluates wt_H (nets.py:262). */
+int ppde_model_set_potts(ppde_model* m, const float* J, const float* h, int Lp, int win_start);
+
+/* Supervised CNN ensemble (nets.py:350-376, :412-442): n_nets networks, each
+ * conv_w [C, 20, K], conv_b [C], lin_w [F, C], lin_b [F], dec_w [F], dec_b [1] on the host. */
+int ppde_model_set_cnn(ppde_model* m, int n_nets, int C, int K, int F,
+                       const float* const* conv_w, const float* const* conv_b,
+                       const float* const* lin_w, const float* const* lin_b,
+                       const float* const* dec_w, const float* const* dec_b);
+
+/* lamda of e = dH + lamda * fit (energy.py:74, :99-100). */
+int ppde_model_set_lamda(ppde_model* m, float lamda);
+
+/* wt_H (nets.py:262) for inspection. */
+int ppde_model_get_wt_hamiltonian(ppde_model* m, float* out_host);
+
+/* ------------------------------------------------------------------------------------------------
+ * Stateless evaluations at the API edge (device pointers; `stream` is a hipStream_t or NULL).
+ * ---------------------------------------------------------------------------------------------- */
+
+/* fp32 one-hot x_dev [n, L, 20] -> idx_dev [n, L]. Fails with PPDE_ERR_NOT_ONEHOT (after a stream sync)
+ * if some row is not exactly one 1.0 and nineteen 0.0. */
+int ppde_onehot_to_idx(ppde_model* m, const float* x_dev, int n, uint8_t* idx_dev, void* stream);
+/* idx_dev [n, L] -> fp32 one-hot x_dev [n, L, 20]. */
+int ppde_idx_to_onehot(ppde_model* m, const uint8_t* idx_dev, int n, float* x_dev, void* stream);
+
+/* get_energy / get_energy_and_grads (energy.py:97-108,132): e_dev [n], fit_dev [n], and, when grad_dev
+ * is not NULL, grad_dev [n, L, 20] = d e.sum() / d x. which: bit 0 = unsupervised (Potts) expert,
+ * bit 1 = supervised expert; 3 = product of experts. With which == 2, e = fit and grad = d fit/dx
+ * (ProteinSupervised, energy.py:153-160); with which == 1, e = dH, fit = 0. */
+int ppde_energy_grad(ppde_model* m, const uint8_t* idx_dev, int n, int which,
+                     float* e_dev, float* fit_dev, float* grad_dev, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Chains = the sampler state of n independent Markov chains (PPDE_PAS.run, ppde.py:24-192).
+ * ---------------------------------------------------------------------------------------------- */
+
+typedef struct {
+    int32_t n_chains;        /* chains held by this object (this rank's shard) */
+    int32_t max_steps;       /* capacity of the histories (T); run may stop earlier */
+    int32_t pas_length;      /* args.ppde_pas_length (ppde.py:12): U ~ randint[1, 2*pas) */
+    int32_t nmut_threshold;  /* args.nmut_threshold; 0 = unlimited (ppde.py:15-17) */
+    int32_t paper_results;   /* args.paper_results (ppde.py:14,76,148) */
+    int32_t min_pos;         /* proposals restricted to residues [min_pos, max_pos] (ppde.py:60-63) */
+    int32_t max_pos;
+    int32_t which;           /* experts in the energy, as in ppde_energy_grad */
+    int32_t rng_mode;        /* 0 = noise supplied by the caller per step (parity with a host generator),
+                                1 = counter-based Philox4x32-10 on the device */
+    int32_t reuse_grad;      /* 1 = keep energy/gradient of the current state from the previous iteration
+                                instead of re-evaluating it (identical results, half the expert calls) */
+    int32_t record_after_reset; /* 1 = histories of STATES hold the post-reset state (the reference's
+                                --device cpu aliasing artefact); 0 = pre-reset (its cuda behaviour) */
+    int32_t trace;           /* 1 = keep per-iteration draws / accept bits / log-acceptance for tests */
+    int32_t random_chain;    /* local index of the chain whose trajectory is kept (ppde.py:37,47,142), or -1 */
+    int32_t use_graph;       /* 1 = replay iterations from a captured hipGraph (rng_mode 1 only) */
+    uint64_t seed;           /* Philox key */
+    uint64_t chain_offset;   /* global index of local chain 0: results do not depend on the sharding */
+} ppde_chain_config;
+
+int ppde_chains_create(ppde_chains** out, ppde_model* m, const ppde_chain_config* cfg);
+int ppde_chains_destroy(ppde_chains* c);
+
+/* Start from idx0_dev [n, L] (ppde.py:35-47): evaluates the initial energies, fills history row 0. */
+int ppde_chains_init(ppde_chains* c, const uint8_t* idx0_dev);
+
+/* Run `steps` iterations of ppde.py:65-153. For rng_mode 0 the caller supplies, for these iterations,
+ *   U_dev int32 [steps, n]          path lengths in [1, 2*pas)        (torch.randint, ppde.py:67)
+ *   q_dev fp32  [sum_t max_u(t), n, L*20]  Exp(1) variates, max_u(t) = max_b U[t,b]  (multinomial, ppde.py:109)
+ *   u_dev fp32  [steps, n]          accept uniforms                  (torch.rand_like, ppde.py:138)
+ *   max_u host int32 [steps]
+ * and for rng_mode 1 passes NULLs. Asynchronous: returns once the work is enqueued. */
+int ppde_chains_run(ppde_chains* c, int steps, const int32_t* U_dev, const float* q_dev,
+                    const float* u_dev, const int32_t* max_u);
+
+/* Block until enqueued work is done; reports PPDE_ERR_NUMERIC if a proposal row degenerated. */
+int ppde_chains_sync(ppde_chains* c);
+int ppde_chains_steps_done(ppde_chains* c);
+
+/* Current population (after the mutation-cap reset) and what the reference logs every log_every
+ * (ppde.py:155-170): any pointer may be NULL. idx host [n, L], energy/fitness host [n] = last history
+ * row, accepted host [n] = last accept bits, dist host [n] = mutation counts. Synchronises. */
+int ppde_chains_peek(ppde_chains* c, uint8_t* idx, float* energy, float* fitness, uint8_t* accepted, int32_t* dist);
+
+/* Final collect (ppde.py:172-192): best state per chain by max energy over history (first index on ties),
+ * histories [steps_done+1, n], random trajectory [steps_done+1, L]. Any pointer may be NULL. Synchronises. */
+int ppde_chains_collect(ppde_chains* c, uint8_t* best_idx, float* best_energy, float* best_fitness,
+                        int32_t* best_step, float* energy_history, float* fitness_history, uint8_t* random_traj);
+
+/* Trace buffers (cfg.trace = 1): flat host int32 [steps_done, 2*pas-1, n] (-1 = not drawn),
+ * accepted host uint8 [steps_done, n], log_acc host fp32 [steps_done, n], U host int32 [steps_done, n]. */
+int ppde_chains_trace(ppde_chains* c, int32_t* flat, uint8_t* accepted, float* log_acc, int32_t* U);
+
+/* Device RNG inspection (tests): fills q_dev [n, L*20], u_dev [n], U_dev [n] with what iteration `it`,
+ * sub-step `s` would use in rng_mode 1. */
+int ppde_chains_philox_dump(ppde_chains* c, int it, int s, float* q_dev, float* u_dev, int32_t* U_dev);
+
+/* Timing hooks for bench.py: average duration in microseconds of the Potts energy+gradient kernel over
+ * the launches recorded since the last reset, measured with HIP events on the chains' stream. */
+int ppde_chains_time_potts_kernel(ppde_chains* c, int reps, float* avg_us);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PPDE_HIP_H */

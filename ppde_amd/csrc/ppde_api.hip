@@ -1,0 +1,740 @@
+// Host side of the C ABI declared in include/ppde_hip.h: device memory ownership, weight re-layout,
+// kernel launches, hipGraph capture of the iteration loop.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include <algorithm>
+#include <string>
+#include <vector>
+
+#include "../../include/ppde_hip.h"
+#include "common.h"
+#include "potts.h"
+#include "cnn.h"
+#include "pas.h"
+
+static thread_local std::string g_err;
+
+static int fail(int code, const std::string& msg) {
+    g_err = msg;
+    return code;
+}
+#define HIPCHK(x)                                                                                   \
+    do {                                                                                            \
+        hipError_t e_ = (x);                                                                        \
+        if (e_ != hipSuccess)                                                                       \
+            return fail(PPDE_ERR_HIP, std::string(#x) + ": " + hipGetErrorString(e_));              \
+    } while (0)
+#define ARGCHK(c, msg)                                                                              \
+    do {                                                                                            \
+        if (!(c)) return fail(PPDE_ERR_INVALID, std::string(msg));                                  \
+    } while (0)
+
+template <typename T>
+static hipError_t dalloc(T** p, size_t count) {
+    *p = nullptr;
+    if (count == 0) count = 1;
+    return hipMalloc((void**)p, count * sizeof(T));
+}
+
+// --------------------------------------------------------------------------------------------
+struct ppde_model {
+    int device = 0;
+    int L = 0;
+    Geom g{};
+    std::vector<uint8_t> h_wt;       // plain [L]
+    uint8_t* d_wt = nullptr;         // state layout [Ls]
+    // Potts
+    bool has_potts = false;
+    float4* d_Jt = nullptr;
+    float* d_h = nullptr;
+    float wt_H = 0.f;
+    // CNN
+    bool has_cnn = false;
+    int n_nets = 0, C = 0, CP = 0, K = 0, F = 0, T = 0, J = 0;
+    CnnNet nets[4]{};
+    std::vector<void*> cnn_allocs;
+    float lamda = 0.f;
+    // scratch of the stateless API
+    int scratch_n = 0;
+    uint8_t* s_state = nullptr;
+    float *s_grad = nullptr, *s_epart = nullptr, *s_gradC = nullptr, *s_fitC = nullptr;
+    int* s_flag = nullptr;
+};
+
+static void set_geom(ppde_model* m, int Lp, int i0) {
+    Geom& g = m->g;
+    g.L = m->L;
+    g.N = m->L * PPDE_A;
+    g.Lp = Lp;
+    g.i0 = i0;
+    g.NC = Lp > 0 ? (((Lp + 3) / 4) + 3) / 4 : 0;
+    g.sh = Lp > 0 ? (4 - (i0 & 3)) & 3 : 0;
+    int need = std::max(g.sh + m->L, g.sh + i0 + 16 * g.NC);
+    g.Ls = (need + 15) & ~15;
+}
+
+static int upload_wt(ppde_model* m) {
+    if (m->d_wt) HIPCHK(hipFree(m->d_wt));
+    std::vector<uint8_t> row(m->g.Ls, 0);
+    for (int l = 0; l < m->L; ++l) row[m->g.sh + l] = m->h_wt[l];
+    HIPCHK(dalloc(&m->d_wt, (size_t)m->g.Ls));
+    HIPCHK(hipMemcpy(m->d_wt, row.data(), row.size(), hipMemcpyHostToDevice));
+    return PPDE_OK;
+}
+
+static void free_scratch(ppde_model* m) {
+    hipFree(m->s_state); hipFree(m->s_grad); hipFree(m->s_epart); hipFree(m->s_gradC); hipFree(m->s_fitC);
+    m->s_state = nullptr; m->s_grad = m->s_epart = m->s_gradC = m->s_fitC = nullptr;
+    m->scratch_n = 0;
+}
+
+// Launch the experts on states in state layout. Outputs go to slot buffers laid out as in PasArgs.
+struct EvalTargets {
+    float* grad;      // [slots][n][N]
+    float* epart;     // [slots][n][Lp]
+    float* gradC;     // [slots][nets][n][N]
+    float* fitC;      // [slots][nets][n]
+    const uint8_t* cursel;
+    int slot_mode, slot_fixed;
+};
+
+static int potts_ng_for(int n) { return n <= 64 ? 1 : n <= 128 ? 2 : n <= 256 ? 4 : 8; }
+
+static size_t potts_lds_bytes(const Geom& g, int NG) {
+    size_t region0 = std::max<size_t>((size_t)g.NC * 320, (size_t)4 * NG * 64);
+    return region0 * 16 + (size_t)4 * g.NC * NG * 64 * 4;
+}
+
+static int launch_potts(const ppde_model* m, const uint8_t* states, int n, const EvalTargets& t, hipStream_t s) {
+    PottsArgs a{};
+    a.Jt = m->d_Jt; a.h = m->d_h; a.idx = states; a.grad = t.grad; a.epart = t.epart;
+    a.cursel = t.cursel; a.slot_mode = t.slot_mode; a.slot_fixed = t.slot_fixed; a.n = n; a.accumulate = 0;
+    a.g = m->g;
+    int NG = potts_ng_for(n);
+    size_t lds = potts_lds_bytes(m->g, NG);
+    while (lds > 150 * 1024 && NG > 1) { NG >>= 1; lds = potts_lds_bytes(m->g, NG); }
+    ARGCHK(lds <= 160 * 1024, "Potts window too long for one LDS slab");
+    dim3 grid(m->g.Lp * 5, (n + NG * 64 - 1) / (NG * 64));
+    switch (NG) {
+        case 1: hipLaunchKernelGGL(potts_energy_grad_kernel<1>, grid, dim3(256), lds, s, a); break;
+        case 2: hipLaunchKernelGGL(potts_energy_grad_kernel<2>, grid, dim3(256), lds, s, a); break;
+        case 4: hipLaunchKernelGGL(potts_energy_grad_kernel<4>, grid, dim3(256), lds, s, a); break;
+        default: hipLaunchKernelGGL(potts_energy_grad_kernel<8>, grid, dim3(256), lds, s, a); break;
+    }
+    HIPCHK(hipGetLastError());
+    return PPDE_OK;
+}
+
+static int launch_cnn(const ppde_model* m, const uint8_t* states, int n, const EvalTargets& t, int want_grad,
+                      float scale, hipStream_t s) {
+    CnnArgs a{};
+    for (int k = 0; k < m->n_nets; ++k) a.net[k] = m->nets[k];
+    a.n_nets = m->n_nets; a.C = m->C; a.CP = m->CP; a.K = m->K; a.F = m->F; a.T = m->T; a.J = m->J;
+    a.idx = states; a.gradC = t.gradC; a.fitC = t.fitC; a.cursel = t.cursel;
+    a.slot_mode = t.slot_mode; a.slot_fixed = t.slot_fixed; a.n = n; a.want_grad = want_grad; a.scale = scale;
+    a.g = m->g;
+    size_t lds = cnn_lds_bytes(m->T, m->CP, m->F, m->J, m->L);
+    ARGCHK(lds <= 160 * 1024, "sequence too long for the LDS-resident CNN kernel");
+    hipLaunchKernelGGL(k_cnn, dim3(n, m->n_nets), dim3(256), lds, s, a);
+    HIPCHK(hipGetLastError());
+    return PPDE_OK;
+}
+
+static int eval_experts(const ppde_model* m, int which, const uint8_t* states, int n, const EvalTargets& t,
+                        int want_grad, hipStream_t s) {
+    if (which & 1) {
+        ARGCHK(m->has_potts, "the energy uses the Potts expert but ppde_model_set_potts was not called");
+        int rc = launch_potts(m, states, n, t, s);
+        if (rc) return rc;
+    }
+    if (which & 2) {
+        ARGCHK(m->has_cnn, "the energy uses the supervised expert but ppde_model_set_cnn was not called");
+        float scale = (which == 2 ? 1.0f : m->lamda) / (float)m->n_nets;
+        int rc = launch_cnn(m, states, n, t, want_grad, scale, s);
+        if (rc) return rc;
+    }
+    return PPDE_OK;
+}
+
+static PasArgs base_pas_args(const ppde_model* m, int which, int n) {
+    PasArgs a{};
+    a.g = m->g; a.n = n; a.wt = m->d_wt; a.wt_H = m->wt_H; a.lamda = m->lamda; a.which = which;
+    a.n_nets = m->n_nets;
+    return a;
+}
+
+// --------------------------------------------------------------------------------------------
+extern "C" {
+
+int ppde_abi_version(void) { return PPDE_ABI_VERSION; }
+const char* ppde_last_error(void) { return g_err.c_str(); }
+
+int ppde_device_count(void) {
+    int n = 0;
+    HIPCHK(hipGetDeviceCount(&n));
+    return n;
+}
+
+int ppde_model_create(ppde_model** out, int device, int L, const uint8_t* wt_idx) {
+    ARGCHK(out && wt_idx, "null argument");
+    ARGCHK(L >= 5 && L <= 4096, "sequence length out of range");
+    for (int l = 0; l < L; ++l) ARGCHK(wt_idx[l] < PPDE_A, "wild-type residue index out of range");
+    HIPCHK(hipSetDevice(device));
+    ppde_model* m = new ppde_model();
+    m->device = device;
+    m->L = L;
+    m->h_wt.assign(wt_idx, wt_idx + L);
+    set_geom(m, 0, 0);
+    int rc = upload_wt(m);
+    if (rc) { delete m; return rc; }
+    *out = m;
+    return PPDE_OK;
+}
+
+int ppde_model_destroy(ppde_model* m) {
+    if (!m) return PPDE_OK;
+    hipSetDevice(m->device);
+    free_scratch(m);
+    hipFree(m->s_flag);
+    hipFree(m->d_wt); hipFree(m->d_Jt); hipFree(m->d_h);
+    for (void* p : m->cnn_allocs) hipFree(p);
+    delete m;
+    return PPDE_OK;
+}
+
+int ppde_model_set_lamda(ppde_model* m, float lamda) {
+    ARGCHK(m, "null model");
+    m->lamda = lamda;
+    return PPDE_OK;
+}
+
+int ppde_model_set_potts(ppde_model* m, const float* J, const float* h, int Lp, int win_start) {
+    ARGCHK(m && J && h, "null argument");
+    ARGCHK(Lp >= 1 && win_start >= 0 && win_start + Lp <= m->L, "Potts window does not fit the sequence");
+    HIPCHK(hipSetDevice(m->device));
+    set_geom(m, Lp, win_start);
+    free_scratch(m);
+    int rc = upload_wt(m);
+    if (rc) return rc;
+    const Geom& g = m->g;
+    const size_t nJ = (size_t)Lp * Lp * 400;
+    float* d_raw = nullptr;
+    HIPCHK(dalloc(&d_raw, nJ));
+    HIPCHK(hipMemcpy(d_raw, J, nJ * sizeof(float), hipMemcpyHostToDevice));
+    if (m->d_Jt) hipFree(m->d_Jt);
+    if (m->d_h) hipFree(m->d_h);
+    const size_t nJt = (size_t)Lp * 5 * g.NC * 320;           // float4s
+    HIPCHK(dalloc(&m->d_Jt, nJt));
+    HIPCHK(dalloc(&m->d_h, (size_t)Lp * 20));
+    HIPCHK(hipMemcpy(m->d_h, h, (size_t)Lp * 20 * sizeof(float), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(potts_prepare_kernel, dim3(1024), dim3(256), 0, 0, d_raw, (float*)m->d_Jt, Lp, g.NC);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipFree(d_raw));
+    m->has_potts = true;
+    // wt_H = H(wild type) with the same kernel that evaluates every other state
+    float *d_grad = nullptr, *d_ep = nullptr, *d_e = nullptr;
+    HIPCHK(dalloc(&d_grad, (size_t)g.N));
+    HIPCHK(dalloc(&d_ep, (size_t)Lp));
+    HIPCHK(dalloc(&d_e, 1));
+    EvalTargets t{d_grad, d_ep, nullptr, nullptr, nullptr, 0, 0};
+    rc = launch_potts(m, m->d_wt, 1, t, 0);
+    if (rc) return rc;
+    hipLaunchKernelGGL(potts_energy_finalize_kernel, dim3(1), dim3(64), 0, 0, d_ep, Lp, 0.0f, d_e, 1);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpy(&m->wt_H, d_e, sizeof(float), hipMemcpyDeviceToHost));
+    hipFree(d_grad); hipFree(d_ep); hipFree(d_e);
+    return PPDE_OK;
+}
+
+int ppde_model_get_wt_hamiltonian(ppde_model* m, float* out_host) {
+    ARGCHK(m && out_host, "null argument");
+    ARGCHK(m->has_potts, "no Potts expert");
+    *out_host = m->wt_H;
+    return PPDE_OK;
+}
+
+int ppde_model_set_cnn(ppde_model* m, int n_nets, int C, int K, int F, const float* const* conv_w,
+                       const float* const* conv_b, const float* const* lin_w, const float* const* lin_b,
+                       const float* const* dec_w, const float* const* dec_b) {
+    ARGCHK(m && conv_w && conv_b && lin_w && lin_b && dec_w && dec_b, "null argument");
+    ARGCHK(n_nets >= 1 && n_nets <= 4, "1..4 networks supported");
+    ARGCHK(K >= 1 && K <= m->L && C >= 1 && F >= 1, "bad CNN shape");
+    HIPCHK(hipSetDevice(m->device));
+    for (void* p : m->cnn_allocs) hipFree(p);
+    m->cnn_allocs.clear();
+    m->n_nets = n_nets; m->C = C; m->K = K; m->F = F; m->T = m->L - K + 1; m->J = K * 20;
+    const int CP = (C + 3) & ~3;
+    m->CP = CP;
+    auto up = [&](const std::vector<float>& v, const float** out) -> int {
+        float* d = nullptr;
+        HIPCHK(dalloc(&d, v.size()));
+        HIPCHK(hipMemcpy(d, v.data(), v.size() * sizeof(float), hipMemcpyHostToDevice));
+        m->cnn_allocs.push_back(d);
+        *out = d;
+        return PPDE_OK;
+    };
+    for (int k = 0; k < n_nets; ++k) {
+        CnnNet& nt = m->nets[k];
+        std::vector<float> WcT((size_t)K * 20 * CP, 0.f), bc(CP, 0.f), WeT4((size_t)CP * F, 0.f), We((size_t)F * CP, 0.f),
+            Wf4((size_t)CP * m->J, 0.f);
+        for (int o = 0; o < C; ++o) {
+            bc[o] = conv_b[k][o];
+            for (int c = 0; c < 20; ++c)
+                for (int kp = 0; kp < K; ++kp) {
+                    const float w = conv_w[k][((size_t)o * 20 + c) * K + kp];
+                    WcT[((size_t)kp * 20 + c) * CP + o] = w;
+                    Wf4[(((size_t)(o / 4)) * m->J + (kp * 20 + c)) * 4 + (o & 3)] = w;
+                }
+        }
+        for (int f = 0; f < F; ++f)
+            for (int o = 0; o < C; ++o) {
+                const float w = lin_w[k][(size_t)f * C + o];
+                We[(size_t)f * CP + o] = w;
+                WeT4[(((size_t)(o / 4)) * F + f) * 4 + (o & 3)] = w;
+            }
+        std::vector<float> be(lin_b[k], lin_b[k] + F), wd(dec_w[k], dec_w[k] + F);
+        const float* p;
+        int rc;
+        if ((rc = up(WcT, &p))) return rc; nt.WcT = p;
+        if ((rc = up(bc, &p))) return rc; nt.bc = p;
+        if ((rc = up(WeT4, &p))) return rc; nt.WeT4 = (const float4*)p;
+        if ((rc = up(We, &p))) return rc; nt.We = p;
+        if ((rc = up(be, &p))) return rc; nt.be = p;
+        if ((rc = up(wd, &p))) return rc; nt.wd = p;
+        if ((rc = up(Wf4, &p))) return rc; nt.Wf4 = (const float4*)p;
+        nt.bd = dec_b[k][0];
+    }
+    free_scratch(m);
+    m->has_cnn = true;
+    return PPDE_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+static int ensure_scratch(ppde_model* m, int n) {
+    if (!m->s_flag) {
+        HIPCHK(dalloc(&m->s_flag, 1));
+        HIPCHK(hipMemset(m->s_flag, 0, sizeof(int)));
+    }
+    if (n <= m->scratch_n) return PPDE_OK;
+    free_scratch(m);
+    const Geom& g = m->g;
+    HIPCHK(dalloc(&m->s_state, (size_t)n * g.Ls));
+    HIPCHK(dalloc(&m->s_grad, (size_t)n * g.N));
+    HIPCHK(hipMemset(m->s_grad, 0, (size_t)n * g.N * sizeof(float)));
+    HIPCHK(dalloc(&m->s_epart, (size_t)n * std::max(g.Lp, 1)));
+    if (m->has_cnn) {
+        HIPCHK(dalloc(&m->s_gradC, (size_t)m->n_nets * n * g.N));
+        HIPCHK(dalloc(&m->s_fitC, (size_t)m->n_nets * n));
+    }
+    m->scratch_n = n;
+    return PPDE_OK;
+}
+
+int ppde_onehot_to_idx(ppde_model* m, const float* x_dev, int n, uint8_t* idx_dev, void* stream) {
+    ARGCHK(m && x_dev && idx_dev && n >= 0, "bad argument");
+    if (n == 0) return PPDE_OK;
+    HIPCHK(hipSetDevice(m->device));
+    hipStream_t s = (hipStream_t)stream;
+    int rc = ensure_scratch(m, 1);
+    if (rc) return rc;
+    HIPCHK(hipMemsetAsync(m->s_flag, 0, sizeof(int), s));
+    const int tot = n * m->L;
+    hipLaunchKernelGGL(k_onehot_to_idx, dim3((tot + 255) / 256), dim3(256), 0, s, x_dev, idx_dev, n, m->L, m->L, 0, m->s_flag);
+    HIPCHK(hipGetLastError());
+    int bad = 0;
+    HIPCHK(hipMemcpyAsync(&bad, m->s_flag, sizeof(int), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    if (bad) return fail(PPDE_ERR_NOT_ONEHOT, "input is not one-hot: every residue row must hold exactly one 1.0 and nineteen 0.0");
+    return PPDE_OK;
+}
+
+int ppde_idx_to_onehot(ppde_model* m, const uint8_t* idx_dev, int n, float* x_dev, void* stream) {
+    ARGCHK(m && x_dev && idx_dev && n >= 0, "bad argument");
+    if (n == 0) return PPDE_OK;
+    HIPCHK(hipSetDevice(m->device));
+    const int tot = n * m->L * 20;
+    hipLaunchKernelGGL(k_idx_to_onehot, dim3((tot + 255) / 256), dim3(256), 0, (hipStream_t)stream, idx_dev, x_dev, n, m->L, m->L, 0);
+    HIPCHK(hipGetLastError());
+    return PPDE_OK;
+}
+
+int ppde_energy_grad(ppde_model* m, const uint8_t* idx_dev, int n, int which, float* e_dev, float* fit_dev,
+                     float* grad_dev, void* stream) {
+    ARGCHK(m && idx_dev && n >= 0, "bad argument");
+    ARGCHK(which >= 1 && which <= 3, "which must be 1 (Potts), 2 (supervised) or 3 (product of experts)");
+    if (n == 0) return PPDE_OK;
+    HIPCHK(hipSetDevice(m->device));
+    hipStream_t s = (hipStream_t)stream;
+    int rc = ensure_scratch(m, n);
+    if (rc) return rc;
+    const Geom& g = m->g;
+    hipLaunchKernelGGL(k_pack_state, dim3((n * g.Ls + 255) / 256), dim3(256), 0, s, idx_dev, m->s_state, n, g.L, g.Ls, g.sh);
+    HIPCHK(hipGetLastError());
+    EvalTargets t{m->s_grad, m->s_epart, m->s_gradC, m->s_fitC, nullptr, 0, 0};
+    // the scratch is laid out for scratch_n chains; kernels index slot 0 with stride n, which is fine for slot 0
+    rc = eval_experts(m, which, m->s_state, n, t, grad_dev != nullptr, s);
+    if (rc) return rc;
+    PasArgs a = base_pas_args(m, which, n);
+    a.grad = m->s_grad; a.epart = m->s_epart; a.gradC = m->s_gradC; a.fitC = m->s_fitC;
+    if (e_dev || fit_dev) {
+        hipLaunchKernelGGL(k_slot_energy, dim3((n + 3) / 4), dim3(256), 0, s, a, e_dev, fit_dev);
+        HIPCHK(hipGetLastError());
+    }
+    if (grad_dev) {
+        hipLaunchKernelGGL(k_combine_rows, dim3(n), dim3(256), 0, s, a, grad_dev);
+        HIPCHK(hipGetLastError());
+    }
+    return PPDE_OK;
+}
+
+}  // extern "C"
+
+// --------------------------------------------------------------------------------------------
+struct ppde_chains {
+    ppde_model* m = nullptr;
+    ppde_chain_config cfg{};
+    hipStream_t stream = nullptr;
+    int n = 0, T = 0, mu_max = 1, steps_done = 0;
+    bool initialised = false;
+    // device buffers
+    uint8_t *cur = nullptr, *prop = nullptr, *fb_state = nullptr, *cursel = nullptr, *best_state = nullptr,
+            *rtraj = nullptr, *acc_last = nullptr, *tr_acc = nullptr, *tmp_idx = nullptr;
+    float *grad = nullptr, *epart = nullptr, *gradC = nullptr, *fitC = nullptr, *cur_e = nullptr, *cur_f = nullptr,
+          *fb_grad = nullptr, *fb_e = nullptr, *fb_f = nullptr, *logp_fwd = nullptr, *e_hist = nullptr,
+          *f_hist = nullptr, *best_e = nullptr, *best_f = nullptr, *tr_logacc = nullptr;
+    int *flat = nullptr, *Ucur = nullptr, *best_t = nullptr, *tr_flat = nullptr, *tr_U = nullptr, *err_flag = nullptr,
+        *d_it = nullptr, *tmp_dist = nullptr;
+    // graph replay
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t graph_exec = nullptr;
+    int graph_len = 0;
+    std::vector<void*> allocs;
+};
+
+static PasArgs chain_args(const ppde_chains* c) {
+    const ppde_model* m = c->m;
+    PasArgs a = base_pas_args(m, c->cfg.which, c->n);
+    a.pas = c->cfg.pas_length;
+    a.thr = c->cfg.nmut_threshold == 0 ? 0x7fffffff : c->cfg.nmut_threshold;
+    a.paper = c->cfg.paper_results; a.min_pos = c->cfg.min_pos; a.max_pos = c->cfg.max_pos;
+    a.rng_mode = c->cfg.rng_mode; a.reuse = c->cfg.reuse_grad; a.rec_after_reset = c->cfg.record_after_reset;
+    a.random_chain = c->cfg.random_chain; a.mu_max = c->mu_max;
+    a.key.k0 = (uint32_t)c->cfg.seed;
+    a.key.k1 = (uint32_t)(c->cfg.seed >> 32) ^ (uint32_t)(c->cfg.chain_offset >> 32);
+    a.key.chain_lo = (uint32_t)c->cfg.chain_offset;
+    a.cur = c->cur; a.prop = c->prop; a.fb_state = c->fb_state;
+    a.fb_state_stride = c->cfg.paper_results ? m->g.Ls : 0;
+    a.grad = c->grad; a.epart = c->epart; a.gradC = c->gradC; a.fitC = c->fitC;
+    a.cursel = c->cursel; a.cur_e = c->cur_e; a.cur_f = c->cur_f;
+    a.fb_grad = c->fb_grad; a.fb_grad_stride = c->cfg.paper_results ? (size_t)m->g.N : 0;
+    a.fb_e = c->fb_e; a.fb_f = c->fb_f; a.fb_ef_stride = c->cfg.paper_results ? 1 : 0;
+    a.flat = c->flat; a.logp_fwd = c->logp_fwd; a.Ucur = c->Ucur;
+    a.e_hist = c->e_hist; a.f_hist = c->f_hist; a.best_state = c->best_state; a.best_e = c->best_e;
+    a.best_f = c->best_f; a.best_t = c->best_t; a.rtraj = c->rtraj; a.acc_last = c->acc_last;
+    a.tr_flat = c->tr_flat; a.tr_acc = c->tr_acc; a.tr_logacc = c->tr_logacc; a.tr_U = c->tr_U;
+    a.err_flag = c->err_flag;
+    return a;
+}
+
+static EvalTargets chain_targets(const ppde_chains* c, int slot_mode, int slot_fixed) {
+    return EvalTargets{c->grad, c->epart, c->gradC, c->fitC, c->cursel, slot_mode, slot_fixed};
+}
+
+// one iteration of ppde.py:65-153 enqueued on the chains' stream
+static int enqueue_iteration(ppde_chains* c, const int* it_base, int it_local, const int* U, const float* q,
+                             const float* u) {
+    const ppde_model* m = c->m;
+    hipStream_t s = c->stream;
+    const size_t lds = pas_lds_bytes(m->g);
+    int rc;
+    if (!c->cfg.reuse_grad) {   // energy and gradient at the current state (ppde.py:79)
+        rc = eval_experts(m, c->cfg.which, c->cur, c->n, chain_targets(c, 0, 0), 1, s);
+        if (rc) return rc;
+    }
+    PasArgs a = chain_args(c);
+    a.it_base = it_base; a.it_local = it_local; a.U_in = U; a.q_in = q; a.u_in = u;
+    hipLaunchKernelGGL(k_propose, dim3(c->n), dim3(PPDE_BLOCK), lds, s, a);
+    HIPCHK(hipGetLastError());
+    // energy and gradient at the proposal (ppde.py:119)
+    rc = eval_experts(m, c->cfg.which, c->prop, c->n, chain_targets(c, 1, 0), 1, s);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_accept, dim3(c->n), dim3(PPDE_BLOCK), lds, s, a);
+    HIPCHK(hipGetLastError());
+    return PPDE_OK;
+}
+
+extern "C" {
+
+int ppde_chains_create(ppde_chains** out, ppde_model* m, const ppde_chain_config* cfg) {
+    ARGCHK(out && m && cfg, "null argument");
+    ARGCHK(cfg->n_chains >= 1, "need at least one chain");
+    ARGCHK(cfg->max_steps >= 0, "negative max_steps");
+    ARGCHK(cfg->pas_length >= 1 && cfg->pas_length <= 64, "ppde_pas_length out of range");
+    ARGCHK(cfg->nmut_threshold >= 0, "negative nmut_threshold");
+    ARGCHK(cfg->which >= 1 && cfg->which <= 3, "which must be 1, 2 or 3");
+    ARGCHK(cfg->min_pos >= 0 && cfg->max_pos < m->L && cfg->min_pos <= cfg->max_pos, "bad [min_pos, max_pos]");
+    ARGCHK(cfg->rng_mode == 0 || cfg->rng_mode == 1, "rng_mode must be 0 or 1");
+    ARGCHK(cfg->random_chain < cfg->n_chains, "random_chain out of range");
+    ARGCHK(!(cfg->which & 1) || m->has_potts, "Potts expert not set");
+    ARGCHK(!(cfg->which & 2) || m->has_cnn, "supervised expert not set");
+    ARGCHK(cfg->chain_offset + (uint64_t)cfg->n_chains <= 0xffffffffull, "chain_offset + n_chains must fit 32 bits");
+    ARGCHK(pas_lds_bytes(m->g) <= 160 * 1024, "sequence too long for the LDS-resident proposal row");
+    HIPCHK(hipSetDevice(m->device));
+    ppde_chains* c = new ppde_chains();
+    c->m = m; c->cfg = *cfg; c->n = cfg->n_chains; c->T = cfg->max_steps; c->mu_max = 2 * cfg->pas_length - 1;
+    const Geom& g = m->g;
+    const size_t n = c->n, T1 = (size_t)c->T + 1;
+    const int nets = std::max(m->n_nets, 1);
+    bool ok = true;
+    auto A = [&](auto** p, size_t count, bool zero) {
+        if (!ok) return;
+        if (dalloc(p, count) != hipSuccess) { ok = false; return; }
+        c->allocs.push_back((void*)*p);
+        if (zero && hipMemset((void*)*p, 0, std::max<size_t>(count, 1) * sizeof(**p)) != hipSuccess) ok = false;
+    };
+    A(&c->cur, n * g.Ls, true); A(&c->prop, n * g.Ls, true);
+    A(&c->fb_state, (cfg->paper_results ? n : 1) * g.Ls, true);
+    A(&c->cursel, n, true); A(&c->best_state, n * g.L, true); A(&c->rtraj, T1 * g.L, true); A(&c->acc_last, n, true);
+    A(&c->tmp_idx, n * g.L, true); A(&c->tmp_dist, n, true);
+    A(&c->grad, 2 * n * g.N, true); A(&c->epart, 2 * n * std::max(g.Lp, 1), true);
+    if (cfg->which & 2) { A(&c->gradC, 2 * nets * n * g.N, true); A(&c->fitC, 2 * nets * n, true); }
+    A(&c->cur_e, n, true); A(&c->cur_f, n, true);
+    A(&c->fb_grad, (cfg->paper_results ? n : 1) * g.N, true);
+    A(&c->fb_e, cfg->paper_results ? n : 1, true); A(&c->fb_f, cfg->paper_results ? n : 1, true);
+    A(&c->logp_fwd, n * c->mu_max, true); A(&c->flat, n * c->mu_max, true); A(&c->Ucur, n, true);
+    A(&c->e_hist, T1 * n, true); A(&c->f_hist, T1 * n, true);
+    A(&c->best_e, n, true); A(&c->best_f, n, true); A(&c->best_t, n, true);
+    A(&c->err_flag, 1, true); A(&c->d_it, 1, true);
+    if (cfg->trace) {
+        A(&c->tr_flat, (size_t)c->T * c->mu_max * n, true); A(&c->tr_acc, (size_t)c->T * n, true);
+        A(&c->tr_logacc, (size_t)c->T * n, true); A(&c->tr_U, (size_t)c->T * n, true);
+    }
+    if (!ok || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+        for (void* p : c->allocs) hipFree(p);
+        delete c;
+        return fail(PPDE_ERR_HIP, "device allocation failed while creating chains");
+    }
+    *out = c;
+    return PPDE_OK;
+}
+
+int ppde_chains_destroy(ppde_chains* c) {
+    if (!c) return PPDE_OK;
+    hipSetDevice(c->m->device);
+    if (c->stream) hipStreamSynchronize(c->stream);
+    if (c->graph_exec) hipGraphExecDestroy(c->graph_exec);
+    if (c->graph) hipGraphDestroy(c->graph);
+    for (void* p : c->allocs) hipFree(p);
+    if (c->stream) hipStreamDestroy(c->stream);
+    delete c;
+    return PPDE_OK;
+}
+
+int ppde_chains_init(ppde_chains* c, const uint8_t* idx0_dev) {
+    ARGCHK(c && idx0_dev, "null argument");
+    ppde_model* m = c->m;
+    HIPCHK(hipSetDevice(m->device));
+    const Geom& g = m->g;
+    hipStream_t s = c->stream;
+    const int n = c->n;
+    hipLaunchKernelGGL(k_pack_state, dim3((n * g.Ls + 255) / 256), dim3(256), 0, s, idx0_dev, c->cur, n, g.L, g.Ls, g.sh);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemsetAsync(c->cursel, 0, n, s));
+    HIPCHK(hipMemsetAsync(c->err_flag, 0, sizeof(int), s));
+    HIPCHK(hipMemsetAsync(c->d_it, 0, sizeof(int), s));
+    PasArgs a = chain_args(c);
+    int rc;
+    if (c->cfg.reuse_grad || c->cfg.paper_results) {
+        // fallback rows: the wild type (mutation-cap reset) or the initial population (paper_results)
+        const int nf = c->cfg.paper_results ? n : 1;
+        const uint8_t* fstates = c->cfg.paper_results ? c->cur : m->d_wt;
+        if (c->cfg.paper_results) HIPCHK(hipMemcpyAsync(c->fb_state, c->cur, (size_t)n * g.Ls, hipMemcpyDeviceToDevice, s));
+        else HIPCHK(hipMemcpyAsync(c->fb_state, m->d_wt, (size_t)g.Ls, hipMemcpyDeviceToDevice, s));
+        if (c->cfg.reuse_grad) {
+            // evaluate into slot 0 viewed with n = nf (layout [slot][nf][...] only matters within this call)
+            EvalTargets t = chain_targets(c, 0, 0);
+            rc = eval_experts(m, c->cfg.which, fstates, nf, t, 1, s);
+            if (rc) return rc;
+            PasArgs f = a;
+            f.n = nf;
+            hipLaunchKernelGGL(k_combine_rows, dim3(nf), dim3(256), 0, s, f, c->fb_grad);
+            HIPCHK(hipGetLastError());
+            hipLaunchKernelGGL(k_slot_energy, dim3((nf + 3) / 4), dim3(256), 0, s, f, c->fb_e, c->fb_f);
+            HIPCHK(hipGetLastError());
+        }
+    } else {
+        HIPCHK(hipMemcpyAsync(c->fb_state, m->d_wt, (size_t)g.Ls, hipMemcpyDeviceToDevice, s));
+    }
+    // energies (and, when gradients are reused, the gradient) of the initial population -> slot 0
+    rc = eval_experts(m, c->cfg.which, c->cur, n, chain_targets(c, 0, 0), 1, s);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_init_chain, dim3((n + 3) / 4), dim3(256), 0, s, a);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(s));
+    c->steps_done = 0;
+    c->initialised = true;
+    return PPDE_OK;
+}
+
+int ppde_chains_run(ppde_chains* c, int steps, const int32_t* U_dev, const float* q_dev, const float* u_dev,
+                    const int32_t* max_u) {
+    ARGCHK(c && c->initialised, "chains not initialised");
+    ARGCHK(steps >= 0 && c->steps_done + steps <= c->T, "run would exceed max_steps");
+    ppde_model* m = c->m;
+    HIPCHK(hipSetDevice(m->device));
+    const Geom& g = m->g;
+    if (c->cfg.rng_mode == 0) {
+        ARGCHK(steps == 0 || (U_dev && q_dev && u_dev && max_u), "rng_mode 0 needs U, q, u and max_u");
+        size_t qoff = 0;
+        for (int i = 0; i < steps; ++i) {
+            ARGCHK(max_u[i] >= 1 && max_u[i] <= c->mu_max, "max_u out of range");
+            int rc = enqueue_iteration(c, nullptr, c->steps_done + i, U_dev + (size_t)i * c->n,
+                                       q_dev + qoff * c->n * g.N, u_dev + (size_t)i * c->n);
+            if (rc) return rc;
+            qoff += max_u[i];
+        }
+        c->steps_done += steps;
+        return PPDE_OK;
+    }
+    int done = 0;
+    if (c->cfg.use_graph) {
+        const int GL = 20;
+        if (steps >= GL && !c->graph_exec) {
+            HIPCHK(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+            int rc = PPDE_OK;
+            for (int i = 0; i < GL && rc == PPDE_OK; ++i) rc = enqueue_iteration(c, c->d_it, i, nullptr, nullptr, nullptr);
+            if (rc == PPDE_OK) {
+                hipLaunchKernelGGL(k_bump, dim3(1), dim3(1), 0, c->stream, c->d_it, GL);
+            }
+            hipError_t e = hipStreamEndCapture(c->stream, &c->graph);
+            if (rc) return rc;
+            HIPCHK(e);
+            HIPCHK(hipGraphInstantiate(&c->graph_exec, c->graph, nullptr, nullptr, 0));
+            c->graph_len = GL;
+        }
+        if (c->graph_exec && steps >= c->graph_len) {
+            HIPCHK(hipMemsetD32Async((hipDeviceptr_t)c->d_it, c->steps_done, 1, c->stream));
+            while (steps - done >= c->graph_len) {
+                HIPCHK(hipGraphLaunch(c->graph_exec, c->stream));
+                done += c->graph_len;
+            }
+        }
+    }
+    for (; done < steps; ++done) {
+        int rc = enqueue_iteration(c, nullptr, c->steps_done + done, nullptr, nullptr, nullptr);
+        if (rc) return rc;
+    }
+    c->steps_done += steps;
+    return PPDE_OK;
+}
+
+int ppde_chains_sync(ppde_chains* c) {
+    ARGCHK(c, "null chains");
+    HIPCHK(hipSetDevice(c->m->device));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    int err = 0;
+    HIPCHK(hipMemcpy(&err, c->err_flag, sizeof(int), hipMemcpyDeviceToHost));
+    if (err) return fail(PPDE_ERR_NUMERIC, "a proposal row had no finite logit (every move masked out): the categorical is undefined");
+    return PPDE_OK;
+}
+
+int ppde_chains_steps_done(ppde_chains* c) { return c ? c->steps_done : PPDE_ERR_INVALID; }
+
+int ppde_chains_peek(ppde_chains* c, uint8_t* idx, float* energy, float* fitness, uint8_t* accepted, int32_t* dist) {
+    ARGCHK(c && c->initialised, "chains not initialised");
+    int rc = ppde_chains_sync(c);
+    if (rc) return rc;
+    const Geom& g = c->m->g;
+    const int n = c->n;
+    hipStream_t s = c->stream;
+    if (idx) {
+        hipLaunchKernelGGL(k_unpack_state, dim3((n * g.L + 255) / 256), dim3(256), 0, s, c->cur, c->tmp_idx, n, g.L, g.Ls, g.sh);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(idx, c->tmp_idx, (size_t)n * g.L, hipMemcpyDeviceToHost, s));
+    }
+    if (dist) {
+        hipLaunchKernelGGL(k_mut_distance, dim3((n + 3) / 4), dim3(256), 0, s, c->cur, c->m->d_wt, n, g.L, g.Ls, g.sh, c->tmp_dist);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(dist, c->tmp_dist, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, s));
+    }
+    if (energy) HIPCHK(hipMemcpyAsync(energy, c->e_hist + (size_t)c->steps_done * n, n * sizeof(float), hipMemcpyDeviceToHost, s));
+    if (fitness) HIPCHK(hipMemcpyAsync(fitness, c->f_hist + (size_t)c->steps_done * n, n * sizeof(float), hipMemcpyDeviceToHost, s));
+    if (accepted) HIPCHK(hipMemcpyAsync(accepted, c->acc_last, n, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    return PPDE_OK;
+}
+
+int ppde_chains_collect(ppde_chains* c, uint8_t* best_idx, float* best_energy, float* best_fitness, int32_t* best_step,
+                        float* energy_history, float* fitness_history, uint8_t* random_traj) {
+    ARGCHK(c && c->initialised, "chains not initialised");
+    int rc = ppde_chains_sync(c);
+    if (rc) return rc;
+    const Geom& g = c->m->g;
+    const size_t n = c->n, rows = (size_t)c->steps_done + 1;
+    if (best_idx) HIPCHK(hipMemcpy(best_idx, c->best_state, n * g.L, hipMemcpyDeviceToHost));
+    if (best_energy) HIPCHK(hipMemcpy(best_energy, c->best_e, n * sizeof(float), hipMemcpyDeviceToHost));
+    if (best_fitness) HIPCHK(hipMemcpy(best_fitness, c->best_f, n * sizeof(float), hipMemcpyDeviceToHost));
+    if (best_step) HIPCHK(hipMemcpy(best_step, c->best_t, n * sizeof(int), hipMemcpyDeviceToHost));
+    if (energy_history) HIPCHK(hipMemcpy(energy_history, c->e_hist, rows * n * sizeof(float), hipMemcpyDeviceToHost));
+    if (fitness_history) HIPCHK(hipMemcpy(fitness_history, c->f_hist, rows * n * sizeof(float), hipMemcpyDeviceToHost));
+    if (random_traj) {
+        ARGCHK(c->cfg.random_chain >= 0, "no random trajectory was recorded (random_chain = -1)");
+        HIPCHK(hipMemcpy(random_traj, c->rtraj, rows * g.L, hipMemcpyDeviceToHost));
+    }
+    return PPDE_OK;
+}
+
+int ppde_chains_trace(ppde_chains* c, int32_t* flat, uint8_t* accepted, float* log_acc, int32_t* U) {
+    ARGCHK(c && c->cfg.trace, "chains were created without trace");
+    int rc = ppde_chains_sync(c);
+    if (rc) return rc;
+    const size_t n = c->n, t = c->steps_done;
+    if (flat) HIPCHK(hipMemcpy(flat, c->tr_flat, t * c->mu_max * n * sizeof(int), hipMemcpyDeviceToHost));
+    if (accepted) HIPCHK(hipMemcpy(accepted, c->tr_acc, t * n, hipMemcpyDeviceToHost));
+    if (log_acc) HIPCHK(hipMemcpy(log_acc, c->tr_logacc, t * n * sizeof(float), hipMemcpyDeviceToHost));
+    if (U) HIPCHK(hipMemcpy(U, c->tr_U, t * n * sizeof(int), hipMemcpyDeviceToHost));
+    return PPDE_OK;
+}
+
+int ppde_chains_philox_dump(ppde_chains* c, int it, int s, float* q_dev, float* u_dev, int32_t* U_dev) {
+    ARGCHK(c && q_dev && u_dev && U_dev, "null argument");
+    ARGCHK(s >= 0 && s < c->mu_max, "sub-step out of range");
+    HIPCHK(hipSetDevice(c->m->device));
+    PasArgs a = chain_args(c);
+    hipLaunchKernelGGL(k_philox_dump, dim3(c->n), dim3(256), 0, c->stream, a.key, it, s, c->cfg.pas_length, c->n,
+                       c->m->g.N, q_dev, u_dev, U_dev);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return PPDE_OK;
+}
+
+int ppde_chains_time_potts_kernel(ppde_chains* c, int reps, float* avg_us) {
+    ARGCHK(c && c->initialised && avg_us && reps >= 1, "bad argument");
+    ARGCHK(c->cfg.which & 1, "no Potts expert in this energy");
+    HIPCHK(hipSetDevice(c->m->device));
+    hipEvent_t e0, e1;
+    HIPCHK(hipEventCreate(&e0));
+    HIPCHK(hipEventCreate(&e1));
+    // writes the slot that does not hold the current gradient, exactly as the launch inside an iteration does
+    EvalTargets t = chain_targets(c, 1, 0);
+    int rc = launch_potts(c->m, c->cur, c->n, t, c->stream);   // warm
+    if (rc) return rc;
+    HIPCHK(hipEventRecord(e0, c->stream));
+    for (int i = 0; i < reps; ++i) {
+        rc = launch_potts(c->m, c->cur, c->n, t, c->stream);
+        if (rc) return rc;
+    }
+    HIPCHK(hipEventRecord(e1, c->stream));
+    HIPCHK(hipEventSynchronize(e1));
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+    *avg_us = ms * 1000.f / reps;
+    hipEventDestroy(e0);
+    hipEventDestroy(e1);
+    return PPDE_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,217 @@
+"""Energy functions of the path, backed by the HIP library.
+
+Mirrors the reference's interface (ppde/energy.py:71-164):
+    ProteinProductOfExperts(args)   e = dH_potts(x[:, window]) + lamda * fit(x)
+    ProteinSupervised(args)         e = fit(x)
+with .get_energy(x) -> (e, fit), .get_energy_and_grads(x) -> (e, fit, grad_x), .wt_onehot,
+.get_supervised_expert(x), .get_unsupervised_expert(x), .lamda, .to(device).
+
+Inputs are fp32 one-hot tensors [n, L, 20]; they are converted to residue indices on the device and
+everything else happens in the HIP kernels (ppde_amd/csrc). There is no CPU path: a non-HIP device raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+import torch
+
+from . import _hip
+from .encoding import idx_to_onehot
+from .weights import PottsParams, load_cnn_states, load_wt
+
+WHICH_POTTS, WHICH_SUPERVISED, WHICH_POE = 1, 2, 3
+
+
+def _device_index(device):
+    d = torch.device(device)
+    if d.type != "cuda":
+        raise RuntimeError(f"ppde_amd runs on a HIP GPU only (got device {device!r}); there is no CPU fallback")
+    if not torch.cuda.is_available():
+        raise RuntimeError("no HIP device is visible to torch; ppde_amd has no CPU fallback")
+    return d.index if d.index is not None else torch.cuda.current_device()
+
+
+class HipModel:
+    """Owner of a `ppde_model` (include/ppde_hip.h): expert parameters resident on one GPU."""
+
+    def __init__(self, wt_idx, device="cuda"):
+        self.lib = _hip.load()
+        self.device_index = _device_index(device)
+        self.device = torch.device("cuda", self.device_index)
+        self.wt_idx = np.ascontiguousarray(np.asarray(wt_idx, dtype=np.uint8).reshape(-1))
+        self.L = int(self.wt_idx.shape[0])
+        self.handle = C.c_void_p()
+        _hip.check(self.lib.ppde_model_create(C.byref(self.handle), self.device_index, self.L, _hip.ptr(self.wt_idx)))
+        self.has_potts = self.has_cnn = False
+        self.win_start, self.Lp, self.lamda = 0, 0, 0.0
+
+    def close(self):
+        if getattr(self, "handle", None) is not None and self.handle.value:
+            self.lib.ppde_model_destroy(self.handle)
+            self.handle = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_potts(self, J, h, win_start):
+        J = np.ascontiguousarray(J, dtype=np.float32)
+        h = np.ascontiguousarray(h, dtype=np.float32)
+        Lp = int(J.shape[0])
+        if J.shape != (Lp, Lp, 20, 20) or h.shape != (Lp, 20):
+            raise ValueError(f"Potts shapes {J.shape} / {h.shape}; expected [Lp,Lp,20,20] / [Lp,20]")
+        _hip.check(self.lib.ppde_model_set_potts(self.handle, _hip.ptr(J), _hip.ptr(h), Lp, int(win_start)))
+        self.has_potts, self.win_start, self.Lp = True, int(win_start), Lp
+
+    def set_cnn(self, states):
+        """states: list of OnehotCNN state dicts (numpy / tensors) with the reference's parameter names."""
+        g = lambda sd, k: np.ascontiguousarray(np.asarray(sd[k].detach().cpu() if isinstance(sd[k], torch.Tensor) else sd[k],
+                                                          dtype=np.float32))
+        nets = [dict(cw=g(sd, "encoder.weight"), cb=g(sd, "encoder.bias"), lw=g(sd, "embedding.0.weight"),
+                     lb=g(sd, "embedding.0.bias"), dw=g(sd, "decoder.weight").reshape(-1), db=g(sd, "decoder.bias").reshape(-1))
+                for sd in states]
+        Cc, A, K = nets[0]["cw"].shape
+        F = nets[0]["lw"].shape[0]
+        if A != 20:
+            raise ValueError("OnehotCNN must take 20 input channels")
+        for nt in nets:
+            if nt["cw"].shape != (Cc, 20, K) or nt["lw"].shape != (F, Cc) or nt["dw"].shape != (F,):
+                raise ValueError("all networks of the ensemble must share one shape")
+        arr = lambda key: (C.c_void_p * len(nets))(*[nt[key].ctypes.data for nt in nets])
+        self._cnn_keepalive = nets
+        _hip.check(self.lib.ppde_model_set_cnn(self.handle, len(nets), Cc, K, F, arr("cw"), arr("cb"), arr("lw"),
+                                               arr("lb"), arr("dw"), arr("db")))
+        self.has_cnn, self.n_nets = True, len(nets)
+
+    def set_lamda(self, lamda):
+        _hip.check(self.lib.ppde_model_set_lamda(self.handle, float(lamda)))
+        self.lamda = float(lamda)
+
+    @property
+    def wt_hamiltonian(self):
+        v = C.c_float()
+        _hip.check(self.lib.ppde_model_get_wt_hamiltonian(self.handle, C.byref(v)))
+        return v.value
+
+    # ---- stateless evaluations -----------------------------------------------------------------
+    def onehot_to_idx(self, x):
+        """fp32 one-hot [n, L, 20] (any device) -> uint8 [n, L] on the model's device; ValueError if not one-hot."""
+        if x.dim() != 3 or x.shape[1] != self.L or x.shape[2] != 20:
+            raise ValueError(f"expected a one-hot tensor [n, {self.L}, 20], got {tuple(x.shape)}")
+        x = x.detach().to(self.device, torch.float32).contiguous()
+        idx = torch.empty(x.shape[0], self.L, dtype=torch.uint8, device=self.device)
+        with torch.cuda.device(self.device):
+            _hip.check(self.lib.ppde_onehot_to_idx(self.handle, _hip.ptr(x), x.shape[0], _hip.ptr(idx),
+                                                   _hip.current_stream_ptr(self.device)))
+        return idx
+
+    def idx_to_onehot(self, idx):
+        idx = idx.to(self.device, torch.uint8).contiguous()
+        x = torch.empty(idx.shape[0], self.L, 20, dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            _hip.check(self.lib.ppde_idx_to_onehot(self.handle, _hip.ptr(idx), idx.shape[0], _hip.ptr(x),
+                                                   _hip.current_stream_ptr(self.device)))
+        return x
+
+    def energy_grad(self, idx, which, want_grad=True):
+        """idx uint8 [n, L] on the device -> (e [n], fit [n], grad [n, L, 20] or None)."""
+        idx = idx.to(self.device, torch.uint8).contiguous()
+        n = idx.shape[0]
+        e = torch.empty(n, dtype=torch.float32, device=self.device)
+        fit = torch.empty(n, dtype=torch.float32, device=self.device)
+        grad = torch.empty(n, self.L, 20, dtype=torch.float32, device=self.device) if want_grad else None
+        with torch.cuda.device(self.device):
+            _hip.check(self.lib.ppde_energy_grad(self.handle, _hip.ptr(idx), n, int(which), _hip.ptr(e), _hip.ptr(fit),
+                                                 _hip.ptr(grad), _hip.current_stream_ptr(self.device)))
+        return e, fit, grad
+
+
+class PottsWindow:
+    """What callers read off the reference's PottsModel (ppde/nets.py:244-299): index_list, wtseqs, seq_len, ...
+    and the Delta-H evaluation itself."""
+
+    def __init__(self, params, model):
+        self.index_list = params.index_list
+        self.wtseqs = params.wtseqs
+        self.seq_len = params.seq_len
+        self.reg_coef = params.reg_coef
+        self.offset = params.offset
+        self.n_tokens = 20
+        self._model = model
+
+    @property
+    def wt_H(self):
+        return torch.tensor(self._model.wt_hamiltonian)
+
+    def preprocess_onehot(self, x):
+        return x[:, self.index_list[0]:self.index_list[-1] + 1]
+
+    def __call__(self, x_full, delta=True):
+        """Delta-H (or H) of FULL-length one-hot sequences (the window is cut on the device)."""
+        e, _, _ = self._model.energy_grad(self._model.onehot_to_idx(x_full), WHICH_POTTS, want_grad=False)
+        return e if delta else e + self._model.wt_hamiltonian
+
+
+class _HipEnergy(torch.nn.Module):
+    which = WHICH_POE
+
+    def _setup(self, args, with_potts):
+        dataset = os.path.join(args.protein_weights, args.protein)
+        wtseqs, wt_idx = load_wt(dataset)
+        self.model = HipModel(wt_idx[0], getattr(args, "device", "cuda"))
+        self.wt_idx = wt_idx[0]
+        self.wt_onehot = torch.from_numpy(idx_to_onehot(wt_idx)).float().to(self.model.device)
+        if with_potts:
+            params = PottsParams(dataset)
+            self.model.set_potts(params.J, params.h, params.win_start)
+            self.unsupervised_expert = PottsWindow(params, self.model)
+        self.model.set_cnn(load_cnn_states(dataset))
+
+    def to(self, *a, **k):   # parameters live in the HIP model on args.device; nothing to move
+        return self
+
+    def eval(self):
+        return self
+
+    def _eval(self, x, which, want_grad):
+        return self.model.energy_grad(self.model.onehot_to_idx(x), which, want_grad)
+
+    def get_energy(self, x):
+        e, fit, _ = self._eval(x, self.which, False)
+        return e, fit
+
+    def get_energy_and_grads(self, x):
+        return self._eval(x, self.which, True)
+
+    def get_supervised_expert(self, x):
+        return self._eval(x, WHICH_SUPERVISED, False)[1]
+
+
+class ProteinProductOfExperts(_HipEnergy):
+    """Counterpart of ppde/energy.py:71-140 for `--unsupervised_expert potts`."""
+
+    def __init__(self, args):
+        super().__init__()
+        self.lamda = args.energy_lamda
+        self.unsupervised_expert_type = args.unsupervised_expert
+        if args.unsupervised_expert != "potts":
+            raise NotImplementedError(
+                f"unsupervised_expert={args.unsupervised_expert!r}: only the Potts expert is on the HIP path "
+                "(the transformer experts are out of scope, see DESIGN.md)")
+        self._setup(args, with_potts=True)
+        self.model.set_lamda(self.lamda)
+
+    def get_unsupervised_expert(self, x):
+        return self._eval(x, WHICH_POTTS, False)[0]
+
+
+class ProteinSupervised(_HipEnergy):
+    """Counterpart of ppde/energy.py:143-164: energy = predicted fitness."""
+    which = WHICH_SUPERVISED
+
+    def __init__(self, args):
+        super().__init__()
+        self.lamda = 0.0
+        self._setup(args, with_potts=False)

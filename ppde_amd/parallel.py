@@ -1,0 +1,52 @@
+"""Chain sharding across the GPUs of a node.
+
+Chains are independent Markov chains, so the population splits into contiguous blocks, one per rank, with NO
+per-step communication: the device RNG is keyed by the GLOBAL chain index, so a chain's trajectory does not
+depend on how many ranks there are. The only collective is the final population collect (all_gather over
+RCCL/xGMI on GPUs; gloo in the CPU tests).
+"""
+import torch
+import torch.distributed as dist
+
+
+def world():
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
+def shard_range(n, rank, world_size):
+    """Contiguous block [lo, hi) of rank `rank`; the first n % world_size ranks hold one extra chain."""
+    base, extra = divmod(n, world_size)
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+def all_gather_rows(t, n_global, dim=0):
+    """Concatenate per-rank shards (unequal sizes allowed) along `dim` on every rank."""
+    rank, ws = world()
+    if ws == 1:
+        return t
+    sizes = [shard_range(n_global, r, ws) for r in range(ws)]
+    mx = max(hi - lo for lo, hi in sizes)
+    home = t.device
+    if dist.get_backend() == "nccl" and t.device.type != "cuda":   # RCCL moves device memory only
+        t = t.cuda()
+    t = t.movedim(dim, 0).contiguous()
+    pad = torch.zeros((mx,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+    pad[: t.shape[0]] = t
+    bufs = [torch.empty_like(pad) for _ in range(ws)]
+    dist.all_gather(bufs, pad)
+    out = torch.cat([b[: hi - lo] for b, (lo, hi) in zip(bufs, sizes)], 0)
+    return out.movedim(0, dim).to(home)
+
+
+def broadcast_from(t, src):
+    rank, ws = world()
+    if ws > 1:
+        home = t.device
+        if dist.get_backend() == "nccl" and t.device.type != "cuda":
+            t = t.cuda()
+        dist.broadcast(t, src)
+        t = t.to(home)
+    return t

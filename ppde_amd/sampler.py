@@ -1,0 +1,228 @@
+"""PPDE path-auxiliary sampler driven from Python, executed by the HIP library.
+
+`PPDE_PAS` keeps the reference's interface (ppde/protein_samplers/ppde.py:8-192): constructed from the
+argparse namespace (reads ppde_pas_length, nmut_threshold, paper_results) and
+    run(initial_population, num_steps, energy_function, min_pos, max_pos, oracle, log_every=50)
+returns (best_x Tensor[n,L,20], best_energy np[n], best_fitness np[n], energy_history np[T+1,n],
+fitness_history np[T+1,n], random_traj list of T+1 np[L,20]).
+
+Extra, optional attributes on `args` (absent in the reference, defaults keep its behaviour):
+    ppde_rng            'torch' (default): path lengths / race variates / accept uniforms are drawn with torch's
+                        CPU generator in the reference's order, so a run replays the reference's trajectory for the
+                        same torch.manual_seed; 'philox': counter-based device RNG (the fast path).
+    ppde_seed           Philox key (default: args.seed or torch.initial_seed()).
+    ppde_reuse_grad     True (default): energy/gradient of the current state are carried over from the previous
+                        iteration instead of being recomputed (bit-identical results).
+    ppde_use_graph      True (default): replay iterations from a captured hipGraph in philox mode.
+    ppde_cpu_alias      False (default): state histories hold the pre-reset state (reference on cuda);
+                        True reproduces the reference's `--device cpu` aliasing artefact.
+    ppde_shard          False (default). True with torch.distributed initialised: chains are split over ranks
+                        and gathered at the end (one RCCL all_gather); every rank returns the full result.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _hip
+from .base_sampler import BaseSampler
+from .encoding import idx_to_onehot
+from .noise import draw_chunk
+from .parallel import all_gather_rows, broadcast_from, shard_range, world
+
+
+class Chains:
+    """Owner of a `ppde_chains` (include/ppde_hip.h)."""
+
+    def __init__(self, model, n_chains, max_steps, pas_length, nmut_threshold, paper_results, min_pos, max_pos, which,
+                 rng_mode, reuse_grad=True, record_after_reset=False, trace=False, random_chain=-1, use_graph=True,
+                 seed=0, chain_offset=0):
+        self.model, self.lib = model, model.lib
+        self.n, self.T, self.mu_max = int(n_chains), int(max_steps), 2 * int(pas_length) - 1
+        self.cfg = _hip.ChainConfig(
+            n_chains=self.n, max_steps=self.T, pas_length=int(pas_length), nmut_threshold=int(nmut_threshold),
+            paper_results=int(bool(paper_results)), min_pos=int(min_pos), max_pos=int(max_pos), which=int(which),
+            rng_mode=int(rng_mode), reuse_grad=int(bool(reuse_grad)), record_after_reset=int(bool(record_after_reset)),
+            trace=int(bool(trace)), random_chain=int(random_chain), use_graph=int(bool(use_graph)),
+            seed=int(seed) & (2 ** 64 - 1), chain_offset=int(chain_offset))
+        self.handle = C.c_void_p()
+        with torch.cuda.device(model.device):
+            _hip.check(self.lib.ppde_chains_create(C.byref(self.handle), model.handle, C.byref(self.cfg)))
+
+    def close(self):
+        if getattr(self, "handle", None) is not None and self.handle.value:
+            self.lib.ppde_chains_destroy(self.handle)
+            self.handle = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def init(self, idx0):
+        idx0 = idx0.to(self.model.device, torch.uint8).contiguous()
+        assert idx0.shape == (self.n, self.model.L)
+        torch.cuda.current_stream(self.model.device).synchronize()
+        _hip.check(self.lib.ppde_chains_init(self.handle, _hip.ptr(idx0)))
+
+    def run(self, steps, noise=None):
+        """noise = (U int32 [steps,n], q fp32 [sum max_u, n, N], u fp32 [steps,n], max_u list) for rng_mode 0."""
+        if noise is None:
+            _hip.check(self.lib.ppde_chains_run(self.handle, int(steps), None, None, None, None))
+            return
+        U, q, u, mus = noise
+        dev = self.model.device
+        U, q, u = (t.to(dev, non_blocking=False).contiguous() for t in (U, q, u))
+        mu = np.ascontiguousarray(np.asarray(mus, dtype=np.int32))
+        torch.cuda.current_stream(dev).synchronize()
+        _hip.check(self.lib.ppde_chains_run(self.handle, int(steps), _hip.ptr(U), _hip.ptr(q), _hip.ptr(u), _hip.ptr(mu)))
+        _hip.check(self.lib.ppde_chains_sync(self.handle))   # the noise tensors must outlive the kernels
+
+    def sync(self):
+        _hip.check(self.lib.ppde_chains_sync(self.handle))
+
+    @property
+    def steps_done(self):
+        return self.lib.ppde_chains_steps_done(self.handle)
+
+    def peek(self):
+        n, L = self.n, self.model.L
+        idx = np.empty((n, L), np.uint8)
+        e, f = np.empty(n, np.float32), np.empty(n, np.float32)
+        acc, dist = np.empty(n, np.uint8), np.empty(n, np.int32)
+        _hip.check(self.lib.ppde_chains_peek(self.handle, _hip.ptr(idx), _hip.ptr(e), _hip.ptr(f), _hip.ptr(acc), _hip.ptr(dist)))
+        return dict(idx=idx, energy=e, fitness=f, accepted=acc, dist=dist)
+
+    def collect(self):
+        n, L, rows = self.n, self.model.L, self.steps_done + 1
+        out = dict(best_idx=np.empty((n, L), np.uint8), best_energy=np.empty(n, np.float32),
+                   best_fitness=np.empty(n, np.float32), best_step=np.empty(n, np.int32),
+                   energy_history=np.empty((rows, n), np.float32), fitness_history=np.empty((rows, n), np.float32),
+                   random_traj=np.empty((rows, L), np.uint8) if self.cfg.random_chain >= 0 else None)
+        _hip.check(self.lib.ppde_chains_collect(self.handle, *[_hip.ptr(out[k]) for k in (
+            "best_idx", "best_energy", "best_fitness", "best_step", "energy_history", "fitness_history", "random_traj")]))
+        return out
+
+    def trace(self):
+        t, n = self.steps_done, self.n
+        out = dict(flat=np.empty((t, self.mu_max, n), np.int32), accepted=np.empty((t, n), np.uint8),
+                   log_acc=np.empty((t, n), np.float32), U=np.empty((t, n), np.int32))
+        _hip.check(self.lib.ppde_chains_trace(self.handle, *[_hip.ptr(out[k]) for k in ("flat", "accepted", "log_acc", "U")]))
+        return out
+
+    def philox_dump(self, it, s):
+        dev, n, N = self.model.device, self.n, self.model.L * 20
+        q = torch.empty(n, N, device=dev)
+        u = torch.empty(n, device=dev)
+        U = torch.empty(n, dtype=torch.int32, device=dev)
+        torch.cuda.current_stream(dev).synchronize()
+        _hip.check(self.lib.ppde_chains_philox_dump(self.handle, int(it), int(s), _hip.ptr(q), _hip.ptr(u), _hip.ptr(U)))
+        return q, u, U
+
+    def time_potts_kernel(self, reps=200):
+        v = C.c_float()
+        _hip.check(self.lib.ppde_chains_time_potts_kernel(self.handle, int(reps), C.byref(v)))
+        return v.value
+
+
+class PPDE_PAS(BaseSampler):
+    def __init__(self, args):
+        super().__init__()
+        self.ppde_temp = 2  # locally balanced g(t) = sqrt(t)  (ppde.py:11)
+        self.ppde_pas_length = args.ppde_pas_length
+        self.nmut_threshold = args.nmut_threshold
+        self.paper_results = args.paper_results
+        self.rng = getattr(args, "ppde_rng", "torch")
+        if self.rng not in ("torch", "philox"):
+            raise ValueError("ppde_rng must be 'torch' or 'philox'")
+        self.seed = getattr(args, "ppde_seed", None)
+        if self.seed is None:
+            self.seed = getattr(args, "seed", None)
+        self.reuse_grad = getattr(args, "ppde_reuse_grad", True)
+        self.use_graph = getattr(args, "ppde_use_graph", True)
+        self.cpu_alias = getattr(args, "ppde_cpu_alias", False)
+        self.shard = getattr(args, "ppde_shard", False)
+        self.trace = getattr(args, "ppde_trace", False)
+        self.noise_bytes = 96 << 20         # host->device noise is uploaded in chunks of about this size
+        self.last_chains = None
+
+    def approximate_energy_change(self, score_change):
+        return score_change / self.ppde_temp
+
+    def run(self, initial_population, num_steps, energy_function, min_pos, max_pos, oracle, log_every=50):
+        print(min_pos, max_pos)
+        model = getattr(energy_function, "model", None)
+        if model is None or not hasattr(energy_function, "which"):
+            raise TypeError("PPDE_PAS.run needs a ppde_amd energy function (ProteinProductOfExperts / ProteinSupervised); "
+                            "there is no generic torch fallback")
+        n_global, L = int(initial_population.size(0)), int(initial_population.size(1))
+        min_pos, max_pos = int(min_pos), int(max_pos)
+        random_idx = np.random.randint(0, n_global)                       # ppde.py:37 (same numpy RNG consumption)
+        rank, ws = world() if self.shard else (0, 1)
+        lo, hi = shard_range(n_global, rank, ws)
+        n = hi - lo
+        idx0 = model.onehot_to_idx(initial_population)
+        seed = self.seed if self.seed is not None else torch.initial_seed()
+        chains = Chains(model, n, num_steps, self.ppde_pas_length, self.nmut_threshold, self.paper_results, min_pos,
+                        max_pos, energy_function.which, 0 if self.rng == "torch" else 1, self.reuse_grad, self.cpu_alias,
+                        self.trace, random_idx - lo if lo <= random_idx < hi else -1, self.use_graph, seed, lo)
+        self.last_chains = chains
+        chains.init(idx0[lo:hi])
+
+        def gathered(a):
+            return all_gather_rows(torch.as_tensor(a), n_global).numpy() if ws > 1 else np.asarray(a)
+
+        def log(i, first=False):
+            pk = chains.peek()
+            x_now = torch.from_numpy(idx_to_onehot(gathered(pk["idx"]))).float().to(model.device)
+            gt = oracle(x_now).detach().cpu().numpy()
+            fq = np.quantile(gathered(pk["fitness"]), [0.5, 0.9])
+            gq = np.quantile(gt, [0.5, 0.9])
+            eq = np.quantile(gathered(pk["energy"]), [0.5, 0.9])
+            print(f'[Iteration {i}] energy: 50% {eq[0]:.3f}, 90% {eq[1]:.3f}', flush=not first)
+            if first:
+                print(f'[Iteration {i}] pred fit 50% {fq[0]:.3f}, 90% {fq[1]:.3f}')
+                print(f'[Iteration {i}] oracle fit 50% {gq[0]:.3f}, 90% {gq[1]:.3f}')
+                print('')
+            else:
+                print(f'[Iteration {i}] pred 50% {fq[0]:.3f}, 90% {fq[1]:.3f}', flush=True)
+                print(f'[Iteration {i}] oracle 50% {gq[0]:.3f}, 90% {gq[1]:.3f}', flush=True)
+                print(f'   # accepted = {float(gathered(pk["accepted"]).sum())}')
+                print(f'   # dist = {float(gathered(pk["dist"]).astype(np.float32).mean())}')
+                print('', flush=True)
+
+        log(0, first=True)
+        N = L * 20
+        done = 0
+        while done < num_steps:
+            # next iteration index i with i > 0 and (i+1) % log_every == 0  ->  stop after i+1 steps
+            stop = min(num_steps, ((done // log_every) + 1) * log_every) if log_every > 0 else num_steps
+            if stop - done > 0:
+                if self.rng == "torch":
+                    per_it = self.ppde_pas_length * 2 * n * N * 4 + 1
+                    kmax = max(1, int(self.noise_bytes // per_it))
+                    while done < stop:
+                        k = min(kmax, stop - done)
+                        chains.run(k, draw_chunk(k, n_global, N, self.ppde_pas_length, rows=(lo, hi)))
+                        done += k
+                else:
+                    chains.run(stop - done)
+                    done = stop
+            i = done - 1
+            if log_every > 0 and i > 0 and (i + 1) % log_every == 0:
+                log(i)
+        res = chains.collect()
+        dev = initial_population.device
+        best_idx = gathered(res["best_idx"])
+        best_x = torch.from_numpy(idx_to_onehot(best_idx)).float().to(dev)
+        e_hist = all_gather_rows(torch.from_numpy(res["energy_history"]), n_global, dim=1).numpy() if ws > 1 else res["energy_history"]
+        f_hist = all_gather_rows(torch.from_numpy(res["fitness_history"]), n_global, dim=1).numpy() if ws > 1 else res["fitness_history"]
+        if ws > 1:
+            owner = [r for r in range(ws) if shard_range(n_global, r, ws)[0] <= random_idx < shard_range(n_global, r, ws)[1]][0]
+            rt = torch.from_numpy(res["random_traj"]) if res["random_traj"] is not None else torch.zeros(num_steps + 1, L, dtype=torch.uint8)
+            rtraj = broadcast_from(rt, owner).numpy()
+        else:
+            rtraj = res["random_traj"]
+        random_traj = [idx_to_onehot(rtraj[t]).astype(np.float32) for t in range(rtraj.shape[0])]
+        return (best_x, gathered(res["best_energy"]), gathered(res["best_fitness"]), e_hist, f_hist, random_traj)

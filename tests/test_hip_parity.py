@@ -1,0 +1,265 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle and the reference's fixtures.
+
+Tolerances (fp32): energies |d| <= 2e-6 * (|H| + |wt_H| + 1) (H and wt_H are each sums of ~L' terms of O(1) and are
+subtracted), fitness 5e-6, gradients 2e-6 * max(1, lamda); sampled indices, accept bits, best states: exact.
+"""
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import ppde_oracle as orc
+from helpers import GOLDEN, fixture_noise, load, model_from_fixture, oracle_energy
+from ppde_amd import synthetic
+from ppde_amd.encoding import seqs_to_idx
+
+
+def hip_model(J, h, i0, wt_idx, cnn, lamda):
+    from ppde_amd.energy import HipModel
+    m = HipModel(wt_idx, "cuda:0")
+    m.set_potts(J, h, i0)
+    if cnn is not None:
+        m.set_cnn(cnn)
+    m.set_lamda(lamda)
+    return m
+
+
+def e_tol(e, wt_H):
+    return 2e-6 * (np.abs(e) + abs(wt_H) + 1.0) * 4
+
+
+@pytest.mark.parametrize("name", ["ops_toy24_lam5.npz", "ops_pabp_lam5.npz", "ops_pabp_lam0.npz", "ops_toy24_nonsym.npz"])
+def test_energy_grad_vs_reference_fixture(name):
+    fx = load(name)
+    J, h, i0, wt_idx, cnn = model_from_fixture(fx)
+    lam = float(fx["lamda"])
+    m = hip_model(J, h, i0, wt_idx, cnn, lam)
+    idx = torch.as_tensor(fx["idx"]).cuda()
+    wt_H = float(np.ravel(fx["wt_H"])[0])
+    assert abs(m.wt_hamiltonian - wt_H) <= 4e-6 * (abs(wt_H) + 1)
+    e, fit, g = m.energy_grad(idx, 3)
+    assert np.all(np.abs(e.cpu().numpy() - fx["e"]) <= e_tol(fx["e"], wt_H) + 5e-6 * lam)
+    assert np.abs(fit.cpu().numpy() - fx["fit"]).max() <= 5e-6
+    assert np.abs(g.cpu().numpy() - fx["grad"]).max() <= 2e-6 * max(1.0, lam)
+    e1, f1, g1 = m.energy_grad(idx, 1)
+    assert np.all(np.abs(e1.cpu().numpy() - fx["unsupervised"]) <= e_tol(fx["unsupervised"], wt_H))
+    assert float(f1.abs().max()) == 0.0
+    e2, f2, g2 = m.energy_grad(idx, 2)
+    assert np.abs(f2.cpu().numpy() - fx["supervised"]).max() <= 5e-6
+    assert np.abs(e2.cpu().numpy() - fx["supervised"]).max() <= 5e-6
+    assert np.abs(g2.cpu().numpy() - fx["supervised_grad"]).max() <= 2e-6
+    # the wild type's Delta-H is exactly zero, as in the reference
+    e_wt, _, _ = m.energy_grad(torch.as_tensor(wt_idx).reshape(1, -1).cuda(), 1)
+    assert float(e_wt[0]) == 0.0
+
+
+@pytest.mark.parametrize("n", [1, 3, 64, 65, 128, 200, 600])
+def test_energy_grad_vs_oracle_batch_sizes(n):
+    """Ragged batch sizes through every chain-group instantiation; also checks batch-independence bit for bit."""
+    fx = load("ops_pabp_lam5.npz")
+    J, h, i0, wt_idx, cnn = model_from_fixture(fx)
+    m = hip_model(J, h, i0, wt_idx, cnn, 5.0)
+    rng = np.random.default_rng(n)
+    idx = rng.integers(0, 20, size=(n, wt_idx.shape[0])).astype(np.uint8)
+    e, fit, g = m.energy_grad(torch.as_tensor(idx).cuda(), 3)
+    en = oracle_energy(J, h, i0, wt_idx, cnn, 5.0)
+    eo, fo, go = en.energy_grad(torch.as_tensor(idx.astype(np.int64)))
+    wt_H = float(en.potts.wt_H)
+    assert np.all(np.abs(e.cpu().numpy() - eo.numpy()) <= e_tol(eo.numpy(), wt_H) + 2.5e-5)
+    assert np.abs(fit.cpu().numpy() - fo.numpy()).max() <= 5e-6
+    assert np.abs(g.cpu().numpy() - go.numpy()).max() <= 1e-5
+    # a chain's numbers do not depend on which batch it sits in
+    e1, f1, g1 = m.energy_grad(torch.as_tensor(idx[:1]).cuda(), 3)
+    assert torch.equal(e1, e[:1]) and torch.equal(f1, fit[:1]) and torch.equal(g1, g[:1])
+
+
+def test_not_onehot_is_rejected():
+    fx = load("ops_toy24_lam5.npz")
+    J, h, i0, wt_idx, cnn = model_from_fixture(fx)
+    m = hip_model(J, h, i0, wt_idx, cnn, 5.0)
+    x = m.idx_to_onehot(torch.as_tensor(fx["idx"]).cuda())
+    assert torch.equal(m.onehot_to_idx(x).cpu(), torch.as_tensor(fx["idx"]))
+    x[0, 3] = 0.25
+    with pytest.raises(ValueError):
+        m.onehot_to_idx(x)
+
+
+def _chains(m, fx, n, T, rng_mode, **kw):
+    from ppde_amd.sampler import Chains
+    return Chains(m, n, T, int(fx["pas"]), int(fx["nmut"]), bool(fx["paper"]), int(fx["min_pos"]), int(fx["max_pos"]),
+                  3, rng_mode, trace=True, random_chain=int(fx["random_idx"]), **kw)
+
+
+def _feed(ch, noise, n, lo=0, hi=None):
+    for U, q, u in noise:
+        hi_ = hi if hi is not None else n
+        ch.run(1, (U[lo:hi_].to(torch.int32).reshape(1, -1), q[:, lo:hi_].contiguous(), u[lo:hi_].reshape(1, -1), [int(q.shape[0])]))
+
+
+RUNS_Q = sorted(os.path.basename(p) for p in glob.glob(os.path.join(GOLDEN, "run_toy24_*.npz")))
+RUNS_ALL = sorted(os.path.basename(p) for p in glob.glob(os.path.join(GOLDEN, "run_*.npz")))
+
+
+@pytest.mark.parametrize("reuse", [True, False])
+@pytest.mark.parametrize("name", RUNS_Q)
+def test_sampler_replays_reference_trajectory(name, reuse):
+    """HIP path vs the REFERENCE's own recorded run (noise stored in the fixture)."""
+    fx = load(name)
+    J, h, i0, wt_idx, cnn = model_from_fixture(fx)
+    lam, n, T, pas = float(fx["lamda"]), int(fx["n"]), int(fx["T"]), int(fx["pas"])
+    noise, _ = fixture_noise(fx, n, wt_idx.shape[0] * 20, pas, T)
+    m = hip_model(J, h, i0, wt_idx, cnn, lam)
+    ch = _chains(m, fx, n, T, 0, reuse_grad=reuse)
+    ch.init(torch.as_tensor(np.tile(wt_idx, (n, 1))).cuda())
+    _feed(ch, noise, n)
+    tr, res = ch.trace(), ch.collect()
+    U = fx["U"]
+    for t in range(T):
+        for s in range(int(U[t].max())):
+            act = s < U[t]
+            assert np.array_equal(tr["flat"][t, s][act], fx["flat"][t, s][act]), f"draw differs at iteration {t} sub-step {s}"
+    assert np.array_equal(tr["accepted"].astype(bool), fx["accepted"])
+    assert np.abs(res["energy_history"] - fx["energy_history"]).max() <= 2e-5
+    assert np.abs(res["fitness_history"] - fx["fitness_history"]).max() <= 5e-6
+    assert np.array_equal(res["best_idx"], fx["best_idx"])
+    assert np.abs(res["best_energy"] - fx["best_energy"]).max() <= 2e-5
+    assert np.array_equal(res["random_traj"], fx["random_traj"])
+    # the reference's --device cpu aliasing of recorded states
+    ch2 = _chains(m, fx, n, T, 0, reuse_grad=reuse, record_after_reset=True)
+    ch2.init(torch.as_tensor(np.tile(wt_idx, (n, 1))).cuda())
+    _feed(ch2, noise, n)
+    res2 = ch2.collect()
+    assert np.array_equal(res2["best_idx"], fx["best_idx_cpu_alias"])
+    assert np.array_equal(res2["random_traj"], fx["random_traj_cpu_alias"])
+
+
+@pytest.mark.parametrize("name", [r for r in RUNS_ALL if "pabp" in r])
+def test_sampler_vs_oracle_pabp(name):
+    """PABP-size runs: same locally drawn noise into the oracle and the HIP path."""
+    fx = load(name)
+    J, h, i0, wt_idx, cnn = model_from_fixture(fx)
+    lam, n, T, pas = float(fx["lamda"]), int(fx["n"]), int(fx["T"]), int(fx["pas"])
+    L = wt_idx.shape[0]
+    torch.manual_seed(int(fx["seed"]))
+    noise = [orc.draw_noise_torch(n, L * 20, pas) for _ in range(T)]
+    en = oracle_energy(J, h, i0, wt_idx, cnn, lam)
+    kw = dict(num_steps=T, min_pos=int(fx["min_pos"]), max_pos=int(fx["max_pos"]), pas_length=pas,
+              nmut_threshold=int(fx["nmut"]), paper_results=bool(fx["paper"]))
+    ref = orc.run(en, np.tile(wt_idx.astype(np.int64), (n, 1)), wt_idx, lambda t: noise[t], trace=True, **kw)
+    m = hip_model(J, h, i0, wt_idx, cnn, lam)
+    ch = _chains(m, fx, n, T, 0)
+    ch.init(torch.as_tensor(np.tile(wt_idx, (n, 1))).cuda())
+    _feed(ch, noise, n)
+    tr, res = ch.trace(), ch.collect()
+    for t in range(T):
+        U = noise[t][0].numpy()
+        for s in range(int(U.max())):
+            act = s < U
+            assert np.array_equal(tr["flat"][t, s][act], ref["traces"][t]["flat"][s].numpy()[act]), (t, s)
+    assert np.array_equal(tr["accepted"].astype(bool), ref["accepted"].numpy())
+    assert np.abs(res["energy_history"] - ref["energy_history"].numpy()).max() <= 2e-5
+    assert np.array_equal(res["best_idx"], ref["best_idx"].numpy())
+    assert np.array_equal(res["random_traj"], ref["states"][:, int(fx["random_idx"])].numpy())
+
+
+def _philox_setup(n=16, T=12, pas=2, nmut=3, lam=5.0):
+    fx = load("ops_pabp_lam5.npz")
+    J, h, i0, wt_idx, cnn = model_from_fixture(fx)
+    m = hip_model(J, h, i0, wt_idx, cnn, lam)
+    return fx, J, h, i0, wt_idx, cnn, m
+
+
+def test_philox_stream_matches_numpy():
+    from ppde_amd.sampler import Chains
+    fx, J, h, i0, wt_idx, cnn, m = _philox_setup()
+    n, N = 8, wt_idx.shape[0] * 20
+    seed, off = 0x1234567887654321, 40
+    ch = Chains(m, n, 4, 2, 0, False, i0, i0 + J.shape[0] - 1, 1, 1, seed=seed, chain_offset=off)
+    for it, s in [(0, 0), (3, 1), (7, 2)]:
+        q, u, U = ch.philox_dump(it, s)
+        k = np.array([seed & 0xffffffff, seed >> 32], dtype=np.uint32)
+        chain = (off + np.arange(n)).astype(np.uint32)
+        ctr = np.zeros((n, N // 4, 4), dtype=np.uint32)
+        ctr[..., 0] = chain[:, None]; ctr[..., 1] = it; ctr[..., 2] = 2 + s; ctr[..., 3] = np.arange(N // 4)[None]
+        r = orc.philox4x32(ctr, k).reshape(n, N)
+        qe = -np.log(((r >> 9).astype(np.float32) + np.float32(0.5)) * np.float32(2.0 ** -23))
+        assert np.abs(q.cpu().numpy() - qe).max() <= 4e-7 * np.abs(qe).max() + 1e-12
+        c1 = np.zeros((n, 4), dtype=np.uint32); c1[:, 0] = chain; c1[:, 1] = it; c1[:, 2] = 1
+        ue = (orc.philox4x32(c1, k)[:, 0] >> 8).astype(np.float32) * np.float32(2.0 ** -24)
+        assert np.array_equal(u.cpu().numpy(), ue)
+        c0 = np.zeros((n, 4), dtype=np.uint32); c0[:, 0] = chain; c0[:, 1] = it
+        Ue = 1 + ((orc.philox4x32(c0, k)[:, 0].astype(np.uint64) * np.uint64(3)) >> np.uint64(32)).astype(np.int64)
+        assert np.array_equal(U.cpu().numpy().astype(np.int64), Ue)
+
+
+def _philox_run(m, n, T, pas, nmut, paper, i0, Lp, wt_idx, off=0, rows=None, **kw):
+    from ppde_amd.sampler import Chains
+    lo, hi = rows if rows else (0, n)
+    ch = Chains(m, hi - lo, T, pas, nmut, paper, i0, i0 + Lp - 1, 3, 1, trace=True, random_chain=0,
+                seed=99, chain_offset=off + lo, **kw)
+    ch.init(torch.as_tensor(np.tile(wt_idx, (hi - lo, 1))).cuda())
+    ch.run(T)
+    return ch, ch.trace(), ch.collect()
+
+
+def test_philox_mode_vs_oracle_and_invariances():
+    """Device-RNG mode: (a) equals the oracle fed with the device's own noise; (b) identical bits with and without
+    gradient reuse, with and without graph replay, and when the chains are split in two shards."""
+    fx, J, h, i0, wt_idx, cnn, m = _philox_setup()
+    n, T, pas, nmut = 16, 45, 2, 3
+    Lp, L = J.shape[0], wt_idx.shape[0]
+    ch, tr, res = _philox_run(m, n, T, pas, nmut, False, i0, Lp, wt_idx, use_graph=False)
+    noise = []
+    for t in range(T):
+        qs = []
+        for s in range(2 * pas - 1):
+            q, u, U = ch.philox_dump(t, s)
+            qs.append(q.cpu())
+        noise.append((U.cpu().long(), torch.stack(qs, 0), u.cpu()))
+    en = oracle_energy(J, h, i0, wt_idx, cnn, 5.0)
+    ref = orc.run(en, np.tile(wt_idx.astype(np.int64), (n, 1)), wt_idx, lambda t: noise[t], T, i0, i0 + Lp - 1, pas, nmut, False, trace=True)
+    for t in range(T):
+        U = noise[t][0].numpy()
+        assert np.array_equal(tr["U"][t], U)
+        for s in range(int(U.max())):
+            act = s < U
+            assert np.array_equal(tr["flat"][t, s][act], ref["traces"][t]["flat"][s].numpy()[act]), (t, s)
+    assert np.array_equal(tr["accepted"].astype(bool), ref["accepted"].numpy())
+    assert np.abs(res["energy_history"] - ref["energy_history"].numpy()).max() <= 2e-5
+    assert np.array_equal(res["best_idx"], ref["best_idx"].numpy())
+    for kw in (dict(reuse_grad=False, use_graph=False), dict(use_graph=True), dict(reuse_grad=False, use_graph=True)):
+        _, tr2, res2 = _philox_run(m, n, T, pas, nmut, False, i0, Lp, wt_idx, **kw)
+        for k in ("energy_history", "fitness_history", "best_idx", "best_energy", "best_step"):
+            assert np.array_equal(res[k], res2[k]), (kw, k)
+        assert np.array_equal(tr["flat"], tr2["flat"]) and np.array_equal(tr["accepted"], tr2["accepted"])
+    a = _philox_run(m, n, T, pas, nmut, False, i0, Lp, wt_idx, rows=(0, 7))[2]
+    b = _philox_run(m, n, T, pas, nmut, False, i0, Lp, wt_idx, rows=(7, 16))[2]
+    assert np.array_equal(np.concatenate([a["energy_history"], b["energy_history"]], 1), res["energy_history"])
+    assert np.array_equal(np.concatenate([a["best_idx"], b["best_idx"]], 0), res["best_idx"])
+
+
+def test_full_size_properties():
+    """BASELINE config sizes (128 chains, PABP, 1000 steps): properties that need no oracle run."""
+    fx, J, h, i0, wt_idx, cnn, m = _philox_setup()
+    n, T, Lp, L = 128, 300, J.shape[0], wt_idx.shape[0]
+    ch, tr, res = _philox_run(m, n, T, 2, 10, False, i0, Lp, wt_idx)
+    eh = res["energy_history"]
+    assert np.isfinite(eh).all()
+    assert np.array_equal(res["best_energy"], eh.max(0))                        # running best == max over history
+    assert np.array_equal(res["best_step"], eh.argmax(0))                       # first index on ties
+    assert (res["best_idx"] < 20).all()
+    # the recorded best state really has the recorded best energy
+    e, f, _ = m.energy_grad(torch.as_tensor(res["best_idx"]).cuda(), 3, want_grad=False)
+    assert np.array_equal(e.cpu().numpy(), res["best_energy"])
+    assert np.array_equal(f.cpu().numpy(), res["best_fitness"])
+    # a rejected step repeats the previous energy exactly; an accepted one generally changes it
+    acc = tr["accepted"].astype(bool)
+    pk = ch.peek()
+    assert (pk["dist"] < 10).all()                                              # mutation cap enforced after every step
+    same = eh[1:] == eh[:-1]
+    assert same[~acc].mean() > 0.95                                             # (a reset to WT may also change it)
+    assert 0.02 < acc.mean() < 0.98
