@@ -39,6 +39,8 @@ def parse():
                    help="0 (default): evaluate energy+gradient twice per step exactly as the reference does; "
                         "1: carry the current state's gradient over (bit-identical results, half the expert calls)")
     p.add_argument("--nmut", type=int, default=0)
+    p.add_argument("--pas", type=int, default=2, help="ppde_pas_length (reference default 2)")
+    p.add_argument("--streams", type=int, default=1, help="sub-populations run on separate HIP streams")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-seconds", type=float, default=15.0)
     return p.parse_args()
@@ -65,7 +67,7 @@ def cpu_baseline(args, wt, J, h, i0, Lp, cnn, n):
     """The oracle (torch-CPU restatement, pinned to the reference by tests/golden) on this box's host cores."""
     sys.path.insert(0, os.path.join(REPO, "oracle"))
     import ppde_oracle as orc
-    cores = os.cpu_count() or 1
+    cores = min(os.cpu_count() or 1, 16)      # a 1-GPU box's CPU share; torch's intra-op pool beyond that only adds overhead
     torch.set_num_threads(cores)
     lam = 5.0 if cnn is not None else 0.0
     en = orc.EnergyOracle(orc.PottsOracle(J, h, i0, torch.as_tensor(wt.astype(np.int64))),
@@ -78,17 +80,17 @@ def cpu_baseline(args, wt, J, h, i0, Lp, cnn, n):
         noise = {}
         def nz(t):
             if t not in noise:
-                noise[t] = orc.draw_noise_torch(n, L * 20, 2)
+                noise[t] = orc.draw_noise_torch(n, L * 20, args.pas)
             return noise[t]
         t0 = time.perf_counter()
-        orc.run(en, idx0, wt, nz, T, i0, i0 + Lp - 1, 2, args.nmut, False)
+        orc.run(en, idx0, wt, nz, T, i0, i0 + Lp - 1, args.pas, args.nmut, False)
         return time.perf_counter() - t0
 
     t_probe = timed(3)
     T = int(max(5, min(400, args.cpu_seconds / max(t_probe / 3, 1e-4))))
     dt = timed(T)
     return {"value": T / dt, "unit": "MCMC steps/s", "cores": int(torch.get_num_threads()), "kind": "port",
-            "sample": f"{T} iterations of the same workload ({n} chains, pas_length 2, noise drawn with torch's CPU "
+            "sample": f"{T} iterations of the same workload ({n} chains, pas_length {args.pas}, noise drawn with torch's CPU "
                       f"generator as the reference does) through oracle/ppde_oracle.py; {dt:.1f} s"}
 
 
@@ -110,8 +112,8 @@ def main():
     n, L = args.chains, wt.shape[0]
     which = 3 if args.workload == "potts+cnn" else 1
     T = args.warmup + args.steps
-    ch = Chains(m, n, T, 2, args.nmut, False, i0, i0 + Lp - 1, which, 1, reuse_grad=bool(args.reuse_grad),
-                random_chain=0, use_graph=True, seed=1, chain_offset=rank * n)
+    ch = Chains(m, n, T, args.pas, args.nmut, False, i0, i0 + Lp - 1, which, 1, reuse_grad=bool(args.reuse_grad),
+                random_chain=0, use_graph=True, seed=1, chain_offset=rank * n, n_streams=args.streams)
     ch.init(torch.as_tensor(np.tile(wt, (n, 1))).to(device))
 
     def barrier():
@@ -163,10 +165,10 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": "PABP_YEAST Potts product of experts" + (" + supervised CNN (lamda=5)" if cnn else "")
-                                   + f", L=96, L'=80, A=20, {n} chains/GPU, pas_length=2, nmut_threshold={args.nmut}, "
+                                   + f", L=96, L'=80, A=20, {n} chains/GPU, pas_length={args.pas}, nmut_threshold={args.nmut}, "
                                      "device Philox RNG, all chains start at WT",
                        "chains_per_gpu": n, "total_chains": n * world, "parallelism": f"chains sharded x{world}, no per-step collective",
-                       "energy_evaluations_per_step": 1 if args.reuse_grad else 2},
+                       "energy_evaluations_per_step": 1 if args.reuse_grad else 2, "hip_streams": args.streams},
             "chain_steps_per_s": world * n * args.steps / dt,
             "roofline": {"kernel": "potts_energy_grad_kernel", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,

@@ -115,6 +115,9 @@ typedef struct {
     int32_t trace;           /* 1 = keep per-iteration draws / accept bits / log-acceptance for tests */
     int32_t random_chain;    /* local index of the chain whose trajectory is kept (ppde.py:37,47,142), or -1 */
     int32_t use_graph;       /* 1 = replay iterations from a captured hipGraph (rng_mode 1 only) */
+    int32_t n_streams;       /* >1: the chains are cut into this many sub-populations whose iterations run on
+                                separate HIP streams and overlap on the GPU (chains are independent, results
+                                are unchanged); 0/1 = one stream. rng_mode 1 only. */
     uint64_t seed;           /* Philox key */
     uint64_t chain_offset;   /* global index of local chain 0: results do not depend on the sharding */
 } ppde_chain_config;

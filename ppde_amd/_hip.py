@@ -20,7 +20,7 @@ class PpdeHipError(RuntimeError):
 class ChainConfig(C.Structure):
     _fields_ = [(k, C.c_int32) for k in (
         "n_chains", "max_steps", "pas_length", "nmut_threshold", "paper_results", "min_pos", "max_pos", "which",
-        "rng_mode", "reuse_grad", "record_after_reset", "trace", "random_chain", "use_graph")] + \
+        "rng_mode", "reuse_grad", "record_after_reset", "trace", "random_chain", "use_graph", "n_streams")] + [("_pad", C.c_int32)] + \
         [("seed", C.c_uint64), ("chain_offset", C.c_uint64)]
 
 

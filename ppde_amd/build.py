@@ -24,15 +24,16 @@ def is_stale():
     return any(os.path.getmtime(d) > t for d in DEPS)
 
 
-def build(force=False, verbose=False, extra=()):
-    if not force and not is_stale():
+def build(force=False, verbose=False, extra=(), out=None):
+    out = out or OUT
+    if out == OUT and not force and not is_stale():
         return OUT
     cmd = [hipcc(), "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-shared", "-fno-fast-math",
-           "-ffp-contract=off", "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-Wl,-rpath,/opt/rocm/lib", *extra, SRC, "-o", OUT]
+           "-ffp-contract=off", "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-Wl,-rpath,/opt/rocm/lib", *extra, SRC, "-o", out]
     if verbose:
         print(" ".join(cmd))
     subprocess.run(cmd, check=True)
-    return OUT
+    return out
 
 
 if __name__ == "__main__":

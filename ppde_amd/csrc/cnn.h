@@ -32,7 +32,8 @@ struct CnnArgs {
     float* fitC;                    // [slots][nets][n]
     const uint8_t* cursel;
     int slot_mode, slot_fixed;
-    int n;
+    int n;                          // chains in the buffers (slot stride)
+    int b_off;                      // first chain of this launch
     int want_grad;
     float scale;                    // upstream gradient of every network output: lamda / nets (or 1 / nets)
     Geom g;
@@ -67,7 +68,7 @@ __device__ __forceinline__ void fma_block(float (&acc)[CNN_TB], const float* A, 
 __global__ __launch_bounds__(256) void k_cnn(CnnArgs a) {
     extern __shared__ unsigned char smem_raw[];
     const Geom g = a.g;
-    const int b = blockIdx.x, ni = blockIdx.y, tid = threadIdx.x;
+    const int b = a.b_off + blockIdx.x, ni = blockIdx.y, tid = threadIdx.x;
     const CnnNet net = a.net[ni];
     const int T = a.T, CP = a.CP, F = a.F, J = a.J, K = a.K;
     const int AS = CP + 4;                                     // LDS row stride of h1 / dH1
@@ -126,7 +127,7 @@ __global__ __launch_bounds__(256) void k_cnn(CnnArgs a) {
     {
         float s = 0.f;
         for (int f = tid; f < F; f += 256) s += net.wd[f] * sM[f];
-        const float tot = block_sum(s, red, phase);
+        const float tot = block_sum<4>(s, red, phase);
         if (tid == 0) a.fitC[((size_t)slot * a.n_nets + ni) * a.n + b] = tot + net.bd;
     }
     if (!a.want_grad) return;

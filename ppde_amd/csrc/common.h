@@ -5,8 +5,23 @@
 #include <stdint.h>
 
 #define PPDE_A 20
-#define PPDE_BLOCK 256           // threads per workgroup of the chain-parallel kernels (4 waves)
+#define PPDE_BLOCK 512           // threads per workgroup of the chain-parallel kernels (8 waves, 2 per SIMD)
+#define PPDE_NW (PPDE_BLOCK / 64)
 #define PPDE_EPS 1.1920928955078125e-07f   // 2^-23, clamp floor of torch.distributions.utils.clamp_probs
+
+// Diagnostic build only (-DPPDE_STAMPS, scripts/stamp_kernels.py): wave 0 of the first workgroup of a launch
+// stores s_memtime at named points into a buffer nothing else reads. The shipped library executes no stamp.
+#ifdef PPDE_STAMPS
+#define PPDE_STAMP(buf, slot, cond)                                                          \
+    do {                                                                                     \
+        if ((buf) && (cond) && threadIdx.x == 0) {                                           \
+            (buf)[2 * (slot)] = __builtin_amdgcn_s_memtime();                                \
+            (buf)[2 * (slot) + 1] = __builtin_amdgcn_s_memrealtime();                        \
+        }                                                                                    \
+    } while (0)
+#else
+#define PPDE_STAMP(buf, slot, cond) do { } while (0)
+#endif
 
 // Problem geometry shared by every kernel (passed by value).
 struct Geom {
@@ -19,61 +34,168 @@ struct Geom {
     int NC;       // window chunks: the padded window is 4 parts x NC chunks x 4 residues
 };
 
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) v += __shfl_xor(v, o);
-    return v;
+// ---- wavefront reductions on DPP (no LDS round trips): two quad permutes, row_half_mirror, row_mirror
+// leave every 16-lane row holding its row total; the four row totals are then read with v_readlane and
+// combined as (r0 + r1) + (r2 + r3). Each step combines a lane with its mirror image, so both partners
+// compute the same (commutative) result and every lane ends with the same bits.
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
 }
-__device__ __forceinline__ double wave_sum_d(double v) {
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) v += __shfl_xor(v, o);
-    return v;
+template <int CTRL>
+__device__ __forceinline__ int dpp_i(int v) {
+    return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true);
 }
-__device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) v = fmaxf(v, __shfl_xor(v, o));
-    return v;
+#define DPP_XOR1 0xB1        // quad_perm [1,0,3,2]
+#define DPP_XOR2 0x4E        // quad_perm [2,3,0,1]
+#define DPP_HALF_MIRROR 0x141
+#define DPP_MIRROR 0x140
+__device__ __forceinline__ float lane_f(float v, int lane) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
 }
 
-// Block-wide reductions for PPDE_BLOCK threads. `scratch` holds 2 x 4 floats; `phase` alternates the half
-// in use so that ONE barrier per reduction suffices. Every thread returns the same value; the tree
-// (lane butterfly, then waves 0..3 in order) does not depend on the data or the launch.
+__device__ __forceinline__ float wave_sum(float v) {
+    v += dpp_f<DPP_XOR1>(v);
+    v += dpp_f<DPP_XOR2>(v);
+    v += dpp_f<DPP_HALF_MIRROR>(v);
+    v += dpp_f<DPP_MIRROR>(v);
+    return (lane_f(v, 0) + lane_f(v, 16)) + (lane_f(v, 32) + lane_f(v, 48));
+}
+template <int CTRL>
+__device__ __forceinline__ double dpp_d(double v) {
+    const long long b = __builtin_bit_cast(long long, v);
+    const int lo = dpp_i<CTRL>((int)(b & 0xffffffffll)), hi = dpp_i<CTRL>((int)(b >> 32));
+    return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
+}
+__device__ __forceinline__ double lane_d(double v, int lane) {
+    const long long b = __builtin_bit_cast(long long, v);
+    const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffll), lane), hi = __builtin_amdgcn_readlane((int)(b >> 32), lane);
+    return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+    v += dpp_d<DPP_XOR1>(v);
+    v += dpp_d<DPP_XOR2>(v);
+    v += dpp_d<DPP_HALF_MIRROR>(v);
+    v += dpp_d<DPP_MIRROR>(v);
+    return (lane_d(v, 0) + lane_d(v, 16)) + (lane_d(v, 32) + lane_d(v, 48));
+}
+// wave-wide maximum of a 64-bit key (used as (race value bits << 32) | ~index: larger value wins, then the
+// smaller index)
+template <int CTRL>
+__device__ __forceinline__ unsigned long long dpp_u64(unsigned long long v) {
+    const int lo = dpp_i<CTRL>((int)(v & 0xffffffffull)), hi = dpp_i<CTRL>((int)(v >> 32));
+    return ((unsigned long long)(unsigned int)hi << 32) | (unsigned int)lo;
+}
+__device__ __forceinline__ unsigned long long umax64(unsigned long long a, unsigned long long b) { return a > b ? a : b; }
+__device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v) {
+    v = umax64(v, dpp_u64<DPP_XOR1>(v));
+    v = umax64(v, dpp_u64<DPP_XOR2>(v));
+    v = umax64(v, dpp_u64<DPP_HALF_MIRROR>(v));
+    v = umax64(v, dpp_u64<DPP_MIRROR>(v));
+    unsigned long long r = 0;
+#pragma unroll
+    for (int l = 0; l < 64; l += 16) {
+        const unsigned int lo = (unsigned int)__builtin_amdgcn_readlane((int)(v & 0xffffffffull), l);
+        const unsigned int hi = (unsigned int)__builtin_amdgcn_readlane((int)(v >> 32), l);
+        r = umax64(r, ((unsigned long long)hi << 32) | lo);
+    }
+    return r;
+}
+__device__ __forceinline__ float wave_max(float v) {
+    v = fmaxf(v, dpp_f<DPP_XOR1>(v));
+    v = fmaxf(v, dpp_f<DPP_XOR2>(v));
+    v = fmaxf(v, dpp_f<DPP_HALF_MIRROR>(v));
+    v = fmaxf(v, dpp_f<DPP_MIRROR>(v));
+    return fmaxf(fmaxf(lane_f(v, 0), lane_f(v, 16)), fmaxf(lane_f(v, 32), lane_f(v, 48)));
+}
+
+// Block-wide reductions for NW waves. `scratch` holds 2 x NW floats; `phase` alternates the half in use so
+// that ONE barrier per reduction suffices. Every thread returns the same value; the tree (lane mirror steps,
+// rows, then waves pairwise in index order) does not depend on the data or on the launch.
+template <int NW>
+__device__ __forceinline__ float tree_sum(const float* s) {
+    if constexpr (NW == 1) return s[0];
+    else return tree_sum<NW / 2>(s) + tree_sum<NW / 2>(s + NW / 2);
+}
+template <int NW>
+__device__ __forceinline__ float tree_max(const float* s) {
+    if constexpr (NW == 1) return s[0];
+    else return fmaxf(tree_max<NW / 2>(s), tree_max<NW / 2>(s + NW / 2));
+}
+template <int NW>
 __device__ __forceinline__ float block_sum(float v, float* scratch, int& phase) {
     v = wave_sum(v);
-    float* s = scratch + 4 * (phase & 1);
+    float* s = scratch + NW * (phase & 1);
     if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = v;
     __syncthreads();
     phase++;
-    return (s[0] + s[1]) + (s[2] + s[3]);
+    return tree_sum<NW>(s);
 }
+template <int NW>
 __device__ __forceinline__ float block_max(float v, float* scratch, int& phase) {
     v = wave_max(v);
-    float* s = scratch + 4 * (phase & 1);
+    float* s = scratch + NW * (phase & 1);
     if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = v;
     __syncthreads();
     phase++;
-    return fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3]));
+    return tree_max<NW>(s);
 }
 
 // arg-max of (value, index) with the smaller index winning ties (what argmax over a row returns).
 __device__ __forceinline__ void argmax_combine(float& v, int& i, float ov, int oi) {
     if (ov > v || (ov == v && oi < i)) { v = ov; i = oi; }
 }
-__device__ __forceinline__ void block_argmax(float& v, int& i, float* scratch_v, int* scratch_i, int& phase) {
+template <int CTRL>
+__device__ __forceinline__ void argmax_dpp(float& v, int& i) {
+    const float ov = dpp_f<CTRL>(v);
+    const int oi = dpp_i<CTRL>(i);
+    argmax_combine(v, i, ov, oi);
+}
+// wave-wide arg-max carrying two payloads (probability of the winner, letter it replaces); every lane ends
+// with the winner's tuple
+template <int CTRL>
+__device__ __forceinline__ void argmax_p_dpp(float& v, int& i, float& p, int& o) {
+    const float ov = dpp_f<CTRL>(v), op = dpp_f<CTRL>(p);
+    const int oi = dpp_i<CTRL>(i), oo = dpp_i<CTRL>(o);
+    if (ov > v || (ov == v && oi < i)) { v = ov; i = oi; p = op; o = oo; }
+}
+__device__ __forceinline__ void wave_argmax_p(float& v, int& i, float& p, int& o) {
+    argmax_p_dpp<DPP_XOR1>(v, i, p, o);
+    argmax_p_dpp<DPP_XOR2>(v, i, p, o);
+    argmax_p_dpp<DPP_HALF_MIRROR>(v, i, p, o);
+    argmax_p_dpp<DPP_MIRROR>(v, i, p, o);
+    float bv = lane_f(v, 0), bp = lane_f(p, 0);
+    int bi = __builtin_amdgcn_readlane(i, 0), bo = __builtin_amdgcn_readlane(o, 0);
 #pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        float ov = __shfl_xor(v, o);
-        int oi = __shfl_xor(i, o);
-        argmax_combine(v, i, ov, oi);
+    for (int r = 16; r < 64; r += 16) {
+        const float ov = lane_f(v, r);
+        const int oi = __builtin_amdgcn_readlane(i, r);
+        if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; bp = lane_f(p, r); bo = __builtin_amdgcn_readlane(o, r); }
     }
-    float* sv = scratch_v + 4 * (phase & 1);
-    int* si = scratch_i + 4 * (phase & 1);
+    v = bv; i = bi; p = bp; o = bo;
+}
+
+template <int NW>
+__device__ __forceinline__ void block_argmax(float& v, int& i, float* scratch_v, int* scratch_i, int& phase) {
+    argmax_dpp<DPP_XOR1>(v, i);
+    argmax_dpp<DPP_XOR2>(v, i);
+    argmax_dpp<DPP_HALF_MIRROR>(v, i);
+    argmax_dpp<DPP_MIRROR>(v, i);
+    {
+        float bv = lane_f(v, 0);
+        int bi = __builtin_amdgcn_readlane(i, 0);
+#pragma unroll
+        for (int r = 16; r < 64; r += 16) argmax_combine(bv, bi, lane_f(v, r), __builtin_amdgcn_readlane(i, r));
+        v = bv; i = bi;
+    }
+    float* sv = scratch_v + NW * (phase & 1);
+    int* si = scratch_i + NW * (phase & 1);
     if ((threadIdx.x & 63) == 0) { sv[threadIdx.x >> 6] = v; si[threadIdx.x >> 6] = i; }
     __syncthreads();
     phase++;
     v = sv[0]; i = si[0];
 #pragma unroll
-    for (int w = 1; w < 4; ++w) argmax_combine(v, i, sv[w], si[w]);
+    for (int w = 1; w < NW; ++w) argmax_combine(v, i, sv[w], si[w]);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -14,7 +14,8 @@
 
 struct PasArgs {
     Geom g;
-    int n;
+    int n;                      // chains in the buffers
+    int b_off;                  // first chain of this launch (sub-population)
     // model
     const uint8_t* wt;          // wild-type row in state layout [Ls]
     float wt_H, lamda;
@@ -65,70 +66,35 @@ struct PasArgs {
     float* tr_logacc;           // [T][n]
     int* tr_U;                  // [T][n]
     int* err_flag;
+    unsigned long long* dbg;    // stamp buffer (diagnostic build)
 };
 
+// LDS of a chain workgroup: the gradient row (float4[N/4]), the letters of the start state and of the wild
+// type, and two small exchange areas for the two reductions of a sub-step.
 struct RowLds {
-    float4* G;      // gradient row        [N/4]
-    float4* Z;      // logits              [N/4]
-    float4* P;      // exp / probabilities [N/4]
-    float* Gc;      // gradient at the current letter [L]
-    uint8_t* St;    // letters of the working state   [L]
-    uint8_t* Wt;    // wild-type letters              [L]
-    float* red;     // 8 floats
-    int* redi;      // 8 ints
+    float4* G;      // gradient row [N/4]
+    float* xa;      // exchange A: NW x (max, sum)
+    float* xb;      // exchange B: NW x 8 floats (sum, race value, index, prob, replaced letter)
+    int* mv;        // moves of the current path: (residue, new letter) pairs [2 * 128]
+    uint8_t* St;    // letters of the start state [L]
+    uint8_t* Wt;    // wild-type letters         [L]
 };
 
 __device__ __forceinline__ RowLds carve_lds(unsigned char* base, const Geom& g) {
     RowLds r;
-    const int n4 = g.N / 4;
     r.G = (float4*)base;
-    r.Z = r.G + n4;
-    r.P = r.Z + n4;
-    r.Gc = (float*)(r.P + n4);
-    r.red = r.Gc + ((g.L + 3) & ~3);
-    r.redi = (int*)(r.red + 8);
-    r.St = (uint8_t*)(r.redi + 8);
+    r.xa = (float*)(r.G + g.N / 4);
+    r.xb = r.xa + 2 * PPDE_NW;
+    r.mv = (int*)(r.xb + 8 * PPDE_NW);
+    r.St = (uint8_t*)(r.mv + 256);
     r.Wt = r.St + ((g.L + 15) & ~15);
     return r;
 }
 __host__ __device__ inline size_t pas_lds_bytes(const Geom& g) {
-    return (size_t)3 * g.N * 4 + (size_t)((g.L + 3) & ~3) * 4 + 64 + 2 * (size_t)((g.L + 15) & ~15);
+    return (size_t)g.N * 4 + 10 * PPDE_NW * 4 + 1024 + 2 * (size_t)((g.L + 15) & ~15);
 }
 
 __device__ __forceinline__ float clampp(float p) { return fminf(fmaxf(p, PPDE_EPS), 1.0f - PPDE_EPS); }
-
-// Given logits in lds.Z and their maximum m, run  z - logsumexp(z) -> softmax -> clamp -> renormalise.
-// Leaves the clamped (not yet renormalised) probabilities in lds.P and returns their sum S3, so that
-// p_hat[e] = P[e] / S3.
-__device__ __forceinline__ float normalise_row(const RowLds& lds, int n4, float m, int& phase) {
-    const int tid = threadIdx.x;
-    float s = 0.f;
-    for (int g4 = tid; g4 < n4; g4 += PPDE_BLOCK) {
-        float4 z = lds.Z[g4];
-        s += expf(z.x - m); s += expf(z.y - m); s += expf(z.z - m); s += expf(z.w - m);
-    }
-    const float S1 = block_sum(s, lds.red, phase);
-    const float lse = logf(S1) + m;
-    const float mp = m - lse;                       // max of the shifted logits
-    s = 0.f;
-    for (int g4 = tid; g4 < n4; g4 += PPDE_BLOCK) {
-        float4 z = lds.Z[g4], e;
-        e.x = expf((z.x - lse) - mp); e.y = expf((z.y - lse) - mp);
-        e.z = expf((z.z - lse) - mp); e.w = expf((z.w - lse) - mp);
-        lds.P[g4] = e;
-        s += e.x; s += e.y; s += e.z; s += e.w;
-    }
-    const float S2 = block_sum(s, lds.red, phase);
-    const float inv = 1.0f / S2;
-    s = 0.f;
-    for (int g4 = tid; g4 < n4; g4 += PPDE_BLOCK) {
-        float4 e = lds.P[g4];
-        e.x = clampp(e.x * inv); e.y = clampp(e.y * inv); e.z = clampp(e.z * inv); e.w = clampp(e.w * inv);
-        lds.P[g4] = e;
-        s += e.x; s += e.y; s += e.z; s += e.w;
-    }
-    return block_sum(s, lds.red, phase);
-}
 
 // Gradient row of one chain = Potts row + the CNN networks' rows (summed in this fixed order), or one
 // pre-combined fallback row.
@@ -145,21 +111,6 @@ __device__ __forceinline__ float4 row_value(const RowSrc& r, int g4) {
     return r.p ? add4(v, r.p[g4]) : v;
 }
 
-// Load one chain's gradient row and working state into LDS and derive Gc.
-__device__ __forceinline__ void load_row(const RowLds& lds, const Geom& g, const RowSrc& src,
-                                         const uint8_t* state_row, const uint8_t* wt_row) {
-    const int tid = threadIdx.x, n4 = g.N / 4;
-    for (int g4 = tid; g4 < n4; g4 += PPDE_BLOCK) lds.G[g4] = row_value(src, g4);
-    for (int l = tid; l < g.L; l += PPDE_BLOCK) {
-        lds.St[l] = state_row[g.sh + l];
-        lds.Wt[l] = wt_row[g.sh + l];
-    }
-    __syncthreads();
-    const float* G = (const float*)lds.G;
-    for (int l = tid; l < g.L; l += PPDE_BLOCK) lds.Gc[l] = G[l * 20 + lds.St[l]];
-    __syncthreads();
-}
-
 __device__ __forceinline__ RowSrc slot_row(const PasArgs& a, int slot, int b) {
     RowSrc r;
     r.nc = 0;
@@ -172,7 +123,7 @@ __device__ __forceinline__ RowSrc slot_row(const PasArgs& a, int slot, int b) {
     return r;
 }
 __device__ __forceinline__ RowSrc current_grad_row(const PasArgs& a, int b) {
-    const int sel = a.cursel[b];
+    const int sel = a.reuse ? (int)a.cursel[b] : 0;   // without reuse the current gradient is always re-evaluated into slot 0
     if (sel == 2) {
         RowSrc r;
         r.nc = 0;
@@ -186,99 +137,204 @@ __device__ __forceinline__ int iteration_of(const PasArgs& a) {
     return (a.it_base ? *a.it_base : 0) + a.it_local;
 }
 
-__device__ __forceinline__ int block_count(bool pred, const RowLds& lds, int& phase) {
-    return (int)block_sum(pred ? 1.f : 0.f, lds.red, phase);   // exact: counts are far below 2^24
+// Per-thread view of the row: thread t owns the 4-logit groups g4 = t + r*PPDE_BLOCK (r < GPT). A group lies
+// inside one residue l = g4 / 5 (letters 4*(g4 % 5) .. +3), so the thread tracks that residue's current and
+// wild-type letter in registers and no shared state changes during the sub-steps.
+template <int GPT>
+struct RowRegs {
+    float4 gv[GPT];
+    int l[GPT], kb[GPT];
+    int cur[GPT], wt[GPT];
+    bool valid[GPT];
+};
+
+// Stage the gradient row and the two letter rows in LDS, then fill the per-thread registers.
+template <int GPT>
+__device__ __forceinline__ void load_row(const RowLds& lds, const Geom& g, const RowSrc& src, const uint8_t* state_row,
+                                         const uint8_t* wt_row, RowRegs<GPT>& R) {
+    const int tid = threadIdx.x, n4 = g.N / 4;
+#pragma unroll
+    for (int r = 0; r < GPT; ++r) {
+        const int g4 = tid + r * PPDE_BLOCK;
+        R.valid[r] = g4 < n4;
+        R.l[r] = R.valid[r] ? g4 / 5 : 0;
+        R.kb[r] = (g4 - 5 * R.l[r]) * 4;
+        R.gv[r] = R.valid[r] ? row_value(src, g4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        if (R.valid[r]) lds.G[g4] = R.gv[r];
+    }
+    for (int l = tid; l < g.L; l += PPDE_BLOCK) {
+        lds.St[l] = state_row[g.sh + l];
+        lds.Wt[l] = wt_row[g.sh + l];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < GPT; ++r) {
+        R.cur[r] = lds.St[R.l[r]];
+        R.wt[r] = lds.Wt[R.l[r]];
+    }
+}
+
+// number of residues where the staged state differs from the wild type (every wave computes it for itself)
+__device__ __forceinline__ int wave_mut_count(const RowLds& lds, int L) {
+    float c = 0.f;
+    for (int l = threadIdx.x & 63; l < L; l += 64) c += (lds.St[l] != lds.Wt[l]) ? 1.f : 0.f;
+    return (int)wave_sum(c);
+}
+
+// ---- reduction 1 of a sub-step: logits z (registers) -> (m, S1) with m = max z, S1 = sum exp(z - m).
+// Each wave reduces against its own maximum; the NW (max, sum) pairs are merged after ONE barrier as
+// S1 = sum_w s_w * exp(m_w - m) by lanes 0..NW-1 of every wave (same tree everywhere).
+template <int GPT>
+__device__ __forceinline__ void row_max_sumexp(const RowLds& lds, const float4 (&z)[GPT], const bool (&valid)[GPT],
+                                               float& m, float& S1) {
+    float lm = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < GPT; ++r)
+        if (valid[r]) lm = fmaxf(fmaxf(lm, fmaxf(z[r].x, z[r].y)), fmaxf(z[r].z, z[r].w));
+    const float mw = wave_max(lm);
+    float s = 0.f;
+    if (mw != -INFINITY) {
+#pragma unroll
+        for (int r = 0; r < GPT; ++r)
+            if (valid[r]) { s += expf(z[r].x - mw); s += expf(z[r].y - mw); s += expf(z[r].z - mw); s += expf(z[r].w - mw); }
+    }
+    const float sw = wave_sum(s);
+    const int lane = threadIdx.x & 63;
+    if (lane == 0) { lds.xa[2 * (threadIdx.x >> 6)] = mw; lds.xa[2 * (threadIdx.x >> 6) + 1] = sw; }
+    __syncthreads();
+    const float mj = lane < PPDE_NW ? lds.xa[2 * (lane & (PPDE_NW - 1))] : -INFINITY;
+    const float sj = lane < PPDE_NW ? lds.xa[2 * (lane & (PPDE_NW - 1)) + 1] : 0.f;
+    m = wave_max(mj);
+    const float term = (mj == -INFINITY) ? 0.f : sj * expf(mj - m);
+    S1 = wave_sum(term);
+}
+
+// logits of one 4-letter group of residue l: (g - g[current letter]) / 2 with the forward masks
+__device__ __forceinline__ float4 forward_logits(const PasArgs& a, const float* G, float4 gv, int l, int kb, int cur, int wt,
+                                                 bool capped) {
+    const float gc = G[l * 20 + cur];
+    float4 z = make_float4((gv.x - gc) * 0.5f, (gv.y - gc) * 0.5f, (gv.z - gc) * 0.5f, (gv.w - gc) * 0.5f);
+    const bool outside = (l < a.min_pos) | (l > a.max_pos);
+    // capped chains may only move a mutated residue back to its wild-type letter (ppde/utils.py:17-28)
+    const bool revertible = capped & (cur != wt);
+    const int kw = wt - kb;
+    if (outside | (capped & !(revertible & (kw == 0)))) z.x = -INFINITY;
+    if (outside | (capped & !(revertible & (kw == 1)))) z.y = -INFINITY;
+    if (outside | (capped & !(revertible & (kw == 2)))) z.z = -INFINITY;
+    if (outside | (capped & !(revertible & (kw == 3)))) z.w = -INFINITY;
+    return z;
 }
 
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(PPDE_BLOCK) void k_propose(PasArgs a) {
-    extern __shared__ unsigned char smem_raw[];
+// The forward path of one iteration (ppde.py:67-116). Expects lds.G / lds.St / lds.Wt staged and visible, R
+// holding the current letters, `dist` = mutation count of that state.
+template <int GPT>
+__device__ __forceinline__ void propose_body(const PasArgs& a, const RowLds& lds, RowRegs<GPT>& R, int b, int it, int dist,
+                                             bool stamp) {
     const Geom g = a.g;
-    const RowLds lds = carve_lds(smem_raw, g);
-    const int b = blockIdx.x, tid = threadIdx.x, n4 = g.N / 4;
-    const int it = iteration_of(a);
-    int phase = 0;
-
-    load_row(lds, g, current_grad_row(a, b), a.cur + (size_t)b * g.Ls, a.wt);
+    const int tid = threadIdx.x, lane = tid & 63;
     const float* G = (const float*)lds.G;
-    const float* P = (const float*)lds.P;
-
     int Ub;
     const uint32_t gchain = a.key.chain_lo + (uint32_t)b;
     if (a.rng_mode == 0) Ub = a.U_in[b];
     else Ub = pathlen_from_bits(philox4x32_10(U4{gchain, (uint32_t)it, 0u, 0u}, a.key.k0, a.key.k1).x, a.pas);
     Ub = min(max(Ub, 1), a.mu_max);
 
-    int dist;                                       // mutation count of the working state (ppde/utils.py:5-14)
-    {
-        float c = 0.f;
-        for (int l = tid; l < g.L; l += PPDE_BLOCK) c += (lds.St[l] != lds.Wt[l]) ? 1.f : 0.f;
-        dist = (int)block_sum(c, lds.red, phase);
-    }
-
     for (int s = 0; s < Ub; ++s) {
         const bool capped = dist >= a.thr;
-        // ---- logits z = (g - g[current letter]) / 2 with the forward masks; row maximum
-        float lm = -INFINITY;
-        for (int g4 = tid; g4 < n4; g4 += PPDE_BLOCK) {
-            const int l = g4 / 5, kb = (g4 - 5 * l) * 4;
-            const float4 gv = lds.G[g4];
-            const float gc = lds.Gc[l];
-            float4 z = make_float4((gv.x - gc) * 0.5f, (gv.y - gc) * 0.5f, (gv.z - gc) * 0.5f, (gv.w - gc) * 0.5f);
-            const bool outside = (l < a.min_pos) | (l > a.max_pos);
-            const int w = lds.Wt[l];
-            const bool revertible = capped & (lds.St[l] != w);
-            // capped chains may only move a mutated residue back to its wild-type letter
-            if (outside | (capped & !(revertible & (kb + 0 == w)))) z.x = -INFINITY;
-            if (outside | (capped & !(revertible & (kb + 1 == w)))) z.y = -INFINITY;
-            if (outside | (capped & !(revertible & (kb + 2 == w)))) z.z = -INFINITY;
-            if (outside | (capped & !(revertible & (kb + 3 == w)))) z.w = -INFINITY;
-            lds.Z[g4] = z;
-            lm = fmaxf(fmaxf(lm, fmaxf(z.x, z.y)), fmaxf(z.z, z.w));
+        // ---- race variates first: they do not depend on the state, so their latency hides behind the reductions
+        float4 q[GPT];
+#pragma unroll
+        for (int r = 0; r < GPT; ++r) {
+            const int g4 = tid + r * PPDE_BLOCK;
+            if (!R.valid[r]) { q[r] = make_float4(1.f, 1.f, 1.f, 1.f); continue; }
+            if (a.rng_mode == 0) {
+                q[r] = *(const float4*)(a.q_in + ((size_t)s * a.n + b) * g.N + 4 * g4);
+            } else {
+                const U4 rr = philox4x32_10(U4{gchain, (uint32_t)it, (uint32_t)(2 + s), (uint32_t)g4}, a.key.k0, a.key.k1);
+                q[r] = make_float4(exp1_from_bits(rr.x), exp1_from_bits(rr.y), exp1_from_bits(rr.z), exp1_from_bits(rr.w));
+            }
         }
-        float m = block_max(lm, lds.red, phase);
+        // ---- logits z = (g - g[current letter]) / 2 with the forward masks (ppde.py:98-104)
+        float4 z[GPT];
+#pragma unroll
+        for (int r = 0; r < GPT; ++r) z[r] = forward_logits(a, G, R.gv[r], R.l[r], R.kb[r], R.cur[r], R.wt[r], capped);
+        PPDE_STAMP(a.dbg, 10 + 4 * min(s, 1), stamp);
+        float m, S1;
+        row_max_sumexp<GPT>(lds, z, R.valid, m, S1);
+        PPDE_STAMP(a.dbg, 11 + 4 * min(s, 1), stamp);
         if (m == -INFINITY) {                       // no admissible move: the reference raises ValueError here
             if (tid == 0) atomicOr(a.err_flag, 1);
-            m = 0.f;
+            m = 0.f; S1 = 1.f;
         }
-        const float S3 = normalise_row(lds, n4, m, phase);
-
-        // ---- exponential race: argmax p_hat / q
-        float bv = -INFINITY;
-        int bi = 0x7fffffff;
-        for (int g4 = tid; g4 < n4; g4 += PPDE_BLOCK) {
-            const float4 p = lds.P[g4];
-            float4 q;
-            if (a.rng_mode == 0) {
-                q = *(const float4*)(a.q_in + ((size_t)s * a.n + b) * g.N + 4 * g4);
-            } else {
-                const U4 r = philox4x32_10(U4{gchain, (uint32_t)it, (uint32_t)(2 + s), (uint32_t)g4}, a.key.k0, a.key.k1);
-                q = make_float4(exp1_from_bits(r.x), exp1_from_bits(r.y), exp1_from_bits(r.z), exp1_from_bits(r.w));
-            }
-            argmax_combine(bv, bi, (p.x / S3) / q.x, 4 * g4 + 0);
-            argmax_combine(bv, bi, (p.y / S3) / q.y, 4 * g4 + 1);
-            argmax_combine(bv, bi, (p.z / S3) / q.z, 4 * g4 + 2);
-            argmax_combine(bv, bi, (p.w / S3) / q.w, 4 * g4 + 3);
+        // ---- z - logsumexp -> softmax -> clamp (ppde/utils.py:106-111), exponential race argmax p / q, and the
+        //      clamped row sum S3, in one pass + one barrier. Race values are >= 0, so their bit patterns order
+        //      like the floats: key = (bits << 32) | ~index picks the largest value, then the smallest index.
+        const float lse = logf(S1) + m;
+        const float mp = m - lse;
+        const float inv = 1.0f / S1;
+        float s3 = 0.f;
+        unsigned long long key = 0;
+#pragma unroll
+        for (int r = 0; r < GPT; ++r) {
+            if (!R.valid[r]) continue;
+            const unsigned int g4 = tid + r * PPDE_BLOCK;
+            float4 p;
+            p.x = clampp(expf((z[r].x - lse) - mp) * inv); p.y = clampp(expf((z[r].y - lse) - mp) * inv);
+            p.z = clampp(expf((z[r].z - lse) - mp) * inv); p.w = clampp(expf((z[r].w - lse) - mp) * inv);
+            s3 += p.x; s3 += p.y; s3 += p.z; s3 += p.w;
+            key = umax64(key, ((unsigned long long)__float_as_uint(p.x / q[r].x) << 32) | (0xffffffffu - (4 * g4 + 0)));
+            key = umax64(key, ((unsigned long long)__float_as_uint(p.y / q[r].y) << 32) | (0xffffffffu - (4 * g4 + 1)));
+            key = umax64(key, ((unsigned long long)__float_as_uint(p.z / q[r].z) << 32) | (0xffffffffu - (4 * g4 + 2)));
+            key = umax64(key, ((unsigned long long)__float_as_uint(p.w / q[r].w) << 32) | (0xffffffffu - (4 * g4 + 3)));
         }
-        block_argmax(bv, bi, lds.red, lds.redi, phase);
-        const int win = min(bi, g.N - 1);
-        const float logp = logf(clampp(P[win] / S3));
-
-        // ---- apply the substitution (l*, k*)
+        const float s3w = wave_sum(s3);
+        key = wave_max_u64(key);
+        if (lane == 0) {
+            float* e = lds.xb + 8 * (tid >> 6);
+            e[0] = s3w; e[1] = __uint_as_float((unsigned int)(key >> 32)); e[2] = __uint_as_float((unsigned int)key);
+        }
+        __syncthreads();
+        {
+            const float* e = lds.xb + 8 * (lane & (PPDE_NW - 1));
+            s3 = wave_sum(lane < PPDE_NW ? e[0] : 0.f);
+            key = lane < PPDE_NW ? (((unsigned long long)__float_as_uint(e[1]) << 32) | __float_as_uint(e[2])) : 0ull;
+            key = wave_max_u64(key);
+        }
+        PPDE_STAMP(a.dbg, 12 + 4 * min(s, 1), stamp);
+        const int win = min((int)(0xffffffffu - (unsigned int)key), g.N - 1);
         const int ls = win / 20, ks = win - 20 * ls;
-        const int old = lds.St[ls], w = lds.Wt[ls];
-        const float gnew = G[win];
-        dist += (int)(ks != w) - (int)(old != w);
-        __syncthreads();                            // everyone has read St/Gc/P of this sub-step
+        // letter being replaced: the start state's, unless an earlier move of this path touched the residue
+        int old = lds.St[ls];
+        for (int t = 0; t < s; ++t)
+            if (lds.mv[2 * t] == ls) old = lds.mv[2 * t + 1];
+        const int wl = lds.Wt[ls];
+        // probability of the winner, recomputed by everyone exactly as its owner computed it
+        float pwin;
+        {
+            const int kbw = ks & ~3;
+            const float4 gw = lds.G[win >> 2];
+            const float4 zw = forward_logits(a, G, gw, ls, kbw, old, wl, capped);
+            const int d = ks & 3;
+            const float zz = d == 0 ? zw.x : d == 1 ? zw.y : d == 2 ? zw.z : zw.w;
+            pwin = clampp(expf((zz - lse) - mp) * inv);
+        }
+        const float logp = logf(clampp(pwin / s3));   // Categorical.log_prob = log(clamp(p_hat))
+
+        // ---- apply the substitution (l*, k*) to the register copies and log it for later sub-steps
+#pragma unroll
+        for (int r = 0; r < GPT; ++r)
+            if (R.l[r] == ls) R.cur[r] = ks;
+        dist += (int)(ks != wl) - (int)(old != wl);
         if (tid == 0) {
-            lds.St[ls] = (uint8_t)ks;
-            lds.Gc[ls] = gnew;
+            lds.mv[2 * s] = ls; lds.mv[2 * s + 1] = ks;      // read one barrier later at the earliest
             a.flat[b * a.mu_max + s] = win;
             a.logp_fwd[b * a.mu_max + s] = logp;
             if (a.tr_flat) a.tr_flat[((size_t)it * a.mu_max + s) * a.n + b] = win;
         }
-        __syncthreads();
+        PPDE_STAMP(a.dbg, 13 + 4 * min(s, 1), stamp);
     }
+    PPDE_STAMP(a.dbg, 18, stamp);
     if (tid == 0) {
         a.Ucur[b] = Ub;
         if (a.tr_U) a.tr_U[(size_t)it * a.n + b] = Ub;
@@ -287,7 +343,23 @@ __global__ __launch_bounds__(PPDE_BLOCK) void k_propose(PasArgs a) {
             if (a.tr_flat) a.tr_flat[((size_t)it * a.mu_max + s) * a.n + b] = -1;
         }
     }
-    for (int l = tid; l < g.L; l += PPDE_BLOCK) a.prop[(size_t)b * g.Ls + g.sh + l] = lds.St[l];
+#pragma unroll
+    for (int r = 0; r < GPT; ++r)
+        if (R.valid[r] && R.kb[r] == 0) a.prop[(size_t)b * g.Ls + g.sh + R.l[r]] = (uint8_t)R.cur[r];
+    PPDE_STAMP(a.dbg, 19, stamp);
+}
+
+template <int GPT>
+__global__ __launch_bounds__(PPDE_BLOCK) void k_propose(PasArgs a) {
+    extern __shared__ unsigned char smem_raw[];
+    const RowLds lds = carve_lds(smem_raw, a.g);
+    const int b = a.b_off + blockIdx.x;
+    const bool stamp = blockIdx.x == 0;
+    PPDE_STAMP(a.dbg, 8, stamp);
+    RowRegs<GPT> R;
+    load_row<GPT>(lds, a.g, current_grad_row(a, b), a.cur + (size_t)b * a.g.Ls, a.wt, R);
+    PPDE_STAMP(a.dbg, 9, stamp);
+    propose_body<GPT>(a, lds, R, b, iteration_of(a), wave_mut_count(lds, a.g.L), stamp);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -303,73 +375,162 @@ __device__ __forceinline__ void slot_energy(const PasArgs& a, int slot, int b, f
     e = (a.which == 2) ? f : dH + a.lamda * f;
 }
 
-__global__ __launch_bounds__(PPDE_BLOCK) void k_accept(PasArgs a) {
-    extern __shared__ unsigned char smem_raw[];
+// Early-issued loads of a slot's energy terms (two per lane cover L' <= 128; longer windows take the loop).
+struct EnergyPrefetch {
+    float e0, e1, f[4];
+};
+__device__ __forceinline__ EnergyPrefetch prefetch_energy(const PasArgs& a, int slot, int b) {
+    EnergyPrefetch p;
+    p.e0 = p.e1 = 0.f;
+    p.f[0] = p.f[1] = p.f[2] = p.f[3] = 0.f;
+    const int lane = threadIdx.x & 63;
+    if (a.which & 1) {
+        const float* ep = a.epart + ((size_t)slot * a.n + b) * a.g.Lp;
+        if (lane < a.g.Lp) p.e0 = ep[lane];
+        if (lane + 64 < a.g.Lp) p.e1 = ep[lane + 64];
+    }
+    if (a.which & 2)
+        for (int k = 0; k < a.n_nets; ++k) p.f[k] = a.fitC[((size_t)slot * a.n_nets + k) * a.n + b];
+    return p;
+}
+__device__ __forceinline__ void finish_energy(const PasArgs& a, int slot, int b, const EnergyPrefetch& p, float& e, float& f) {
+    float dH = 0.f;
+    if (a.which & 1) {
+        double sacc = (double)p.e0 + (double)p.e1;     // lane partial in index order, as potts_hamiltonian_from_parts
+        if (a.g.Lp > 128) {
+            const float* ep = a.epart + ((size_t)slot * a.n + b) * a.g.Lp;
+            for (int i = (threadIdx.x & 63) + 128; i < a.g.Lp; i += 64) sacc += (double)ep[i];
+        }
+        dH = (float)wave_sum_d(sacc) - a.wt_H;
+    }
+    f = 0.f;
+    if (a.which & 2) {
+        for (int k = 0; k < a.n_nets; ++k) f += p.f[k];
+        f = f / (float)a.n_nets;
+    }
+    e = (a.which == 2) ? f : dH + a.lamda * f;
+}
+
+// What the accept phase hands to a fused propose phase.
+struct AcceptOut {
+    bool acc, reset;
+    int dist;        // mutation count of the state the chain continues from
+    int sel;         // slot of that state's gradient (2 = fallback row)
+};
+
+// Loads issued at kernel entry for the accept phase (one round trip instead of ten).
+struct AcceptPrefetch {
+    int selx, sloty, Ub;
+    EnergyPrefetch py, px;
+    float cur_e, cur_f, best_e, u;
+};
+__device__ __forceinline__ AcceptPrefetch accept_prefetch(const PasArgs& a, const RowLds& lds, int b) {
+    AcceptPrefetch q{};
+    q.selx = a.reuse ? (int)a.cursel[b] : 0;
+    q.sloty = (q.selx == 0) ? 1 : 0;
+    q.Ub = a.Ucur[b];
+    q.py = prefetch_energy(a, q.sloty, b);
+    if (a.reuse) { q.cur_e = a.cur_e[b]; q.cur_f = a.cur_f[b]; }
+    else q.px = prefetch_energy(a, 0, b);
+    q.best_e = a.best_e[b];
+    if (a.rng_mode == 0) q.u = a.u_in[b];
+    float* lpf = (float*)(lds.mv + 128);            // forward log-probabilities of the path, next to the moves
+    if ((int)threadIdx.x < a.mu_max) {
+        lds.mv[threadIdx.x] = a.flat[b * a.mu_max + threadIdx.x];
+        lpf[threadIdx.x] = a.logp_fwd[b * a.mu_max + threadIdx.x];
+    }
+    return q;
+}
+
+// Reverse path, accept/reject, records (ppde.py:122-153). Expects lds.G = gradient at the proposal, lds.St = x,
+// R.cur = x's letters, lds.mv / lpf filled by accept_prefetch. On return R.cur holds the proposal's letters.
+template <int GPT>
+__device__ __forceinline__ AcceptOut accept_body(const PasArgs& a, const RowLds& lds, RowRegs<GPT>& R, int b, int it,
+                                                 const AcceptPrefetch& pf, bool stamp) {
     const Geom g = a.g;
-    const RowLds lds = carve_lds(smem_raw, g);
-    const int b = blockIdx.x, tid = threadIdx.x, n4 = g.N / 4;
-    const int it = iteration_of(a);
-    int phase = 0;
-
-    const int selx = a.cursel[b];
-    const int sloty = (selx == 0) ? 1 : 0;
-    // gradient at the proposal, working state starts from x and replays the path
-    load_row(lds, g, slot_row(a, sloty, b), a.cur + (size_t)b * g.Ls, a.wt);
+    const int tid = threadIdx.x, lane = tid & 63;
     const float* G = (const float*)lds.G;
-    const float* P = (const float*)lds.P;
-    const int Ub = a.Ucur[b];
-
+    const float* lpf = (const float*)(lds.mv + 128);
+    const int Ub = pf.Ub, sloty = pf.sloty;
+    const EnergyPrefetch& py = pf.py;
+    const EnergyPrefetch& px = pf.px;
+    const float cur_e = pf.cur_e, cur_f = pf.cur_f, best_e = pf.best_e;
+    float u = pf.u;
+    PPDE_STAMP(a.dbg, 25, stamp);
     float log_ratio = 0.f;
     for (int s = 0; s < Ub; ++s) {
-        const int win = a.flat[b * a.mu_max + s];
+        const int win = lds.mv[s];
         const int ls = win / 20, ks = win - 20 * ls;
-        if (tid == 0) {
-            lds.St[ls] = (uint8_t)ks;
-            lds.Gc[ls] = G[win];
+        float4 z[GPT];
+#pragma unroll
+        for (int r = 0; r < GPT; ++r) {
+            if (R.l[r] == ls) R.cur[r] = ks;        // state after sub-step s
+            const float gc = G[R.l[r] * 20 + R.cur[r]];
+            const float4 gv = R.gv[r];
+            z[r] = make_float4((gv.x - gc) * 0.5f, (gv.y - gc) * 0.5f, (gv.z - gc) * 0.5f, (gv.w - gc) * 0.5f);
         }
+        float m, S1;
+        row_max_sumexp<GPT>(lds, z, R.valid, m, S1);
+        const float lse = logf(S1) + m;
+        const float mp = m - lse;
+        const float inv = 1.0f / S1;
+        float s3 = 0.f;
+#pragma unroll
+        for (int r = 0; r < GPT; ++r) {
+            if (!R.valid[r]) continue;
+            s3 += clampp(expf((z[r].x - lse) - mp) * inv); s3 += clampp(expf((z[r].y - lse) - mp) * inv);
+            s3 += clampp(expf((z[r].z - lse) - mp) * inv); s3 += clampp(expf((z[r].w - lse) - mp) * inv);
+        }
+        const float s3w = wave_sum(s3);
+        if (lane == 0) lds.xb[8 * (tid >> 6)] = s3w;
+        // probability of the recorded move under the reverse proposal: its residue now holds letter ks, so the
+        // logit is (g[win] - g[win]) / 2 = 0 exactly
+        const float pwin = clampp(expf((0.f - lse) - mp) * inv);
         __syncthreads();
-        float lm = -INFINITY;
-        for (int g4 = tid; g4 < n4; g4 += PPDE_BLOCK) {
-            const int l = g4 / 5;
-            const float4 gv = lds.G[g4];
-            const float gc = lds.Gc[l];
-            const float4 z = make_float4((gv.x - gc) * 0.5f, (gv.y - gc) * 0.5f, (gv.z - gc) * 0.5f, (gv.w - gc) * 0.5f);
-            lds.Z[g4] = z;
-            lm = fmaxf(fmaxf(lm, fmaxf(z.x, z.y)), fmaxf(z.z, z.w));
-        }
-        const float m = block_max(lm, lds.red, phase);
-        const float S3 = normalise_row(lds, n4, m, phase);
-        const float logp_rev = logf(clampp(P[win] / S3));
-        log_ratio += logp_rev - a.logp_fwd[b * a.mu_max + s];
-        __syncthreads();                            // P/Z are rewritten by the next sub-step
+        const float S3 = wave_sum(lane < PPDE_NW ? lds.xb[8 * (lane & (PPDE_NW - 1))] : 0.f);
+        const float logp_rev = logf(clampp(pwin / S3));
+        log_ratio += logp_rev - lpf[s];
     }
 
-    // ---- energies and the accept decision (uniform across the block)
+    PPDE_STAMP(a.dbg, 26, stamp);
+    // ---- energies and the accept decision (every wave computes the same values)
     float e_y, f_y, e_x, f_x;
-    slot_energy(a, sloty, b, e_y, f_y);
-    if (a.reuse) { e_x = a.cur_e[b]; f_x = a.cur_f[b]; }
-    else slot_energy(a, 0, b, e_x, f_x);
+    finish_energy(a, sloty, b, py, e_y, f_y);
+    if (a.reuse) { e_x = cur_e; f_x = cur_f; }
+    else finish_energy(a, 0, b, px, e_x, f_x);
     const float log_acc = (e_y - e_x) + log_ratio;
-    float u;
-    if (a.rng_mode == 0) u = a.u_in[b];
-    else u = unif_from_bits(philox4x32_10(U4{a.key.chain_lo + (uint32_t)b, (uint32_t)it, 1u, 0u}, a.key.k0, a.key.k1).x);
+    if (a.rng_mode != 0)
+        u = unif_from_bits(philox4x32_10(U4{a.key.chain_lo + (uint32_t)b, (uint32_t)it, 1u, 0u}, a.key.k0, a.key.k1).x);
     const bool acc = expf(log_acc) >= u;
     const float e_new = acc ? e_y : e_x, f_new = acc ? f_y : f_x;
 
+    PPDE_STAMP(a.dbg, 27, stamp);
     // ---- new state, mutation-cap reset, records
-    const uint8_t* rej = a.paper ? a.fb_state + (size_t)b * a.fb_state_stride : a.cur + (size_t)b * g.Ls;
+    const uint8_t* rej = a.paper ? a.fb_state + (size_t)b * a.fb_state_stride : nullptr;
     float c = 0.f;
-    for (int l = tid; l < g.L; l += PPDE_BLOCK) {
-        const uint8_t v = acc ? lds.St[l] : rej[g.sh + l];
-        lds.St[l] = v;
-        c += (v != lds.Wt[l]) ? 1.f : 0.f;
+    int nv[GPT];
+#pragma unroll
+    for (int r = 0; r < GPT; ++r) {
+        nv[r] = 0;
+        if (R.valid[r] && R.kb[r] == 0) {
+            // rejected: back to x (still staged in LDS), or to the initial population under paper_results
+            nv[r] = acc ? R.cur[r] : (rej ? (int)rej[g.sh + R.l[r]] : (int)lds.St[R.l[r]]);
+            c += (nv[r] != R.wt[r]) ? 1.f : 0.f;
+        }
     }
-    const int dist = (int)block_sum(c, lds.red, phase);
-    const bool reset = (!a.paper) & (dist >= a.thr);
-    const bool better = e_new > a.best_e[b];        // strict: first index on ties, like torch.max over history
+    const float cw = wave_sum(c);
+    __syncthreads();                                 // xa is free again (all waves are past the last merge)
+    if (lane == 0) lds.xa[tid >> 6] = cw;
     __syncthreads();
-    for (int l = tid; l < g.L; l += PPDE_BLOCK) {
-        const uint8_t v = lds.St[l], w = lds.Wt[l];
+    const int dist = (int)wave_sum(lane < PPDE_NW ? lds.xa[lane & (PPDE_NW - 1)] : 0.f);
+    const bool reset = (!a.paper) & (dist >= a.thr);
+    PPDE_STAMP(a.dbg, 28, stamp);
+    const bool better = e_new > best_e;             // strict: first index on ties, like torch.max over history
+#pragma unroll
+    for (int r = 0; r < GPT; ++r) {
+        if (!(R.valid[r] && R.kb[r] == 0)) continue;
+        const int l = R.l[r];
+        const uint8_t v = (uint8_t)nv[r], w = (uint8_t)R.wt[r];
         const uint8_t rec = (a.rec_after_reset & reset) ? w : v;
         if (better) a.best_state[(size_t)b * g.L + l] = rec;
         if (b == a.random_chain) a.rtraj[(size_t)(it + 1) * g.L + l] = rec;
@@ -391,6 +552,69 @@ __global__ __launch_bounds__(PPDE_BLOCK) void k_accept(PasArgs a) {
             }
         }
     }
+    PPDE_STAMP(a.dbg, 29, stamp);
+    AcceptOut o;
+    o.acc = acc; o.reset = reset;
+    o.dist = reset ? 0 : dist;
+    o.sel = !a.reuse ? 0 : reset ? 2 : acc ? sloty : a.paper ? 2 : pf.selx;
+    return o;
+}
+
+template <int GPT>
+__global__ __launch_bounds__(PPDE_BLOCK) void k_accept(PasArgs a) {
+    extern __shared__ unsigned char smem_raw[];
+    const RowLds lds = carve_lds(smem_raw, a.g);
+    const int b = a.b_off + blockIdx.x;
+    const bool stamp = blockIdx.x == 0;
+    PPDE_STAMP(a.dbg, 24, stamp);
+    const AcceptPrefetch pf = accept_prefetch(a, lds, b);
+    RowRegs<GPT> R;
+    load_row<GPT>(lds, a.g, slot_row(a, pf.sloty, b), a.cur + (size_t)b * a.g.Ls, a.wt, R);
+    accept_body<GPT>(a, lds, R, b, iteration_of(a), pf, stamp);
+}
+
+// Accept phase of iteration `it` and forward path of iteration `it + 1` in one launch (gradient reuse only): an
+// accepted chain already has its next gradient row staged; a rejected / reset chain re-stages the row it falls
+// back to. Saves a launch boundary and a row staging per iteration.
+template <int GPT>
+__global__ __launch_bounds__(PPDE_BLOCK) void k_accept_propose(PasArgs a) {
+    extern __shared__ unsigned char smem_raw[];
+    const Geom g = a.g;
+    const RowLds lds = carve_lds(smem_raw, g);
+    const int b = a.b_off + blockIdx.x, tid = threadIdx.x;
+    const bool stamp = blockIdx.x == 0;
+    const int it = iteration_of(a);
+    PPDE_STAMP(a.dbg, 24, stamp);
+    const AcceptPrefetch pf = accept_prefetch(a, lds, b);
+    RowRegs<GPT> R;
+    load_row<GPT>(lds, g, slot_row(a, pf.sloty, b), a.cur + (size_t)b * g.Ls, a.wt, R);
+    const AcceptOut o = accept_body<GPT>(a, lds, R, b, it, pf, stamp);
+    // ---- the state and gradient the chain continues from
+    const uint8_t* rej = a.paper ? a.fb_state + (size_t)b * a.fb_state_stride : nullptr;
+    const bool restage = o.reset | !o.acc;
+    RowSrc src;
+    if (restage) {
+        if (o.sel == 2) { src.nc = 0; src.p = (const float4*)(a.fb_grad + (size_t)b * a.fb_grad_stride); }
+        else src = slot_row(a, o.sel, b);
+    }
+    __syncthreads();                                 // everyone is done reading lds.G / lds.St of the accept phase
+#pragma unroll
+    for (int r = 0; r < GPT; ++r) {
+        if (!R.valid[r]) continue;
+        const int l = R.l[r];
+        if (o.reset) R.cur[r] = R.wt[r];
+        else if (!o.acc) R.cur[r] = rej ? (int)rej[g.sh + l] : (int)lds.St[l];
+        if (restage) {
+            R.gv[r] = row_value(src, tid + r * PPDE_BLOCK);
+            lds.G[tid + r * PPDE_BLOCK] = R.gv[r];
+        }
+    }
+    __syncthreads();                                 // (reads of lds.St above precede the rewrite below)
+#pragma unroll
+    for (int r = 0; r < GPT; ++r)
+        if (R.valid[r] && R.kb[r] == 0) lds.St[R.l[r]] = (uint8_t)R.cur[r];
+    __syncthreads();
+    propose_body<GPT>(a, lds, R, b, it + 1, o.dist, stamp);
 }
 
 // history row 0 and the running best from the initial population (ppde.py:38-47): one wave per chain

@@ -18,8 +18,9 @@
 #pragma once
 #include "common.h"
 
-// Tiled coupling layout: Jt[tile][chunk][part][q][letter][c], tile = i*5 + k0/4, residue
-// j = part*4*NC + chunk*4 + q (rows of residues j >= Lp are zero).
+// Tiled coupling layout: Jt[tile][part][chunk][q][letter][c], tile = i*5 + k0/4, residue
+// j = part*4*NC + chunk*4 + q (rows of residues j >= Lp are zero). One (tile, part) region is
+// NC*80 rows of 16 B, contiguous, and is streamed by exactly one wavefront.
 __device__ __host__ __forceinline__ size_t jt_tile_float4s(int NC) { return (size_t)NC * 320; }
 
 // Build Jt from the reference-layout couplings J[i][j][k][l] (symmetrising on the fly).
@@ -31,8 +32,8 @@ __global__ void potts_prepare_kernel(const float* __restrict__ J, float* __restr
         size_t r = o >> 2;
         int l = r % 20; r /= 20;
         int q = r & 3; r >>= 2;
-        int part = r & 3; r >>= 2;
         int chunk = r % NC; r /= NC;
+        int part = r & 3; r >>= 2;
         int tile = (int)r;
         int i = tile / 5, k = (tile % 5) * 4 + c;
         int j = part * 4 * NC + chunk * 4 + q;
@@ -55,68 +56,161 @@ struct PottsArgs {
     const uint8_t* cursel;   // per chain: slot holding the CURRENT gradient (NULL -> slot 0 is written)
     int slot_mode;           // 0: write slot `slot_fixed`; 1: write the slot not named by cursel[b]
     int slot_fixed;
-    int n;
-    int accumulate;          // 1: grad += (window columns already hold lamda * d fit/dx)
+    int n;                   // chains in the buffers (slot stride)
+    int b_off, n_sub;        // this launch covers chains [b_off, b_off + n_sub)
+    unsigned long long* dbg; // stamp buffer (diagnostic build)
     Geom g;
 };
 
-template <int NG>   // NG groups of 64 chains per workgroup
+typedef __attribute__((address_space(3))) void* lds_vptr;
+typedef const __attribute__((address_space(1))) void* glb_vptr;
+
+// s_waitcnt vmcnt(n) with a run-time n (the instruction takes an immediate)
+__device__ __forceinline__ void wait_vmcnt(int n) {
+#define PPDE_W(k) case k: __builtin_amdgcn_s_waitcnt(((k) & 0xF) | (((k) >> 4) << 14) | 0x0F70); break;
+    switch (n) {
+        PPDE_W(0) PPDE_W(1) PPDE_W(2) PPDE_W(3) PPDE_W(4) PPDE_W(5) PPDE_W(6) PPDE_W(7)
+        PPDE_W(8) PPDE_W(9) PPDE_W(10) PPDE_W(11) PPDE_W(12) PPDE_W(13) PPDE_W(14) PPDE_W(15)
+        PPDE_W(16) PPDE_W(17) PPDE_W(18) PPDE_W(19) PPDE_W(20) PPDE_W(21) PPDE_W(22) PPDE_W(23)
+        PPDE_W(24) PPDE_W(25) PPDE_W(26) PPDE_W(27) PPDE_W(28) PPDE_W(29) PPDE_W(30) PPDE_W(31)
+        default: break;   // more than 31 younger operations outstanding: nothing to wait for yet
+    }
+#undef PPDE_W
+}
+
+// LDS-DMA issued from inline asm is invisible to hipcc's wait-count bookkeeping, so the counted vmcnt waits
+// below are the only ones in the gather loop (with the builtin form hipcc drains vmcnt(0) before the first
+// ds_read of every chunk). M0 carries the wave-uniform LDS base and is restored (cdna_hip_programming.md §5.7).
+// (gfx9 LDS instructions do not read M0, so it is not restored: nothing else in these kernels uses it.)
+__device__ __forceinline__ void glds16_asm(const void* gsrc, uint32_t lds_base) {
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(gsrc), "s"(lds_base) : "memory");
+}
+__device__ __forceinline__ uint32_t lds_offset_of(const void* p) {
+    return (uint32_t)(uintptr_t)p;   // low 32 bits of a generic LDS address = LDS offset (callers keep it wave-uniform)
+}
+
+// LDS plan of one workgroup: [4 parts][NC*80] float4 slab | [4][CPB] float4 part sums | raw state rows [CPB][Ls] bytes
+__host__ __device__ inline size_t potts_lds_bytes(int NC, int NG, int Ls) {
+    return ((size_t)4 * NC * 80 + (size_t)4 * NG * 64) * 16 + (((size_t)NG * 64 * Ls + 1023) & ~(size_t)1023) + 1024;
+}
+
+template <int NG, int MODE>   // NG groups of 64 chains per workgroup; MODE 0 register staging, 1 LDS-DMA (asm), 2 LDS-DMA (builtin)
 __global__ __launch_bounds__(256) void potts_energy_grad_kernel(PottsArgs a) {
     extern __shared__ float4 smem[];
     const Geom g = a.g;
     const int NC = g.NC;
-    const int CPB = NG * 64;
-    float4* sT = smem;                                   // [NC*320] slab of M
-    const int region0 = max(NC * 320, 4 * CPB);          // slab, later reused for the part sums
-    uint32_t* sW = (uint32_t*)(smem + region0);          // [4*NC][CPB] packed letters
-    const int tid = threadIdx.x, lane = tid & 63, part = tid >> 6;
+    constexpr int CPB = NG * 64;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int part = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: every address derived from it stays in SGPRs
     const int tile = blockIdx.x;
-    const int b0 = blockIdx.y * CPB;
+    const int b0 = a.b_off + blockIdx.y * CPB;
+    const int b_end = a.b_off + a.n_sub;
+    const bool stamp = blockIdx.x == 0 && blockIdx.y == 0;
+    PPDE_STAMP(a.dbg, 0, stamp);
+    float4* sT = smem + (size_t)part * NC * 80;                 // this wave's rows of the slab
+    float4* sR = smem + (size_t)4 * NC * 80;                    // [4][CPB]
+    uint8_t* sS = (uint8_t*)(sR + 4 * CPB);                     // raw state rows of this chain block [CPB][Ls]
 
-    // ---- stage the slab (coalesced 16 B per lane) and the chains' window letters
-    const float4* src = a.Jt + (size_t)tile * NC * 320;
-    for (int k = tid; k < NC * 320; k += 256) sT[k] = src[k];
-    const int words = 4 * NC;
-    for (int w = tid; w < CPB * words; w += 256) {
-        int cl = w / words, wd = w - cl * words;
-        int b = b0 + cl;
-        uint32_t v = 0;
-        if (b < a.n) v = *(const uint32_t*)(a.idx + (size_t)b * g.Ls + g.sh + g.i0 + 4 * wd);
-        sW[wd * CPB + cl] = v;
+    // ---- staging. REG path (default): plain 16-byte loads into registers, all issued up front (a load costs a
+    //      few issue cycles, an LDS-DMA piece 100+), then ds_write_b128 as each lands; this wave's slab rows are
+    //      private to it, so only the shared state rows need the barrier. DMA path (ASM/builtin): LDS-DMA pieces.
+    const int state_bytes = min(CPB, b_end - b0) * g.Ls;
+    const char* ssrc = (const char*)(a.idx + (size_t)b0 * g.Ls);
+    const int region_bytes = NC * 1280;
+    const int npieces = (region_bytes + 1023) >> 10;
+    const char* src = (const char*)(a.Jt + ((size_t)tile * 4 + part) * NC * 80);
+    if constexpr (MODE == 0) {
+        constexpr int SMAX = 4;                                 // state float4s per thread kept in flight (16 KiB per block)
+        float4 sv[SMAX];
+#pragma unroll
+        for (int k = 0; k < SMAX; ++k) {
+            const int off = (k * 256 + tid) * 16;
+            sv[k] = off < state_bytes ? *(const float4*)(ssrc + off) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        float4 jv[8];
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {
+            const int off = p * 1024 + lane * 16;
+            if (p < npieces && off < region_bytes) jv[p] = *(const float4*)(src + off);
+        }
+#pragma unroll
+        for (int k = 0; k < SMAX; ++k) {
+            const int off = (k * 256 + tid) * 16;
+            if (off < state_bytes) *(float4*)(sS + off) = sv[k];
+        }
+        for (int off = (SMAX * 256 + tid) * 16; off < state_bytes; off += 4096)      // big chain blocks: the rest
+            *(float4*)(sS + off) = *(const float4*)(ssrc + off);
+        __syncthreads();
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {
+            const int off = p * 1024 + lane * 16;
+            if (p < npieces && off < region_bytes) sT[p * 64 + lane] = jv[p];
+        }
+        for (int p = 8; p < npieces; ++p) {                     // long windows: the rest, synchronously
+            const int off = p * 1024 + lane * 16;
+            if (off < region_bytes) sT[p * 64 + lane] = *(const float4*)(src + off);
+        }
+    } else {
+        constexpr bool ASM = (MODE == 1);
+        const int spieces = (state_bytes + 1023) >> 10;
+        for (int p = part; p < spieces; p += 4) {
+            const int off = p * 1024 + lane * 16;
+            if (off < state_bytes) {
+                if constexpr (ASM) glds16_asm(ssrc + off, lds_offset_of(sS + p * 1024));
+                else __builtin_amdgcn_global_load_lds((glb_vptr)(ssrc + off), (lds_vptr)(sS + p * 1024), 16, 0, 0);
+            }
+        }
+        for (int p = 0; p < npieces; ++p) {
+            const int off = p * 1024 + lane * 16;
+            if (off < region_bytes) {
+                if constexpr (ASM) glds16_asm(src + off, lds_offset_of(sT + p * 64));
+                else __builtin_amdgcn_global_load_lds((glb_vptr)(src + off), (lds_vptr)(sT + p * 64), 16, 0, 0);
+            }
+        }
+        PPDE_STAMP(a.dbg, 1, stamp);
+        wait_vmcnt(npieces);                                    // my state pieces have landed (issued first) ...
+        if constexpr (ASM) asm volatile("" ::: "memory");
+        __builtin_amdgcn_s_barrier();                           // ... and so have the other waves'
     }
-    __syncthreads();
+    PPDE_STAMP(a.dbg, 2, stamp);
+    const uint8_t* myrow = sS + (size_t)lane * g.Ls + g.sh + g.i0 + 4 * part * NC;
 
-    // ---- gather: wave = part, lane = chain
+    // ---- gather: wave = part, lane = chain; chunk ck is ready once its pieces have landed
     float4 acc[NG];
 #pragma unroll
     for (int gi = 0; gi < NG; ++gi) acc[gi] = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int ck = 0; ck < NC; ++ck) {
-        const float4* rows = sT + ((ck * 4 + part) * 4) * 20;
+        if constexpr (MODE != 0) {
+            const int need = min(((ck + 1) * 1280 + 1023) >> 10, npieces);
+            wait_vmcnt(npieces - need);
+            if constexpr (MODE == 1) asm volatile("" ::: "memory");
+        }
+        const float4* rows = sT + ck * 80;
 #pragma unroll
         for (int gi = 0; gi < NG; ++gi) {
-            uint32_t w = sW[(part * NC + ck) * CPB + gi * 64 + lane];
+            const uint32_t w = *(const uint32_t*)(myrow + (size_t)gi * 64 * g.Ls + 4 * ck);
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                uint32_t letter = min((w >> (8 * q)) & 0xFFu, 19u);
-                float4 r = rows[q * 20 + letter];
+                const uint32_t letter = min((w >> (8 * q)) & 0xFFu, 19u);
+                const float4 r = rows[q * 20 + letter];
                 acc[gi].x += r.x; acc[gi].y += r.y; acc[gi].z += r.z; acc[gi].w += r.w;
             }
         }
     }
-    __syncthreads();                                     // everyone is done with the slab
-    float4* sR = smem;                                   // [4][CPB] part sums (aliases the slab)
+    PPDE_STAMP(a.dbg, 3, stamp);
 #pragma unroll
     for (int gi = 0; gi < NG; ++gi) sR[part * CPB + gi * 64 + lane] = acc[gi];
+    if constexpr (MODE == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
+    PPDE_STAMP(a.dbg, 4, stamp);
     // ---- combine parts, add fields, write gradient columns and the energy term
     const int i = tile / 5, k0 = (tile % 5) * 4;
     const float4 h4 = *(const float4*)(a.h + i * 20 + k0);
-    const int wpart = i / (4 * NC), wrem = i - wpart * 4 * NC;   // where residue i sits in sW
     for (int cl = tid; cl < CPB; cl += 256) {
-        int b = b0 + cl;
-        if (b >= a.n) continue;
-        float4 s0 = sR[cl], s1 = sR[CPB + cl], s2 = sR[2 * CPB + cl], s3 = sR[3 * CPB + cl];
+        const int b = b0 + cl;
+        if (b >= b_end) continue;
+        const float4 s0 = sR[cl], s1 = sR[CPB + cl], s2 = sR[2 * CPB + cl], s3 = sR[3 * CPB + cl];
         float4 S;
         S.x = (s0.x + s1.x) + (s2.x + s3.x);
         S.y = (s0.y + s1.y) + (s2.y + s3.y);
@@ -125,20 +219,16 @@ __global__ __launch_bounds__(256) void potts_energy_grad_kernel(PottsArgs a) {
         int slot = a.slot_fixed;
         if (a.slot_mode == 1) slot = (a.cursel[b] == 0) ? 1 : 0;
         float4* out = (float4*)(a.grad + ((size_t)slot * a.n + b) * g.N + (g.i0 + i) * 20 + k0);
-        float4 o = make_float4(S.x + h4.x, S.y + h4.y, S.z + h4.z, S.w + h4.w);
-        if (a.accumulate) {
-            float4 p = *out;
-            o.x += p.x; o.y += p.y; o.z += p.z; o.w += p.w;
-        }
-        *out = o;
-        uint32_t letter = (sW[(wpart * NC + (wrem >> 2)) * CPB + cl] >> (8 * (wrem & 3))) & 0xFFu;
-        int kk = (int)letter - k0;
+        *out = make_float4(S.x + h4.x, S.y + h4.y, S.z + h4.z, S.w + h4.w);
+        const uint32_t letter = sS[(size_t)cl * g.Ls + g.sh + g.i0 + i];
+        const int kk = (int)letter - k0;
         if (kk >= 0 && kk < 4) {
-            float sv = kk == 0 ? S.x : kk == 1 ? S.y : kk == 2 ? S.z : S.w;
-            float hv = kk == 0 ? h4.x : kk == 1 ? h4.y : kk == 2 ? h4.z : h4.w;
+            const float sv = kk == 0 ? S.x : kk == 1 ? S.y : kk == 2 ? S.z : S.w;
+            const float hv = kk == 0 ? h4.x : kk == 1 ? h4.y : kk == 2 ? h4.z : h4.w;
             a.epart[((size_t)slot * a.n + b) * g.Lp + i] = hv + 0.5f * sv;
         }
     }
+    PPDE_STAMP(a.dbg, 5, stamp);
 }
 
 // H = sum_i epart[i] in a fixed tree with fp64 partials (one wave); returns the same value in all lanes.

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <algorithm>
 #include <string>
@@ -72,7 +73,8 @@ static void set_geom(ppde_model* m, int Lp, int i0) {
     g.NC = Lp > 0 ? (((Lp + 3) / 4) + 3) / 4 : 0;
     g.sh = Lp > 0 ? (4 - (i0 & 3)) & 3 : 0;
     int need = std::max(g.sh + m->L, g.sh + i0 + 16 * g.NC);
-    g.Ls = (need + 15) & ~15;
+    g.Ls = (need + 3) & ~3;
+    if (((g.Ls >> 2) & 1) == 0) g.Ls += 4;   // odd number of dwords per row: strided LDS reads of state rows hit distinct banks
 }
 
 static int upload_wt(ppde_model* m) {
@@ -98,38 +100,51 @@ struct EvalTargets {
     float* fitC;      // [slots][nets][n]
     const uint8_t* cursel;
     int slot_mode, slot_fixed;
+    unsigned long long* dbg = nullptr;
 };
 
 static int potts_ng_for(int n) { return n <= 64 ? 1 : n <= 128 ? 2 : n <= 256 ? 4 : 8; }
 
-static size_t potts_lds_bytes(const Geom& g, int NG) {
-    size_t region0 = std::max<size_t>((size_t)g.NC * 320, (size_t)4 * NG * 64);
-    return region0 * 16 + (size_t)4 * g.NC * NG * 64 * 4;
-}
 
-static int launch_potts(const ppde_model* m, const uint8_t* states, int n, const EvalTargets& t, hipStream_t s) {
+static int launch_potts(const ppde_model* m, const uint8_t* states, int n, const EvalTargets& t, hipStream_t s,
+                        int b_off = 0, int n_sub = -1) {
+    if (n_sub < 0) n_sub = n;
     PottsArgs a{};
+    a.b_off = b_off; a.n_sub = n_sub; a.dbg = t.dbg;
     a.Jt = m->d_Jt; a.h = m->d_h; a.idx = states; a.grad = t.grad; a.epart = t.epart;
-    a.cursel = t.cursel; a.slot_mode = t.slot_mode; a.slot_fixed = t.slot_fixed; a.n = n; a.accumulate = 0;
+    a.cursel = t.cursel; a.slot_mode = t.slot_mode; a.slot_fixed = t.slot_fixed; a.n = n;
     a.g = m->g;
-    int NG = potts_ng_for(n);
-    size_t lds = potts_lds_bytes(m->g, NG);
-    while (lds > 150 * 1024 && NG > 1) { NG >>= 1; lds = potts_lds_bytes(m->g, NG); }
+    int NG = potts_ng_for(n_sub);
+    if (const char* e = getenv("PPDE_POTTS_NG")) NG = std::max(1, std::min(8, atoi(e)));   // tuning knob
+    if (NG == 3) NG = 2;
+    if (NG > 4 && NG < 8) NG = 4;
+    size_t lds = potts_lds_bytes(m->g.NC, NG, m->g.Ls);
+    while (lds > 150 * 1024 && NG > 1) { NG >>= 1; lds = potts_lds_bytes(m->g.NC, NG, m->g.Ls); }
+    ARGCHK(((m->g.NC * 1280 + 1023) >> 10) <= 32, "Potts window too long for the LDS-DMA pipeline");
     ARGCHK(lds <= 160 * 1024, "Potts window too long for one LDS slab");
-    dim3 grid(m->g.Lp * 5, (n + NG * 64 - 1) / (NG * 64));
+    dim3 grid(m->g.Lp * 5, (n_sub + NG * 64 - 1) / (NG * 64));
+    static const int mode = []() { const char* e = getenv("PPDE_POTTS_MODE"); return e ? atoi(e) : 1; }();
+    ARGCHK(m->g.Ls <= 512, "state rows longer than 512 bytes are not supported by the Potts kernel staging");
+#define PPDE_LAUNCH(NGV)                                                                                     \
+    if (mode == 1) hipLaunchKernelGGL((potts_energy_grad_kernel<NGV, 1>), grid, dim3(256), lds, s, a);      \
+    else if (mode == 2) hipLaunchKernelGGL((potts_energy_grad_kernel<NGV, 2>), grid, dim3(256), lds, s, a); \
+    else hipLaunchKernelGGL((potts_energy_grad_kernel<NGV, 0>), grid, dim3(256), lds, s, a);
     switch (NG) {
-        case 1: hipLaunchKernelGGL(potts_energy_grad_kernel<1>, grid, dim3(256), lds, s, a); break;
-        case 2: hipLaunchKernelGGL(potts_energy_grad_kernel<2>, grid, dim3(256), lds, s, a); break;
-        case 4: hipLaunchKernelGGL(potts_energy_grad_kernel<4>, grid, dim3(256), lds, s, a); break;
-        default: hipLaunchKernelGGL(potts_energy_grad_kernel<8>, grid, dim3(256), lds, s, a); break;
+        case 1: PPDE_LAUNCH(1) break;
+        case 2: PPDE_LAUNCH(2) break;
+        case 4: PPDE_LAUNCH(4) break;
+        default: PPDE_LAUNCH(8) break;
     }
+#undef PPDE_LAUNCH
     HIPCHK(hipGetLastError());
     return PPDE_OK;
 }
 
 static int launch_cnn(const ppde_model* m, const uint8_t* states, int n, const EvalTargets& t, int want_grad,
-                      float scale, hipStream_t s) {
+                      float scale, hipStream_t s, int b_off = 0, int n_sub = -1) {
+    if (n_sub < 0) n_sub = n;
     CnnArgs a{};
+    a.b_off = b_off;
     for (int k = 0; k < m->n_nets; ++k) a.net[k] = m->nets[k];
     a.n_nets = m->n_nets; a.C = m->C; a.CP = m->CP; a.K = m->K; a.F = m->F; a.T = m->T; a.J = m->J;
     a.idx = states; a.gradC = t.gradC; a.fitC = t.fitC; a.cursel = t.cursel;
@@ -137,22 +152,22 @@ static int launch_cnn(const ppde_model* m, const uint8_t* states, int n, const E
     a.g = m->g;
     size_t lds = cnn_lds_bytes(m->T, m->CP, m->F, m->J, m->L);
     ARGCHK(lds <= 160 * 1024, "sequence too long for the LDS-resident CNN kernel");
-    hipLaunchKernelGGL(k_cnn, dim3(n, m->n_nets), dim3(256), lds, s, a);
+    hipLaunchKernelGGL(k_cnn, dim3(n_sub, m->n_nets), dim3(256), lds, s, a);
     HIPCHK(hipGetLastError());
     return PPDE_OK;
 }
 
 static int eval_experts(const ppde_model* m, int which, const uint8_t* states, int n, const EvalTargets& t,
-                        int want_grad, hipStream_t s) {
+                        int want_grad, hipStream_t s, int b_off = 0, int n_sub = -1) {
     if (which & 1) {
         ARGCHK(m->has_potts, "the energy uses the Potts expert but ppde_model_set_potts was not called");
-        int rc = launch_potts(m, states, n, t, s);
+        int rc = launch_potts(m, states, n, t, s, b_off, n_sub);
         if (rc) return rc;
     }
     if (which & 2) {
         ARGCHK(m->has_cnn, "the energy uses the supervised expert but ppde_model_set_cnn was not called");
         float scale = (which == 2 ? 1.0f : m->lamda) / (float)m->n_nets;
-        int rc = launch_cnn(m, states, n, t, want_grad, scale, s);
+        int rc = launch_cnn(m, states, n, t, want_grad, scale, s, b_off, n_sub);
         if (rc) return rc;
     }
     return PPDE_OK;
@@ -396,7 +411,10 @@ int ppde_energy_grad(ppde_model* m, const uint8_t* idx_dev, int n, int which, fl
 struct ppde_chains {
     ppde_model* m = nullptr;
     ppde_chain_config cfg{};
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;                // == streams[0]
+    std::vector<hipStream_t> streams;            // one per sub-population
+    std::vector<hipEvent_t> events;              // fork (0) / join (1..) markers
+    std::vector<int> sub_off, sub_n;             // sub-population k covers chains [sub_off[k], sub_off[k] + sub_n[k])
     int n = 0, T = 0, mu_max = 1, steps_done = 0;
     bool initialised = false;
     // device buffers
@@ -407,6 +425,7 @@ struct ppde_chains {
           *f_hist = nullptr, *best_e = nullptr, *best_f = nullptr, *tr_logacc = nullptr;
     int *flat = nullptr, *Ucur = nullptr, *best_t = nullptr, *tr_flat = nullptr, *tr_U = nullptr, *err_flag = nullptr,
         *d_it = nullptr, *tmp_dist = nullptr;
+    unsigned long long* dbg = nullptr;           // stamps of the diagnostic build (64 x (cycles, 100 MHz ticks))
     // graph replay
     hipGraph_t graph = nullptr;
     hipGraphExec_t graph_exec = nullptr;
@@ -436,33 +455,80 @@ static PasArgs chain_args(const ppde_chains* c) {
     a.best_f = c->best_f; a.best_t = c->best_t; a.rtraj = c->rtraj; a.acc_last = c->acc_last;
     a.tr_flat = c->tr_flat; a.tr_acc = c->tr_acc; a.tr_logacc = c->tr_logacc; a.tr_U = c->tr_U;
     a.err_flag = c->err_flag;
+    a.dbg = c->dbg;
     return a;
 }
 
 static EvalTargets chain_targets(const ppde_chains* c, int slot_mode, int slot_fixed) {
-    return EvalTargets{c->grad, c->epart, c->gradC, c->fitC, c->cursel, slot_mode, slot_fixed};
+    return EvalTargets{c->grad, c->epart, c->gradC, c->fitC, c->cursel, slot_mode, slot_fixed, c->dbg};
 }
 
-// one iteration of ppde.py:65-153 enqueued on the chains' stream
-static int enqueue_iteration(ppde_chains* c, const int* it_base, int it_local, const int* U, const float* q,
-                             const float* u) {
+enum ChainKernel { KP_PROPOSE, KP_ACCEPT, KP_ACCEPT_PROPOSE };
+
+static int launch_chain_kernel(ppde_chains* c, ChainKernel which, const PasArgs& a, int n_sub, hipStream_t s) {
     const ppde_model* m = c->m;
-    hipStream_t s = c->stream;
     const size_t lds = pas_lds_bytes(m->g);
+    const int gpt = (m->g.N / 4 + PPDE_BLOCK - 1) / PPDE_BLOCK;
+#define PPDE_CK(KERNEL)                                                                                 \
+    switch (gpt) {                                                                                      \
+        case 1: hipLaunchKernelGGL(KERNEL<1>, dim3(n_sub), dim3(PPDE_BLOCK), lds, s, a); break;          \
+        case 2: hipLaunchKernelGGL(KERNEL<2>, dim3(n_sub), dim3(PPDE_BLOCK), lds, s, a); break;          \
+        default: hipLaunchKernelGGL(KERNEL<3>, dim3(n_sub), dim3(PPDE_BLOCK), lds, s, a); break;         \
+    }
+    if (which == KP_PROPOSE) { PPDE_CK(k_propose) }
+    else if (which == KP_ACCEPT) { PPDE_CK(k_accept) }
+    else { PPDE_CK(k_accept_propose) }
+#undef PPDE_CK
+    HIPCHK(hipGetLastError());
+    return PPDE_OK;
+}
+
+// `count` iterations of ppde.py:65-153 for sub-population k, enqueued on that sub-population's stream.
+// Re-evaluating mode: EG(x) P EG(y) A per iteration. Reuse mode: P, then EG(y) + fused [accept | next propose].
+static int enqueue_iterations(ppde_chains* c, int k, const int* it_base, int first_local, int count, const int* U,
+                              const float* q, const float* u) {
+    const ppde_model* m = c->m;
+    hipStream_t s = c->streams[k];
+    const int b_off = c->sub_off[k], n_sub = c->sub_n[k];
+    PasArgs a = chain_args(c);
+    a.b_off = b_off; a.it_base = it_base; a.U_in = U; a.q_in = q; a.u_in = u;
+    const bool fuse = c->cfg.reuse_grad && c->cfg.rng_mode == 1;
     int rc;
-    if (!c->cfg.reuse_grad) {   // energy and gradient at the current state (ppde.py:79)
-        rc = eval_experts(m, c->cfg.which, c->cur, c->n, chain_targets(c, 0, 0), 1, s);
+    for (int i = 0; i < count; ++i) {
+        a.it_local = first_local + i;
+        if (!c->cfg.reuse_grad) {   // energy and gradient at the current state (ppde.py:79)
+            rc = eval_experts(m, c->cfg.which, c->cur, c->n, chain_targets(c, 0, 0), 1, s, b_off, n_sub);
+            if (rc) return rc;
+        }
+        if (!fuse || i == 0) {
+            rc = launch_chain_kernel(c, KP_PROPOSE, a, n_sub, s);
+            if (rc) return rc;
+        }
+        // energy and gradient at the proposal (ppde.py:119)
+        rc = eval_experts(m, c->cfg.which, c->prop, c->n, chain_targets(c, 1, 0), 1, s, b_off, n_sub);
+        if (rc) return rc;
+        rc = launch_chain_kernel(c, (fuse && i + 1 < count) ? KP_ACCEPT_PROPOSE : KP_ACCEPT, a, n_sub, s);
         if (rc) return rc;
     }
-    PasArgs a = chain_args(c);
-    a.it_base = it_base; a.it_local = it_local; a.U_in = U; a.q_in = q; a.u_in = u;
-    hipLaunchKernelGGL(k_propose, dim3(c->n), dim3(PPDE_BLOCK), lds, s, a);
-    HIPCHK(hipGetLastError());
-    // energy and gradient at the proposal (ppde.py:119)
-    rc = eval_experts(m, c->cfg.which, c->prop, c->n, chain_targets(c, 1, 0), 1, s);
-    if (rc) return rc;
-    hipLaunchKernelGGL(k_accept, dim3(c->n), dim3(PPDE_BLOCK), lds, s, a);
-    HIPCHK(hipGetLastError());
+    return PPDE_OK;
+}
+
+// `count` iterations starting at (it_base, first_local) for every sub-population: fork from stream 0, run the
+// sub-populations' iteration chains side by side, join back on stream 0.
+static int enqueue_block(ppde_chains* c, const int* it_base, int first_local, int count) {
+    const int K = (int)c->streams.size();
+    if (K > 1) {
+        HIPCHK(hipEventRecord(c->events[0], c->streams[0]));
+        for (int k = 1; k < K; ++k) HIPCHK(hipStreamWaitEvent(c->streams[k], c->events[0], 0));
+    }
+    for (int k = 0; k < K; ++k) {
+        int rc = enqueue_iterations(c, k, it_base, first_local, count, nullptr, nullptr, nullptr);
+        if (rc) return rc;
+    }
+    for (int k = 1; k < K; ++k) {
+        HIPCHK(hipEventRecord(c->events[k], c->streams[k]));
+        HIPCHK(hipStreamWaitEvent(c->streams[0], c->events[k], 0));
+    }
     return PPDE_OK;
 }
 
@@ -481,7 +547,7 @@ int ppde_chains_create(ppde_chains** out, ppde_model* m, const ppde_chain_config
     ARGCHK(!(cfg->which & 1) || m->has_potts, "Potts expert not set");
     ARGCHK(!(cfg->which & 2) || m->has_cnn, "supervised expert not set");
     ARGCHK(cfg->chain_offset + (uint64_t)cfg->n_chains <= 0xffffffffull, "chain_offset + n_chains must fit 32 bits");
-    ARGCHK(pas_lds_bytes(m->g) <= 160 * 1024, "sequence too long for the LDS-resident proposal row");
+    ARGCHK(pas_lds_bytes(m->g) <= 160 * 1024 && m->g.N / 4 <= 3 * PPDE_BLOCK, "sequence too long for the chain kernels (L <= 307)");
     HIPCHK(hipSetDevice(m->device));
     ppde_chains* c = new ppde_chains();
     c->m = m; c->cfg = *cfg; c->n = cfg->n_chains; c->T = cfg->max_steps; c->mu_max = 2 * cfg->pas_length - 1;
@@ -507,16 +573,29 @@ int ppde_chains_create(ppde_chains** out, ppde_model* m, const ppde_chain_config
     A(&c->logp_fwd, n * c->mu_max, true); A(&c->flat, n * c->mu_max, true); A(&c->Ucur, n, true);
     A(&c->e_hist, T1 * n, true); A(&c->f_hist, T1 * n, true);
     A(&c->best_e, n, true); A(&c->best_f, n, true); A(&c->best_t, n, true);
-    A(&c->err_flag, 1, true); A(&c->d_it, 1, true);
+    A(&c->err_flag, 1, true); A(&c->d_it, 1, true); A(&c->dbg, 128, true);
     if (cfg->trace) {
         A(&c->tr_flat, (size_t)c->T * c->mu_max * n, true); A(&c->tr_acc, (size_t)c->T * n, true);
         A(&c->tr_logacc, (size_t)c->T * n, true); A(&c->tr_U, (size_t)c->T * n, true);
     }
-    if (!ok || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+    int K = (cfg->rng_mode == 1 && cfg->n_streams > 1) ? std::min(cfg->n_streams, std::min(8, c->n)) : 1;
+    c->streams.assign(K, nullptr);
+    c->events.assign(K, nullptr);
+    for (int k = 0; k < K && ok; ++k) {
+        ok = hipStreamCreateWithFlags(&c->streams[k], hipStreamNonBlocking) == hipSuccess &&
+             hipEventCreateWithFlags(&c->events[k], hipEventDisableTiming) == hipSuccess;
+        const int base = c->n / K, extra = c->n % K;
+        c->sub_off.push_back(k * base + std::min(k, extra));
+        c->sub_n.push_back(base + (k < extra ? 1 : 0));
+    }
+    if (!ok) {
         for (void* p : c->allocs) hipFree(p);
+        for (hipStream_t st : c->streams) if (st) hipStreamDestroy(st);
+        for (hipEvent_t ev : c->events) if (ev) hipEventDestroy(ev);
         delete c;
         return fail(PPDE_ERR_HIP, "device allocation failed while creating chains");
     }
+    c->stream = c->streams[0];
     *out = c;
     return PPDE_OK;
 }
@@ -524,11 +603,12 @@ int ppde_chains_create(ppde_chains** out, ppde_model* m, const ppde_chain_config
 int ppde_chains_destroy(ppde_chains* c) {
     if (!c) return PPDE_OK;
     hipSetDevice(c->m->device);
-    if (c->stream) hipStreamSynchronize(c->stream);
+    for (hipStream_t st : c->streams) if (st) hipStreamSynchronize(st);
     if (c->graph_exec) hipGraphExecDestroy(c->graph_exec);
     if (c->graph) hipGraphDestroy(c->graph);
     for (void* p : c->allocs) hipFree(p);
-    if (c->stream) hipStreamDestroy(c->stream);
+    for (hipStream_t st : c->streams) if (st) hipStreamDestroy(st);
+    for (hipEvent_t ev : c->events) if (ev) hipEventDestroy(ev);
     delete c;
     return PPDE_OK;
 }
@@ -591,8 +671,8 @@ int ppde_chains_run(ppde_chains* c, int steps, const int32_t* U_dev, const float
         size_t qoff = 0;
         for (int i = 0; i < steps; ++i) {
             ARGCHK(max_u[i] >= 1 && max_u[i] <= c->mu_max, "max_u out of range");
-            int rc = enqueue_iteration(c, nullptr, c->steps_done + i, U_dev + (size_t)i * c->n,
-                                       q_dev + qoff * c->n * g.N, u_dev + (size_t)i * c->n);
+            int rc = enqueue_iterations(c, 0, nullptr, c->steps_done + i, 1, U_dev + (size_t)i * c->n,
+                                        q_dev + qoff * c->n * g.N, u_dev + (size_t)i * c->n);
             if (rc) return rc;
             qoff += max_u[i];
         }
@@ -604,8 +684,7 @@ int ppde_chains_run(ppde_chains* c, int steps, const int32_t* U_dev, const float
         const int GL = 20;
         if (steps >= GL && !c->graph_exec) {
             HIPCHK(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
-            int rc = PPDE_OK;
-            for (int i = 0; i < GL && rc == PPDE_OK; ++i) rc = enqueue_iteration(c, c->d_it, i, nullptr, nullptr, nullptr);
+            int rc = enqueue_block(c, c->d_it, 0, GL);
             if (rc == PPDE_OK) {
                 hipLaunchKernelGGL(k_bump, dim3(1), dim3(1), 0, c->stream, c->d_it, GL);
             }
@@ -623,8 +702,8 @@ int ppde_chains_run(ppde_chains* c, int steps, const int32_t* U_dev, const float
             }
         }
     }
-    for (; done < steps; ++done) {
-        int rc = enqueue_iteration(c, nullptr, c->steps_done + done, nullptr, nullptr, nullptr);
+    if (done < steps) {
+        int rc = enqueue_block(c, nullptr, c->steps_done + done, steps - done);
         if (rc) return rc;
     }
     c->steps_done += steps;
@@ -710,6 +789,14 @@ int ppde_chains_philox_dump(ppde_chains* c, int it, int s, float* q_dev, float* 
     HIPCHK(hipStreamSynchronize(c->stream));
     return PPDE_OK;
 }
+
+#ifdef PPDE_STAMPS
+int ppde_debug_read_stamps(ppde_chains* c, unsigned long long* out128) {
+    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipMemcpy(out128, c->dbg, 128 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    return PPDE_OK;
+}
+#endif
 
 int ppde_chains_time_potts_kernel(ppde_chains* c, int reps, float* avg_us) {
     ARGCHK(c && c->initialised && avg_us && reps >= 1, "bad argument");

@@ -14,6 +14,8 @@ Extra, optional attributes on `args` (absent in the reference, defaults keep its
     ppde_reuse_grad     True (default): energy/gradient of the current state are carried over from the previous
                         iteration instead of being recomputed (bit-identical results).
     ppde_use_graph      True (default): replay iterations from a captured hipGraph in philox mode.
+    ppde_streams        1 (default). >1: philox mode cuts the chains into this many sub-populations whose iterations run on
+                        separate HIP streams and overlap on the GPU (independent chains: results unchanged).
     ppde_cpu_alias      False (default): state histories hold the pre-reset state (reference on cuda);
                         True reproduces the reference's `--device cpu` aliasing artefact.
     ppde_shard          False (default). True with torch.distributed initialised: chains are split over ranks
@@ -36,14 +38,14 @@ class Chains:
 
     def __init__(self, model, n_chains, max_steps, pas_length, nmut_threshold, paper_results, min_pos, max_pos, which,
                  rng_mode, reuse_grad=True, record_after_reset=False, trace=False, random_chain=-1, use_graph=True,
-                 seed=0, chain_offset=0):
+                 seed=0, chain_offset=0, n_streams=1):
         self.model, self.lib = model, model.lib
         self.n, self.T, self.mu_max = int(n_chains), int(max_steps), 2 * int(pas_length) - 1
         self.cfg = _hip.ChainConfig(
             n_chains=self.n, max_steps=self.T, pas_length=int(pas_length), nmut_threshold=int(nmut_threshold),
             paper_results=int(bool(paper_results)), min_pos=int(min_pos), max_pos=int(max_pos), which=int(which),
             rng_mode=int(rng_mode), reuse_grad=int(bool(reuse_grad)), record_after_reset=int(bool(record_after_reset)),
-            trace=int(bool(trace)), random_chain=int(random_chain), use_graph=int(bool(use_graph)),
+            trace=int(bool(trace)), random_chain=int(random_chain), use_graph=int(bool(use_graph)), n_streams=int(n_streams),
             seed=int(seed) & (2 ** 64 - 1), chain_offset=int(chain_offset))
         self.handle = C.c_void_p()
         with torch.cuda.device(model.device):
@@ -141,6 +143,7 @@ class PPDE_PAS(BaseSampler):
             self.seed = getattr(args, "seed", None)
         self.reuse_grad = getattr(args, "ppde_reuse_grad", True)
         self.use_graph = getattr(args, "ppde_use_graph", True)
+        self.n_streams = getattr(args, "ppde_streams", 1)
         self.cpu_alias = getattr(args, "ppde_cpu_alias", False)
         self.shard = getattr(args, "ppde_shard", False)
         self.trace = getattr(args, "ppde_trace", False)
@@ -166,7 +169,8 @@ class PPDE_PAS(BaseSampler):
         seed = self.seed if self.seed is not None else torch.initial_seed()
         chains = Chains(model, n, num_steps, self.ppde_pas_length, self.nmut_threshold, self.paper_results, min_pos,
                         max_pos, energy_function.which, 0 if self.rng == "torch" else 1, self.reuse_grad, self.cpu_alias,
-                        self.trace, random_idx - lo if lo <= random_idx < hi else -1, self.use_graph, seed, lo)
+                        self.trace, random_idx - lo if lo <= random_idx < hi else -1, self.use_graph, seed, lo,
+                        self.n_streams)
         self.last_chains = chains
         chains.init(idx0[lo:hi])
 

@@ -1,0 +1,58 @@
+#!/usr/bin/env python3
+"""Diagnostic: where a launch of each hot kernel spends its time (s_memtime stamps of wave 0, workgroup 0).
+Builds ppde_amd/libppde_hip_dbg.so with -DPPDE_STAMPS (the shipped library executes no stamp) and prints
+the cycle / microsecond deltas between the named points. Run on the GPU box: python scripts/stamp_kernels.py"""
+import ctypes as C
+import os
+import sys
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+import numpy as np
+import torch
+from ppde_amd import build as B, _hip
+
+dbg = os.path.join(REPO, "ppde_amd", "libppde_hip_dbg.so")
+B.build(force=True, extra=["-DPPDE_STAMPS"], out=dbg)
+_hip.LIB_PATH = dbg
+from bench import build_model
+from ppde_amd.sampler import Chains
+
+m, wt, J, h, i0, Lp, cnn = build_model("potts", "cuda:0")
+n = 128
+pas = int(sys.argv[1]) if len(sys.argv) > 1 else 2
+ch = Chains(m, n, 64, pas, 0, False, i0, i0 + Lp - 1, 1, 1, reuse_grad=False, use_graph=False, seed=1)
+ch.init(torch.as_tensor(np.tile(wt, (n, 1))).cuda())
+lib = _hip.load()
+lib.ppde_debug_read_stamps.restype = C.c_int
+lib.ppde_debug_read_stamps.argtypes = [C.c_void_p, C.c_void_p]
+NAMES = {0: "potts entry", 1: "potts DMAs issued", 2: "potts states landed+barrier", 3: "potts gather done",
+         4: "potts part sums exchanged", 5: "potts end",
+         8: "propose entry", 9: "propose row staged", 10: "propose s0 logits", 11: "propose s0 max/sumexp merged",
+         12: "propose s0 race merged", 13: "propose s0 end", 14: "propose s>=1 logits", 15: "propose s>=1 merged1",
+         16: "propose s>=1 merged2", 17: "propose s>=1 end", 18: "propose loop done", 19: "propose end",
+         24: "accept entry", 25: "accept row staged", 26: "accept loop done", 27: "accept decision", 28: "accept count done",
+         29: "accept end"}
+acc = {}
+for rep in range(20):
+    ch.run(1)
+    out = np.zeros(128, dtype=np.uint64)
+    _hip.check(lib.ppde_debug_read_stamps(ch.handle, out.ctypes.data))
+    st = out.reshape(64, 2)
+    for grp in ((0, 1, 2, 3, 4, 5), (8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19), (24, 25, 26, 27, 28, 29)):
+        prev = None
+        for k in grp:
+            if st[k, 0] == 0:
+                continue
+            if prev is not None and st[k, 0] > st[prev, 0]:
+                acc.setdefault((prev, k), []).append((int(st[k, 0] - st[prev, 0]), int(st[k, 1] - st[prev, 1])))
+            prev = k
+        ks = [k for k in grp if st[k, 0]]
+        if len(ks) >= 2:
+            acc.setdefault(("total", grp[0]), []).append((int(st[ks[-1], 0] - st[ks[0], 0]), int(st[ks[-1], 1] - st[ks[0], 1])))
+for (a, b), v in acc.items():
+    cyc = np.median([x[0] for x in v]); rt = np.median([x[1] for x in v])
+    if a == "total":
+        print(f"TOTAL group {b}: {cyc:.0f} cycles = {rt / 100:.2f} us  (clock {cyc / max(rt, 1) * 100:.0f} MHz)")
+    else:
+        print(f"  {NAMES[a]:34s} -> {NAMES[b]:34s}: {cyc:7.0f} cycles  {rt / 100:6.2f} us")
