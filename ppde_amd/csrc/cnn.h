@@ -30,8 +30,7 @@ struct CnnArgs {
     const uint8_t* idx;             // states [n][Ls]
     float* gradC;                   // [slots][nets][n][N]
     float* fitC;                    // [slots][nets][n]
-    const uint8_t* cursel;
-    int slot_mode, slot_fixed;
+    int slot;                       // evaluation slot to write
     int n;                          // chains in the buffers (slot stride)
     int b_off;                      // first chain of this launch
     int want_grad;
@@ -82,8 +81,7 @@ __global__ __launch_bounds__(256) void k_cnn(CnnArgs a) {
     uint8_t* sSt = (uint8_t*)(red + 16);                        // [L] letters
     int phase = 0;
 
-    int slot = a.slot_fixed;
-    if (a.slot_mode == 1) slot = (a.cursel[b] == 0) ? 1 : 0;
+    const int slot = a.slot;
 
     for (int l = tid; l < g.L; l += 256) sSt[l] = min((int)a.idx[(size_t)b * g.Ls + g.sh + l], 19);
     __syncthreads();

@@ -23,6 +23,16 @@
 #define PPDE_STAMP(buf, slot, cond) do { } while (0)
 #endif
 
+// A zero the compiler cannot see through. Indexing per-chain scalars with (b + opaque_zero()) makes their loads
+// ordinary vector loads whose results stay in VGPRs until used; with a provably uniform index hipcc instead
+// moves every such value to an SGPR right away (v_readfirstlane behind an s_waitcnt vmcnt(0)), which turns ten
+// independent loads into ten serial round trips.
+__device__ __forceinline__ int opaque_zero() {
+    int z;
+    asm volatile("v_mov_b32 %0, 0" : "=v"(z));
+    return z;
+}
+
 // Problem geometry shared by every kernel (passed by value).
 struct Geom {
     int L;        // sequence length
@@ -109,6 +119,21 @@ __device__ __forceinline__ float wave_max(float v) {
     return fmaxf(fmaxf(lane_f(v, 0), lane_f(v, 16)), fmaxf(lane_f(v, 32), lane_f(v, 48)));
 }
 
+// reductions over lanes 0..7 only (the cross-wave merges: one entry per wave); the result is valid in every lane
+__device__ __forceinline__ float row8_sum(float v) {
+    v += dpp_f<DPP_XOR1>(v);
+    v += dpp_f<DPP_XOR2>(v);
+    v += dpp_f<DPP_HALF_MIRROR>(v);
+    return lane_f(v, 0);
+}
+__device__ __forceinline__ float row8_max(float v) {
+    v = fmaxf(v, dpp_f<DPP_XOR1>(v));
+    v = fmaxf(v, dpp_f<DPP_XOR2>(v));
+    v = fmaxf(v, dpp_f<DPP_HALF_MIRROR>(v));
+    return lane_f(v, 0);
+}
+__device__ __forceinline__ unsigned long long row8_max_u64(unsigned long long v);
+
 // Block-wide reductions for NW waves. `scratch` holds 2 x NW floats; `phase` alternates the half in use so
 // that ONE barrier per reduction suffices. Every thread returns the same value; the tree (lane mirror steps,
 // rows, then waves pairwise in index order) does not depend on the data or on the launch.
@@ -173,6 +198,15 @@ __device__ __forceinline__ void wave_argmax_p(float& v, int& i, float& p, int& o
         if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; bp = lane_f(p, r); bo = __builtin_amdgcn_readlane(o, r); }
     }
     v = bv; i = bi; p = bp; o = bo;
+}
+
+__device__ __forceinline__ unsigned long long row8_max_u64(unsigned long long v) {
+    v = umax64(v, dpp_u64<DPP_XOR1>(v));
+    v = umax64(v, dpp_u64<DPP_XOR2>(v));
+    v = umax64(v, dpp_u64<DPP_HALF_MIRROR>(v));
+    const unsigned int lo = (unsigned int)__builtin_amdgcn_readlane((int)(v & 0xffffffffull), 0);
+    const unsigned int hi = (unsigned int)__builtin_amdgcn_readlane((int)(v >> 32), 0);
+    return ((unsigned long long)hi << 32) | lo;
 }
 
 template <int NW>

@@ -35,7 +35,7 @@ struct PasArgs {
     const float* gradC;         // [2][nets][n][N]  lamda * d fit_net/dx / nets   (NULL without the CNN expert)
     const float* fitC;          // [2][nets][n]     per-network predictions
     int n_nets;
-    uint8_t* cursel;            // [n] slot of the current gradient (2 = fallback row)
+    float* grad_cur;            // [n][N] combined gradient row of the CURRENT state (gradient-reuse mode)
     float* cur_e;               // [n] energy / fitness of the current state (reuse mode)
     float* cur_f;
     const float* fb_grad;       // fallback gradient rows
@@ -104,10 +104,13 @@ struct RowSrc {
     int nc;
 };
 __device__ __forceinline__ float4 add4(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+// (every index into c[] is a compile-time constant: a run-time index would send the struct to scratch memory)
 __device__ __forceinline__ float4 row_value(const RowSrc& r, int g4) {
     if (r.nc == 0) return r.p[g4];
     float4 v = r.c[0][g4];
-    for (int k = 1; k < r.nc; ++k) v = add4(v, r.c[k][g4]);
+    if (r.nc > 1) v = add4(v, r.c[1][g4]);
+    if (r.nc > 2) v = add4(v, r.c[2][g4]);
+    if (r.nc > 3) v = add4(v, r.c[3][g4]);
     return r.p ? add4(v, r.p[g4]) : v;
 }
 
@@ -115,22 +118,26 @@ __device__ __forceinline__ RowSrc slot_row(const PasArgs& a, int slot, int b) {
     RowSrc r;
     r.nc = 0;
     r.p = (a.which & 1) ? (const float4*)(a.grad + ((size_t)slot * a.n + b) * a.g.N) : nullptr;
+    r.c[0] = r.c[1] = r.c[2] = r.c[3] = nullptr;
     if (a.which & 2) {
         r.nc = a.n_nets;
-        for (int k = 0; k < a.n_nets; ++k)
-            r.c[k] = (const float4*)(a.gradC + (((size_t)slot * a.n_nets + k) * a.n + b) * a.g.N);
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (k < a.n_nets) r.c[k] = (const float4*)(a.gradC + (((size_t)slot * a.n_nets + k) * a.n + b) * a.g.N);
     }
     return r;
 }
+__device__ __forceinline__ RowSrc plain_row(const float* row) {
+    RowSrc r;
+    r.nc = 0;
+    r.p = (const float4*)row;
+    r.c[0] = r.c[1] = r.c[2] = r.c[3] = nullptr;
+    return r;
+}
+// gradient at the current state: carried over in grad_cur (reuse) or freshly evaluated into slot 0
 __device__ __forceinline__ RowSrc current_grad_row(const PasArgs& a, int b) {
-    const int sel = a.reuse ? (int)a.cursel[b] : 0;   // without reuse the current gradient is always re-evaluated into slot 0
-    if (sel == 2) {
-        RowSrc r;
-        r.nc = 0;
-        r.p = (const float4*)(a.fb_grad + (size_t)b * a.fb_grad_stride);
-        return r;
-    }
-    return slot_row(a, sel, b);
+    if (a.reuse) return plain_row(a.grad_cur + (size_t)b * a.g.N);
+    return slot_row(a, 0, b);
 }
 
 __device__ __forceinline__ int iteration_of(const PasArgs& a) {
@@ -148,10 +155,13 @@ struct RowRegs {
     bool valid[GPT];
 };
 
-// Stage the gradient row and the two letter rows in LDS, then fill the per-thread registers.
+// Row staging in two halves so that a kernel can put ALL its global loads in flight before the first wait:
+// row_issue() only loads (gradient groups, one state and one wild-type letter per thread) into registers,
+// row_commit() writes them to LDS, synchronises and fills the per-thread letters.
+struct RowLetters { uint8_t st, wt; };
 template <int GPT>
-__device__ __forceinline__ void load_row(const RowLds& lds, const Geom& g, const RowSrc& src, const uint8_t* state_row,
-                                         const uint8_t* wt_row, RowRegs<GPT>& R) {
+__device__ __forceinline__ RowLetters row_issue(const Geom& g, const RowSrc& src, const uint8_t* state_row,
+                                                const uint8_t* wt_row, RowRegs<GPT>& R) {
     const int tid = threadIdx.x, n4 = g.N / 4;
 #pragma unroll
     for (int r = 0; r < GPT; ++r) {
@@ -160,18 +170,30 @@ __device__ __forceinline__ void load_row(const RowLds& lds, const Geom& g, const
         R.l[r] = R.valid[r] ? g4 / 5 : 0;
         R.kb[r] = (g4 - 5 * R.l[r]) * 4;
         R.gv[r] = R.valid[r] ? row_value(src, g4) : make_float4(0.f, 0.f, 0.f, 0.f);
-        if (R.valid[r]) lds.G[g4] = R.gv[r];
     }
-    for (int l = tid; l < g.L; l += PPDE_BLOCK) {
-        lds.St[l] = state_row[g.sh + l];
-        lds.Wt[l] = wt_row[g.sh + l];
-    }
+    RowLetters q{0, 0};
+    if (tid < g.L) { q.st = state_row[g.sh + tid]; q.wt = wt_row[g.sh + tid]; }   // L <= 307 < PPDE_BLOCK
+    return q;
+}
+template <int GPT>
+__device__ __forceinline__ void row_commit(const RowLds& lds, const Geom& g, const RowLetters& q, RowRegs<GPT>& R) {
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int r = 0; r < GPT; ++r)
+        if (R.valid[r]) lds.G[tid + r * PPDE_BLOCK] = R.gv[r];
+    if (tid < g.L) { lds.St[tid] = q.st; lds.Wt[tid] = q.wt; }
     __syncthreads();
 #pragma unroll
     for (int r = 0; r < GPT; ++r) {
         R.cur[r] = lds.St[R.l[r]];
         R.wt[r] = lds.Wt[R.l[r]];
     }
+}
+template <int GPT>
+__device__ __forceinline__ void load_row(const RowLds& lds, const Geom& g, const RowSrc& src, const uint8_t* state_row,
+                                         const uint8_t* wt_row, RowRegs<GPT>& R) {
+    const RowLetters q = row_issue<GPT>(g, src, state_row, wt_row, R);
+    row_commit<GPT>(lds, g, q, R);
 }
 
 // number of residues where the staged state differs from the wild type (every wave computes it for itself)
@@ -204,9 +226,10 @@ __device__ __forceinline__ void row_max_sumexp(const RowLds& lds, const float4 (
     __syncthreads();
     const float mj = lane < PPDE_NW ? lds.xa[2 * (lane & (PPDE_NW - 1))] : -INFINITY;
     const float sj = lane < PPDE_NW ? lds.xa[2 * (lane & (PPDE_NW - 1)) + 1] : 0.f;
-    m = wave_max(mj);
+    static_assert(PPDE_NW == 8, "the cross-wave merges assume 8 waves");
+    m = row8_max(mj);
     const float term = (mj == -INFINITY) ? 0.f : sj * expf(mj - m);
-    S1 = wave_sum(term);
+    S1 = row8_sum(term);
 }
 
 // logits of one 4-letter group of residue l: (g - g[current letter]) / 2 with the forward masks
@@ -225,36 +248,55 @@ __device__ __forceinline__ float4 forward_logits(const PasArgs& a, const float* 
     return z;
 }
 
+// Exp(1) race variates of sub-step s for this thread's groups (state independent)
+template <int GPT>
+__device__ __forceinline__ void race_variates(const PasArgs& a, int b, int it, int s, float4 (&q)[GPT]) {
+    const int n4 = a.g.N / 4;
+    const uint32_t gchain = a.key.chain_lo + (uint32_t)b;
+#pragma unroll
+    for (int r = 0; r < GPT; ++r) {
+        const int g4 = threadIdx.x + r * PPDE_BLOCK;
+        if (g4 >= n4) { q[r] = make_float4(1.f, 1.f, 1.f, 1.f); continue; }
+        if (a.rng_mode == 0) {
+            q[r] = *(const float4*)(a.q_in + ((size_t)s * a.n + b) * a.g.N + 4 * g4);
+        } else {
+            const U4 rr = philox4x32_10(U4{gchain, (uint32_t)it, (uint32_t)(2 + s), (uint32_t)g4}, a.key.k0, a.key.k1);
+            q[r] = make_float4(exp1_from_bits(rr.x), exp1_from_bits(rr.y), exp1_from_bits(rr.z), exp1_from_bits(rr.w));
+        }
+    }
+}
+// Path length and first sub-step's variates: issued at kernel entry, behind the row's global loads
+template <int GPT>
+struct ProposePrefetch {
+    int Ub;
+    float4 q0[GPT];
+};
+template <int GPT>
+__device__ __forceinline__ ProposePrefetch<GPT> propose_prefetch(const PasArgs& a, int b, int it) {
+    ProposePrefetch<GPT> p;
+    if (a.rng_mode == 0) p.Ub = a.U_in[b + opaque_zero()];
+    else p.Ub = pathlen_from_bits(philox4x32_10(U4{a.key.chain_lo + (uint32_t)b, (uint32_t)it, 0u, 0u}, a.key.k0, a.key.k1).x, a.pas);
+    p.Ub = min(max(p.Ub, 1), a.mu_max);
+    race_variates<GPT>(a, b, it, 0, p.q0);
+    return p;
+}
+
 // ------------------------------------------------------------------------------------------------
 // The forward path of one iteration (ppde.py:67-116). Expects lds.G / lds.St / lds.Wt staged and visible, R
 // holding the current letters, `dist` = mutation count of that state.
 template <int GPT>
 __device__ __forceinline__ void propose_body(const PasArgs& a, const RowLds& lds, RowRegs<GPT>& R, int b, int it, int dist,
-                                             bool stamp) {
+                                             const ProposePrefetch<GPT>& pp, bool stamp) {
     const Geom g = a.g;
     const int tid = threadIdx.x, lane = tid & 63;
     const float* G = (const float*)lds.G;
-    int Ub;
-    const uint32_t gchain = a.key.chain_lo + (uint32_t)b;
-    if (a.rng_mode == 0) Ub = a.U_in[b];
-    else Ub = pathlen_from_bits(philox4x32_10(U4{gchain, (uint32_t)it, 0u, 0u}, a.key.k0, a.key.k1).x, a.pas);
-    Ub = min(max(Ub, 1), a.mu_max);
+    const int Ub = __builtin_amdgcn_readfirstlane(pp.Ub);
+    float4 q[GPT];
+#pragma unroll
+    for (int r = 0; r < GPT; ++r) q[r] = pp.q0[r];
 
     for (int s = 0; s < Ub; ++s) {
         const bool capped = dist >= a.thr;
-        // ---- race variates first: they do not depend on the state, so their latency hides behind the reductions
-        float4 q[GPT];
-#pragma unroll
-        for (int r = 0; r < GPT; ++r) {
-            const int g4 = tid + r * PPDE_BLOCK;
-            if (!R.valid[r]) { q[r] = make_float4(1.f, 1.f, 1.f, 1.f); continue; }
-            if (a.rng_mode == 0) {
-                q[r] = *(const float4*)(a.q_in + ((size_t)s * a.n + b) * g.N + 4 * g4);
-            } else {
-                const U4 rr = philox4x32_10(U4{gchain, (uint32_t)it, (uint32_t)(2 + s), (uint32_t)g4}, a.key.k0, a.key.k1);
-                q[r] = make_float4(exp1_from_bits(rr.x), exp1_from_bits(rr.y), exp1_from_bits(rr.z), exp1_from_bits(rr.w));
-            }
-        }
         // ---- logits z = (g - g[current letter]) / 2 with the forward masks (ppde.py:98-104)
         float4 z[GPT];
 #pragma unroll
@@ -267,6 +309,9 @@ __device__ __forceinline__ void propose_body(const PasArgs& a, const RowLds& lds
             if (tid == 0) atomicOr(a.err_flag, 1);
             m = 0.f; S1 = 1.f;
         }
+        // next sub-step's race variates: state independent, so the Philox + log chains overlap with pass 2
+        float4 qn[GPT];
+        if (s + 1 < Ub) race_variates<GPT>(a, b, it, s + 1, qn);
         // ---- z - logsumexp -> softmax -> clamp (ppde/utils.py:106-111), exponential race argmax p / q, and the
         //      clamped row sum S3, in one pass + one barrier. Race values are >= 0, so their bit patterns order
         //      like the floats: key = (bits << 32) | ~index picks the largest value, then the smallest index.
@@ -297,9 +342,9 @@ __device__ __forceinline__ void propose_body(const PasArgs& a, const RowLds& lds
         __syncthreads();
         {
             const float* e = lds.xb + 8 * (lane & (PPDE_NW - 1));
-            s3 = wave_sum(lane < PPDE_NW ? e[0] : 0.f);
+            s3 = row8_sum(lane < PPDE_NW ? e[0] : 0.f);
             key = lane < PPDE_NW ? (((unsigned long long)__float_as_uint(e[1]) << 32) | __float_as_uint(e[2])) : 0ull;
-            key = wave_max_u64(key);
+            key = row8_max_u64(key);
         }
         PPDE_STAMP(a.dbg, 12 + 4 * min(s, 1), stamp);
         const int win = min((int)(0xffffffffu - (unsigned int)key), g.N - 1);
@@ -332,6 +377,10 @@ __device__ __forceinline__ void propose_body(const PasArgs& a, const RowLds& lds
             a.logp_fwd[b * a.mu_max + s] = logp;
             if (a.tr_flat) a.tr_flat[((size_t)it * a.mu_max + s) * a.n + b] = win;
         }
+        if (s + 1 < Ub) {
+#pragma unroll
+            for (int r = 0; r < GPT; ++r) q[r] = qn[r];
+        }
         PPDE_STAMP(a.dbg, 13 + 4 * min(s, 1), stamp);
     }
     PPDE_STAMP(a.dbg, 18, stamp);
@@ -357,9 +406,12 @@ __global__ __launch_bounds__(PPDE_BLOCK) void k_propose(PasArgs a) {
     const bool stamp = blockIdx.x == 0;
     PPDE_STAMP(a.dbg, 8, stamp);
     RowRegs<GPT> R;
-    load_row<GPT>(lds, a.g, current_grad_row(a, b), a.cur + (size_t)b * a.g.Ls, a.wt, R);
+    const int it = iteration_of(a);
+    const RowLetters rl = row_issue<GPT>(a.g, current_grad_row(a, b), a.cur + (size_t)b * a.g.Ls, a.wt, R);
+    const ProposePrefetch<GPT> pp = propose_prefetch<GPT>(a, b, it);
+    row_commit<GPT>(lds, a.g, rl, R);
     PPDE_STAMP(a.dbg, 9, stamp);
-    propose_body<GPT>(a, lds, R, b, iteration_of(a), wave_mut_count(lds, a.g.L), stamp);
+    propose_body<GPT>(a, lds, R, b, it, wave_mut_count(lds, a.g.L), pp, stamp);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -377,20 +429,25 @@ __device__ __forceinline__ void slot_energy(const PasArgs& a, int slot, int b, f
 
 // Early-issued loads of a slot's energy terms (two per lane cover L' <= 128; longer windows take the loop).
 struct EnergyPrefetch {
-    float e0, e1, f[4];
+    float e0, e1, f0, f1, f2, f3;   // scalars, not an array: the struct must stay in registers
 };
 __device__ __forceinline__ EnergyPrefetch prefetch_energy(const PasArgs& a, int slot, int b) {
     EnergyPrefetch p;
     p.e0 = p.e1 = 0.f;
-    p.f[0] = p.f[1] = p.f[2] = p.f[3] = 0.f;
+    p.f0 = p.f1 = p.f2 = p.f3 = 0.f;
     const int lane = threadIdx.x & 63;
     if (a.which & 1) {
         const float* ep = a.epart + ((size_t)slot * a.n + b) * a.g.Lp;
         if (lane < a.g.Lp) p.e0 = ep[lane];
         if (lane + 64 < a.g.Lp) p.e1 = ep[lane + 64];
     }
-    if (a.which & 2)
-        for (int k = 0; k < a.n_nets; ++k) p.f[k] = a.fitC[((size_t)slot * a.n_nets + k) * a.n + b];
+    if (a.which & 2) {
+        const float* fc = a.fitC + (size_t)slot * a.n_nets * a.n + b;
+        p.f0 = fc[0];
+        if (a.n_nets > 1) p.f1 = fc[(size_t)a.n];
+        if (a.n_nets > 2) p.f2 = fc[(size_t)2 * a.n];
+        if (a.n_nets > 3) p.f3 = fc[(size_t)3 * a.n];
+    }
     return p;
 }
 __device__ __forceinline__ void finish_energy(const PasArgs& a, int slot, int b, const EnergyPrefetch& p, float& e, float& f) {
@@ -405,7 +462,10 @@ __device__ __forceinline__ void finish_energy(const PasArgs& a, int slot, int b,
     }
     f = 0.f;
     if (a.which & 2) {
-        for (int k = 0; k < a.n_nets; ++k) f += p.f[k];
+        f = 0.f + p.f0;                               // same order as slot_energy: ((0 + f0) + f1) + ...
+        if (a.n_nets > 1) f += p.f1;
+        if (a.n_nets > 2) f += p.f2;
+        if (a.n_nets > 3) f += p.f3;
         f = f / (float)a.n_nets;
     }
     e = (a.which == 2) ? f : dH + a.lamda * f;
@@ -415,31 +475,41 @@ __device__ __forceinline__ void finish_energy(const PasArgs& a, int slot, int b,
 struct AcceptOut {
     bool acc, reset;
     int dist;        // mutation count of the state the chain continues from
-    int sel;         // slot of that state's gradient (2 = fallback row)
 };
 
 // Loads issued at kernel entry for the accept phase (one round trip instead of ten).
 struct AcceptPrefetch {
-    int selx, sloty, Ub;
+    int Ub;
     EnergyPrefetch py, px;
     float cur_e, cur_f, best_e, u;
+    int flat_v;      // thread t < mu_max: move t of the path
+    float lpf_v;     //                    and its forward log-probability
 };
-__device__ __forceinline__ AcceptPrefetch accept_prefetch(const PasArgs& a, const RowLds& lds, int b) {
-    AcceptPrefetch q{};
-    q.selx = a.reuse ? (int)a.cursel[b] : 0;
-    q.sloty = (q.selx == 0) ? 1 : 0;
+__device__ __forceinline__ AcceptPrefetch accept_prefetch(const PasArgs& a, const RowLds& lds, int b0) {
+    AcceptPrefetch q;
+    q.px.e0 = q.px.e1 = q.px.f0 = q.px.f1 = q.px.f2 = q.px.f3 = 0.f;
+    q.cur_e = q.cur_f = q.u = q.lpf_v = 0.f;
+    q.flat_v = 0;
+    const int b = b0 + opaque_zero();               // keep these loads independent vector loads (see opaque_zero)
     q.Ub = a.Ucur[b];
-    q.py = prefetch_energy(a, q.sloty, b);
+    q.py = prefetch_energy(a, 1, b);
     if (a.reuse) { q.cur_e = a.cur_e[b]; q.cur_f = a.cur_f[b]; }
     else q.px = prefetch_energy(a, 0, b);
     q.best_e = a.best_e[b];
     if (a.rng_mode == 0) q.u = a.u_in[b];
-    float* lpf = (float*)(lds.mv + 128);            // forward log-probabilities of the path, next to the moves
+    else q.u = unif_from_bits(philox4x32_10(U4{a.key.chain_lo + (uint32_t)b0, (uint32_t)iteration_of(a), 1u, 0u}, a.key.k0, a.key.k1).x);
     if ((int)threadIdx.x < a.mu_max) {
-        lds.mv[threadIdx.x] = a.flat[b * a.mu_max + threadIdx.x];
-        lpf[threadIdx.x] = a.logp_fwd[b * a.mu_max + threadIdx.x];
+        q.flat_v = a.flat[b * a.mu_max + threadIdx.x];
+        q.lpf_v = a.logp_fwd[b * a.mu_max + threadIdx.x];
     }
     return q;
+}
+// second half: park the path in LDS (forward log-probabilities sit next to the moves); call before row_commit()
+__device__ __forceinline__ void accept_stage_path(const PasArgs& a, const RowLds& lds, const AcceptPrefetch& q) {
+    if ((int)threadIdx.x < a.mu_max) {
+        lds.mv[threadIdx.x] = q.flat_v;
+        ((float*)(lds.mv + 128))[threadIdx.x] = q.lpf_v;
+    }
 }
 
 // Reverse path, accept/reject, records (ppde.py:122-153). Expects lds.G = gradient at the proposal, lds.St = x,
@@ -451,11 +521,12 @@ __device__ __forceinline__ AcceptOut accept_body(const PasArgs& a, const RowLds&
     const int tid = threadIdx.x, lane = tid & 63;
     const float* G = (const float*)lds.G;
     const float* lpf = (const float*)(lds.mv + 128);
-    const int Ub = pf.Ub, sloty = pf.sloty;
+    const int Ub = __builtin_amdgcn_readfirstlane(pf.Ub);
+    constexpr int sloty = 1;
     const EnergyPrefetch& py = pf.py;
     const EnergyPrefetch& px = pf.px;
     const float cur_e = pf.cur_e, cur_f = pf.cur_f, best_e = pf.best_e;
-    float u = pf.u;
+    const float u = pf.u;
     PPDE_STAMP(a.dbg, 25, stamp);
     float log_ratio = 0.f;
     for (int s = 0; s < Ub; ++s) {
@@ -487,7 +558,7 @@ __device__ __forceinline__ AcceptOut accept_body(const PasArgs& a, const RowLds&
         // logit is (g[win] - g[win]) / 2 = 0 exactly
         const float pwin = clampp(expf((0.f - lse) - mp) * inv);
         __syncthreads();
-        const float S3 = wave_sum(lane < PPDE_NW ? lds.xb[8 * (lane & (PPDE_NW - 1))] : 0.f);
+        const float S3 = row8_sum(lane < PPDE_NW ? lds.xb[8 * (lane & (PPDE_NW - 1))] : 0.f);
         const float logp_rev = logf(clampp(pwin / S3));
         log_ratio += logp_rev - lpf[s];
     }
@@ -499,8 +570,6 @@ __device__ __forceinline__ AcceptOut accept_body(const PasArgs& a, const RowLds&
     if (a.reuse) { e_x = cur_e; f_x = cur_f; }
     else finish_energy(a, 0, b, px, e_x, f_x);
     const float log_acc = (e_y - e_x) + log_ratio;
-    if (a.rng_mode != 0)
-        u = unif_from_bits(philox4x32_10(U4{a.key.chain_lo + (uint32_t)b, (uint32_t)it, 1u, 0u}, a.key.k0, a.key.k1).x);
     const bool acc = expf(log_acc) >= u;
     const float e_new = acc ? e_y : e_x, f_new = acc ? f_y : f_x;
 
@@ -522,7 +591,7 @@ __device__ __forceinline__ AcceptOut accept_body(const PasArgs& a, const RowLds&
     __syncthreads();                                 // xa is free again (all waves are past the last merge)
     if (lane == 0) lds.xa[tid >> 6] = cw;
     __syncthreads();
-    const int dist = (int)wave_sum(lane < PPDE_NW ? lds.xa[lane & (PPDE_NW - 1)] : 0.f);
+    const int dist = (int)row8_sum(lane < PPDE_NW ? lds.xa[lane & (PPDE_NW - 1)] : 0.f);
     const bool reset = (!a.paper) & (dist >= a.thr);
     PPDE_STAMP(a.dbg, 28, stamp);
     const bool better = e_new > best_e;             // strict: first index on ties, like torch.max over history
@@ -542,22 +611,42 @@ __device__ __forceinline__ AcceptOut accept_body(const PasArgs& a, const RowLds&
         if (better) { a.best_e[b] = e_new; a.best_f[b] = f_new; a.best_t[b] = it + 1; }
         a.acc_last[b] = acc ? 1 : 0;
         if (a.tr_acc) { a.tr_acc[(size_t)it * a.n + b] = acc ? 1 : 0; a.tr_logacc[(size_t)it * a.n + b] = log_acc; }
-        if (a.reuse) {
-            if (reset) {
-                a.cursel[b] = 2; a.cur_e[b] = a.fb_e[0]; a.cur_f[b] = a.fb_f[0];
-            } else if (acc) {
-                a.cursel[b] = (uint8_t)sloty; a.cur_e[b] = e_y; a.cur_f[b] = f_y;
-            } else if (a.paper) {
-                a.cursel[b] = 2; a.cur_e[b] = a.fb_e[b]; a.cur_f[b] = a.fb_f[b];
-            }
+        if (a.reuse) {                               // energy / fitness of the state the chain continues from
+            if (reset) { a.cur_e[b] = a.fb_e[0]; a.cur_f[b] = a.fb_f[0]; }
+            else if (acc) { a.cur_e[b] = e_y; a.cur_f[b] = f_y; }
+            else if (a.paper) { a.cur_e[b] = a.fb_e[b]; a.cur_f[b] = a.fb_f[b]; }
         }
     }
     PPDE_STAMP(a.dbg, 29, stamp);
     AcceptOut o;
     o.acc = acc; o.reset = reset;
     o.dist = reset ? 0 : dist;
-    o.sel = !a.reuse ? 0 : reset ? 2 : acc ? sloty : a.paper ? 2 : pf.selx;
     return o;
+}
+
+// Gradient-reuse bookkeeping after the accept decision: grad_cur[b] must hold the combined gradient row of the
+// state the chain continues from. accepted -> the proposal's row (already in registers); reset -> the wild type's
+// row; rejected under paper_results -> the initial state's row; plainly rejected -> unchanged. With `restage` the
+// row the chain continues from is also (re)loaded into R.gv / lds.G for a fused propose phase.
+template <int GPT>
+__device__ __forceinline__ void commit_current_row(const PasArgs& a, const RowLds& lds, RowRegs<GPT>& R, int b,
+                                                   const AcceptOut& o, bool restage) {
+    const float* src = nullptr;                       // row to read (uniform choice)
+    if (o.reset) src = a.fb_grad;                     // wild type (stride 0 outside paper_results; no reset inside it)
+    else if (!o.acc && a.paper) src = a.fb_grad + (size_t)b * a.fb_grad_stride;
+    else if (!o.acc && restage) src = a.grad_cur + (size_t)b * a.g.N;
+    const bool store = o.reset | o.acc | (!o.acc && a.paper);
+    float4* dst = (float4*)(a.grad_cur + (size_t)b * a.g.N);
+#pragma unroll
+    for (int r = 0; r < GPT; ++r) {
+        if (!R.valid[r]) continue;
+        const int g4 = threadIdx.x + r * PPDE_BLOCK;
+        if (src) {
+            R.gv[r] = ((const float4*)src)[g4];
+            if (restage) lds.G[g4] = R.gv[r];
+        }
+        if (store) dst[g4] = R.gv[r];
+    }
 }
 
 template <int GPT>
@@ -567,10 +656,17 @@ __global__ __launch_bounds__(PPDE_BLOCK) void k_accept(PasArgs a) {
     const int b = a.b_off + blockIdx.x;
     const bool stamp = blockIdx.x == 0;
     PPDE_STAMP(a.dbg, 24, stamp);
-    const AcceptPrefetch pf = accept_prefetch(a, lds, b);
     RowRegs<GPT> R;
-    load_row<GPT>(lds, a.g, slot_row(a, pf.sloty, b), a.cur + (size_t)b * a.g.Ls, a.wt, R);
-    accept_body<GPT>(a, lds, R, b, iteration_of(a), pf, stamp);
+    const RowLetters rl = row_issue<GPT>(a.g, slot_row(a, 1, b), a.cur + (size_t)b * a.g.Ls, a.wt, R);
+    PPDE_STAMP(a.dbg, 30, stamp);
+    const AcceptPrefetch pf = accept_prefetch(a, lds, b);
+    PPDE_STAMP(a.dbg, 31, stamp);
+    accept_stage_path(a, lds, pf);
+    PPDE_STAMP(a.dbg, 32, stamp);
+    row_commit<GPT>(lds, a.g, rl, R);
+    PPDE_STAMP(a.dbg, 33, stamp);
+    const AcceptOut o = accept_body<GPT>(a, lds, R, b, iteration_of(a), pf, stamp);
+    if (a.reuse) commit_current_row<GPT>(a, lds, R, b, o, false);
 }
 
 // Accept phase of iteration `it` and forward path of iteration `it + 1` in one launch (gradient reuse only): an
@@ -581,40 +677,33 @@ __global__ __launch_bounds__(PPDE_BLOCK) void k_accept_propose(PasArgs a) {
     extern __shared__ unsigned char smem_raw[];
     const Geom g = a.g;
     const RowLds lds = carve_lds(smem_raw, g);
-    const int b = a.b_off + blockIdx.x, tid = threadIdx.x;
+    const int b = a.b_off + blockIdx.x;
     const bool stamp = blockIdx.x == 0;
     const int it = iteration_of(a);
     PPDE_STAMP(a.dbg, 24, stamp);
-    const AcceptPrefetch pf = accept_prefetch(a, lds, b);
     RowRegs<GPT> R;
-    load_row<GPT>(lds, g, slot_row(a, pf.sloty, b), a.cur + (size_t)b * g.Ls, a.wt, R);
+    const RowLetters rl = row_issue<GPT>(g, slot_row(a, 1, b), a.cur + (size_t)b * g.Ls, a.wt, R);
+    const AcceptPrefetch pf = accept_prefetch(a, lds, b);
+    const ProposePrefetch<GPT> pp = propose_prefetch<GPT>(a, b, it + 1);
+    accept_stage_path(a, lds, pf);
+    row_commit<GPT>(lds, g, rl, R);
     const AcceptOut o = accept_body<GPT>(a, lds, R, b, it, pf, stamp);
     // ---- the state and gradient the chain continues from
     const uint8_t* rej = a.paper ? a.fb_state + (size_t)b * a.fb_state_stride : nullptr;
-    const bool restage = o.reset | !o.acc;
-    RowSrc src;
-    if (restage) {
-        if (o.sel == 2) { src.nc = 0; src.p = (const float4*)(a.fb_grad + (size_t)b * a.fb_grad_stride); }
-        else src = slot_row(a, o.sel, b);
-    }
     __syncthreads();                                 // everyone is done reading lds.G / lds.St of the accept phase
+    commit_current_row<GPT>(a, lds, R, b, o, true);
 #pragma unroll
     for (int r = 0; r < GPT; ++r) {
         if (!R.valid[r]) continue;
-        const int l = R.l[r];
         if (o.reset) R.cur[r] = R.wt[r];
-        else if (!o.acc) R.cur[r] = rej ? (int)rej[g.sh + l] : (int)lds.St[l];
-        if (restage) {
-            R.gv[r] = row_value(src, tid + r * PPDE_BLOCK);
-            lds.G[tid + r * PPDE_BLOCK] = R.gv[r];
-        }
+        else if (!o.acc) R.cur[r] = rej ? (int)rej[g.sh + R.l[r]] : (int)lds.St[R.l[r]];
     }
     __syncthreads();                                 // (reads of lds.St above precede the rewrite below)
 #pragma unroll
     for (int r = 0; r < GPT; ++r)
         if (R.valid[r] && R.kb[r] == 0) lds.St[R.l[r]] = (uint8_t)R.cur[r];
     __syncthreads();
-    propose_body<GPT>(a, lds, R, b, it + 1, o.dist, stamp);
+    propose_body<GPT>(a, lds, R, b, it + 1, o.dist, pp, stamp);
 }
 
 // history row 0 and the running best from the initial population (ppde.py:38-47): one wave per chain
@@ -633,7 +722,7 @@ __global__ void k_init_chain(PasArgs a) {
         a.e_hist[b] = e; a.f_hist[b] = f;
         a.best_e[b] = e; a.best_f[b] = f; a.best_t[b] = 0;
         a.cur_e[b] = e; a.cur_f[b] = f;
-        a.cursel[b] = 0; a.acc_last[b] = 0;
+        a.acc_last[b] = 0;
     }
 }
 

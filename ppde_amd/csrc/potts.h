@@ -53,9 +53,7 @@ struct PottsArgs {
     const uint8_t* idx;      // states [n][Ls]
     float* grad;             // [slots][n][N]   (slot stride = n*N)
     float* epart;            // [slots][n][Lp]  per-residue energy terms h + S/2 at the chain's letter
-    const uint8_t* cursel;   // per chain: slot holding the CURRENT gradient (NULL -> slot 0 is written)
-    int slot_mode;           // 0: write slot `slot_fixed`; 1: write the slot not named by cursel[b]
-    int slot_fixed;
+    int slot;                // which evaluation slot to write (0 = current state, 1 = proposal)
     int n;                   // chains in the buffers (slot stride)
     int b_off, n_sub;        // this launch covers chains [b_off, b_off + n_sub)
     unsigned long long* dbg; // stamp buffer (diagnostic build)
@@ -216,8 +214,7 @@ __global__ __launch_bounds__(256) void potts_energy_grad_kernel(PottsArgs a) {
         S.y = (s0.y + s1.y) + (s2.y + s3.y);
         S.z = (s0.z + s1.z) + (s2.z + s3.z);
         S.w = (s0.w + s1.w) + (s2.w + s3.w);
-        int slot = a.slot_fixed;
-        if (a.slot_mode == 1) slot = (a.cursel[b] == 0) ? 1 : 0;
+        const int slot = a.slot;
         float4* out = (float4*)(a.grad + ((size_t)slot * a.n + b) * g.N + (g.i0 + i) * 20 + k0);
         *out = make_float4(S.x + h4.x, S.y + h4.y, S.z + h4.z, S.w + h4.w);
         const uint32_t letter = sS[(size_t)cl * g.Ls + g.sh + g.i0 + i];

@@ -98,8 +98,7 @@ struct EvalTargets {
     float* epart;     // [slots][n][Lp]
     float* gradC;     // [slots][nets][n][N]
     float* fitC;      // [slots][nets][n]
-    const uint8_t* cursel;
-    int slot_mode, slot_fixed;
+    int slot;
     unsigned long long* dbg = nullptr;
 };
 
@@ -112,7 +111,7 @@ static int launch_potts(const ppde_model* m, const uint8_t* states, int n, const
     PottsArgs a{};
     a.b_off = b_off; a.n_sub = n_sub; a.dbg = t.dbg;
     a.Jt = m->d_Jt; a.h = m->d_h; a.idx = states; a.grad = t.grad; a.epart = t.epart;
-    a.cursel = t.cursel; a.slot_mode = t.slot_mode; a.slot_fixed = t.slot_fixed; a.n = n;
+    a.slot = t.slot; a.n = n;
     a.g = m->g;
     int NG = potts_ng_for(n_sub);
     if (const char* e = getenv("PPDE_POTTS_NG")) NG = std::max(1, std::min(8, atoi(e)));   // tuning knob
@@ -147,8 +146,8 @@ static int launch_cnn(const ppde_model* m, const uint8_t* states, int n, const E
     a.b_off = b_off;
     for (int k = 0; k < m->n_nets; ++k) a.net[k] = m->nets[k];
     a.n_nets = m->n_nets; a.C = m->C; a.CP = m->CP; a.K = m->K; a.F = m->F; a.T = m->T; a.J = m->J;
-    a.idx = states; a.gradC = t.gradC; a.fitC = t.fitC; a.cursel = t.cursel;
-    a.slot_mode = t.slot_mode; a.slot_fixed = t.slot_fixed; a.n = n; a.want_grad = want_grad; a.scale = scale;
+    a.idx = states; a.gradC = t.gradC; a.fitC = t.fitC;
+    a.slot = t.slot; a.n = n; a.want_grad = want_grad; a.scale = scale;
     a.g = m->g;
     size_t lds = cnn_lds_bytes(m->T, m->CP, m->F, m->J, m->L);
     ARGCHK(lds <= 160 * 1024, "sequence too long for the LDS-resident CNN kernel");
@@ -254,7 +253,7 @@ int ppde_model_set_potts(ppde_model* m, const float* J, const float* h, int Lp, 
     HIPCHK(dalloc(&d_grad, (size_t)g.N));
     HIPCHK(dalloc(&d_ep, (size_t)Lp));
     HIPCHK(dalloc(&d_e, 1));
-    EvalTargets t{d_grad, d_ep, nullptr, nullptr, nullptr, 0, 0};
+    EvalTargets t{d_grad, d_ep, nullptr, nullptr, 0};
     rc = launch_potts(m, m->d_wt, 1, t, 0);
     if (rc) return rc;
     hipLaunchKernelGGL(potts_energy_finalize_kernel, dim3(1), dim3(64), 0, 0, d_ep, Lp, 0.0f, d_e, 1);
@@ -388,7 +387,7 @@ int ppde_energy_grad(ppde_model* m, const uint8_t* idx_dev, int n, int which, fl
     const Geom& g = m->g;
     hipLaunchKernelGGL(k_pack_state, dim3((n * g.Ls + 255) / 256), dim3(256), 0, s, idx_dev, m->s_state, n, g.L, g.Ls, g.sh);
     HIPCHK(hipGetLastError());
-    EvalTargets t{m->s_grad, m->s_epart, m->s_gradC, m->s_fitC, nullptr, 0, 0};
+    EvalTargets t{m->s_grad, m->s_epart, m->s_gradC, m->s_fitC, 0};
     // the scratch is laid out for scratch_n chains; kernels index slot 0 with stride n, which is fine for slot 0
     rc = eval_experts(m, which, m->s_state, n, t, grad_dev != nullptr, s);
     if (rc) return rc;
@@ -418,9 +417,9 @@ struct ppde_chains {
     int n = 0, T = 0, mu_max = 1, steps_done = 0;
     bool initialised = false;
     // device buffers
-    uint8_t *cur = nullptr, *prop = nullptr, *fb_state = nullptr, *cursel = nullptr, *best_state = nullptr,
+    uint8_t *cur = nullptr, *prop = nullptr, *fb_state = nullptr, *best_state = nullptr,
             *rtraj = nullptr, *acc_last = nullptr, *tr_acc = nullptr, *tmp_idx = nullptr;
-    float *grad = nullptr, *epart = nullptr, *gradC = nullptr, *fitC = nullptr, *cur_e = nullptr, *cur_f = nullptr,
+    float *grad_cur = nullptr, *grad = nullptr, *epart = nullptr, *gradC = nullptr, *fitC = nullptr, *cur_e = nullptr, *cur_f = nullptr,
           *fb_grad = nullptr, *fb_e = nullptr, *fb_f = nullptr, *logp_fwd = nullptr, *e_hist = nullptr,
           *f_hist = nullptr, *best_e = nullptr, *best_f = nullptr, *tr_logacc = nullptr;
     int *flat = nullptr, *Ucur = nullptr, *best_t = nullptr, *tr_flat = nullptr, *tr_U = nullptr, *err_flag = nullptr,
@@ -447,7 +446,7 @@ static PasArgs chain_args(const ppde_chains* c) {
     a.cur = c->cur; a.prop = c->prop; a.fb_state = c->fb_state;
     a.fb_state_stride = c->cfg.paper_results ? m->g.Ls : 0;
     a.grad = c->grad; a.epart = c->epart; a.gradC = c->gradC; a.fitC = c->fitC;
-    a.cursel = c->cursel; a.cur_e = c->cur_e; a.cur_f = c->cur_f;
+    a.grad_cur = c->grad_cur; a.cur_e = c->cur_e; a.cur_f = c->cur_f;
     a.fb_grad = c->fb_grad; a.fb_grad_stride = c->cfg.paper_results ? (size_t)m->g.N : 0;
     a.fb_e = c->fb_e; a.fb_f = c->fb_f; a.fb_ef_stride = c->cfg.paper_results ? 1 : 0;
     a.flat = c->flat; a.logp_fwd = c->logp_fwd; a.Ucur = c->Ucur;
@@ -459,8 +458,8 @@ static PasArgs chain_args(const ppde_chains* c) {
     return a;
 }
 
-static EvalTargets chain_targets(const ppde_chains* c, int slot_mode, int slot_fixed) {
-    return EvalTargets{c->grad, c->epart, c->gradC, c->fitC, c->cursel, slot_mode, slot_fixed, c->dbg};
+static EvalTargets chain_targets(const ppde_chains* c, int slot) {
+    return EvalTargets{c->grad, c->epart, c->gradC, c->fitC, slot, c->dbg};
 }
 
 enum ChainKernel { KP_PROPOSE, KP_ACCEPT, KP_ACCEPT_PROPOSE };
@@ -497,7 +496,7 @@ static int enqueue_iterations(ppde_chains* c, int k, const int* it_base, int fir
     for (int i = 0; i < count; ++i) {
         a.it_local = first_local + i;
         if (!c->cfg.reuse_grad) {   // energy and gradient at the current state (ppde.py:79)
-            rc = eval_experts(m, c->cfg.which, c->cur, c->n, chain_targets(c, 0, 0), 1, s, b_off, n_sub);
+            rc = eval_experts(m, c->cfg.which, c->cur, c->n, chain_targets(c, 0), 1, s, b_off, n_sub);
             if (rc) return rc;
         }
         if (!fuse || i == 0) {
@@ -505,7 +504,7 @@ static int enqueue_iterations(ppde_chains* c, int k, const int* it_base, int fir
             if (rc) return rc;
         }
         // energy and gradient at the proposal (ppde.py:119)
-        rc = eval_experts(m, c->cfg.which, c->prop, c->n, chain_targets(c, 1, 0), 1, s, b_off, n_sub);
+        rc = eval_experts(m, c->cfg.which, c->prop, c->n, chain_targets(c, 1), 1, s, b_off, n_sub);
         if (rc) return rc;
         rc = launch_chain_kernel(c, (fuse && i + 1 < count) ? KP_ACCEPT_PROPOSE : KP_ACCEPT, a, n_sub, s);
         if (rc) return rc;
@@ -563,7 +562,7 @@ int ppde_chains_create(ppde_chains** out, ppde_model* m, const ppde_chain_config
     };
     A(&c->cur, n * g.Ls, true); A(&c->prop, n * g.Ls, true);
     A(&c->fb_state, (cfg->paper_results ? n : 1) * g.Ls, true);
-    A(&c->cursel, n, true); A(&c->best_state, n * g.L, true); A(&c->rtraj, T1 * g.L, true); A(&c->acc_last, n, true);
+    A(&c->grad_cur, cfg->reuse_grad ? n * g.N : 1, true); A(&c->best_state, n * g.L, true); A(&c->rtraj, T1 * g.L, true); A(&c->acc_last, n, true);
     A(&c->tmp_idx, n * g.L, true); A(&c->tmp_dist, n, true);
     A(&c->grad, 2 * n * g.N, true); A(&c->epart, 2 * n * std::max(g.Lp, 1), true);
     if (cfg->which & 2) { A(&c->gradC, 2 * nets * n * g.N, true); A(&c->fitC, 2 * nets * n, true); }
@@ -622,7 +621,6 @@ int ppde_chains_init(ppde_chains* c, const uint8_t* idx0_dev) {
     const int n = c->n;
     hipLaunchKernelGGL(k_pack_state, dim3((n * g.Ls + 255) / 256), dim3(256), 0, s, idx0_dev, c->cur, n, g.L, g.Ls, g.sh);
     HIPCHK(hipGetLastError());
-    HIPCHK(hipMemsetAsync(c->cursel, 0, n, s));
     HIPCHK(hipMemsetAsync(c->err_flag, 0, sizeof(int), s));
     HIPCHK(hipMemsetAsync(c->d_it, 0, sizeof(int), s));
     PasArgs a = chain_args(c);
@@ -635,7 +633,7 @@ int ppde_chains_init(ppde_chains* c, const uint8_t* idx0_dev) {
         else HIPCHK(hipMemcpyAsync(c->fb_state, m->d_wt, (size_t)g.Ls, hipMemcpyDeviceToDevice, s));
         if (c->cfg.reuse_grad) {
             // evaluate into slot 0 viewed with n = nf (layout [slot][nf][...] only matters within this call)
-            EvalTargets t = chain_targets(c, 0, 0);
+            EvalTargets t = chain_targets(c, 0);
             rc = eval_experts(m, c->cfg.which, fstates, nf, t, 1, s);
             if (rc) return rc;
             PasArgs f = a;
@@ -649,10 +647,14 @@ int ppde_chains_init(ppde_chains* c, const uint8_t* idx0_dev) {
         HIPCHK(hipMemcpyAsync(c->fb_state, m->d_wt, (size_t)g.Ls, hipMemcpyDeviceToDevice, s));
     }
     // energies (and, when gradients are reused, the gradient) of the initial population -> slot 0
-    rc = eval_experts(m, c->cfg.which, c->cur, n, chain_targets(c, 0, 0), 1, s);
+    rc = eval_experts(m, c->cfg.which, c->cur, n, chain_targets(c, 0), 1, s);
     if (rc) return rc;
     hipLaunchKernelGGL(k_init_chain, dim3((n + 3) / 4), dim3(256), 0, s, a);
     HIPCHK(hipGetLastError());
+    if (c->cfg.reuse_grad) {   // the current state's combined gradient row travels with the chain from here on
+        hipLaunchKernelGGL(k_combine_rows, dim3(n), dim3(256), 0, s, a, c->grad_cur);
+        HIPCHK(hipGetLastError());
+    }
     HIPCHK(hipStreamSynchronize(s));
     c->steps_done = 0;
     c->initialised = true;
@@ -805,8 +807,8 @@ int ppde_chains_time_potts_kernel(ppde_chains* c, int reps, float* avg_us) {
     hipEvent_t e0, e1;
     HIPCHK(hipEventCreate(&e0));
     HIPCHK(hipEventCreate(&e1));
-    // writes the slot that does not hold the current gradient, exactly as the launch inside an iteration does
-    EvalTargets t = chain_targets(c, 1, 0);
+    // writes the proposal slot, exactly as the launch inside an iteration does
+    EvalTargets t = chain_targets(c, 1);
     int rc = launch_potts(c->m, c->cur, c->n, t, c->stream);   // warm
     if (rc) return rc;
     HIPCHK(hipEventRecord(e0, c->stream));

@@ -32,14 +32,15 @@ NAMES = {0: "potts entry", 1: "potts DMAs issued", 2: "potts states landed+barri
          12: "propose s0 race merged", 13: "propose s0 end", 14: "propose s>=1 logits", 15: "propose s>=1 merged1",
          16: "propose s>=1 merged2", 17: "propose s>=1 end", 18: "propose loop done", 19: "propose end",
          24: "accept entry", 25: "accept row staged", 26: "accept loop done", 27: "accept decision", 28: "accept count done",
-         29: "accept end"}
+         29: "accept end", 30: "accept row loads issued", 31: "accept prefetch issued", 32: "accept path staged",
+         33: "accept row committed"}
 acc = {}
 for rep in range(20):
     ch.run(1)
     out = np.zeros(128, dtype=np.uint64)
     _hip.check(lib.ppde_debug_read_stamps(ch.handle, out.ctypes.data))
     st = out.reshape(64, 2)
-    for grp in ((0, 1, 2, 3, 4, 5), (8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19), (24, 25, 26, 27, 28, 29)):
+    for grp in ((0, 1, 2, 3, 4, 5), (8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19), (24, 30, 31, 32, 33, 25, 26, 27, 28, 29)):
         prev = None
         for k in grp:
             if st[k, 0] == 0:
