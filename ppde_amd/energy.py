@@ -154,6 +154,17 @@ class PottsWindow:
         return e if delta else e + self._model.wt_hamiltonian
 
 
+def _advance_generator_like_reference(L):
+    """The reference builds three OnehotCNN(20, 5, L) modules before loading their checkpoints
+    (ppde/energy.py:92-93, ppde/nets.py:351-358, :421); their default initialisers draw from torch's global CPU
+    generator. Replaying the reference's trajectory from the same `torch.manual_seed` therefore needs the same
+    draws to have happened by the time the sampler starts: construct (and drop) the same layers in the same order."""
+    for _ in range(3):
+        torch.nn.Conv1d(20, L, kernel_size=5)
+        torch.nn.Linear(L, 2 * L)
+        torch.nn.Linear(2 * L, 1)
+
+
 class _HipEnergy(torch.nn.Module):
     which = WHICH_POE
 
@@ -168,6 +179,8 @@ class _HipEnergy(torch.nn.Module):
             self.model.set_potts(params.J, params.h, params.win_start)
             self.unsupervised_expert = PottsWindow(params, self.model)
         self.model.set_cnn(load_cnn_states(dataset))
+        if getattr(args, "ppde_rng", "torch") == "torch":
+            _advance_generator_like_reference(len(wtseqs[0]))
 
     def to(self, *a, **k):   # parameters live in the HIP model on args.device; nothing to move
         return self

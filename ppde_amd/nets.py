@@ -1,0 +1,59 @@
+"""Ground-truth ("oracle") fitness model and the Potts score of a population, on top of the HIP Potts kernel.
+
+AugmentedLinearRegression mirrors ppde/nets.py:315-347: 20 ridge models on the augmented feature
+[ sqrt(1/reg_ev) * Delta-H(x),  sqrt(1/reg_k) * x_flat ], averaged. Delta-H comes from the same HIP kernel the
+sampler uses; the 20 x (1 + L*20) linear map is a small torch matmul on the device (it runs once per
+`log_every` iterations and once at the end: not part of the hot path).
+proteins_potts_score mirrors ppde/metrics.py:14-19.
+"""
+import math
+
+import numpy as np
+import torch
+
+from .energy import HipModel, PottsWindow, WHICH_POTTS
+from .weights import PottsParams, load_linear, load_wt
+
+
+class AugmentedLinearRegression(torch.nn.Module):
+    def __init__(self, protein, device="cuda"):
+        super().__init__()
+        params = PottsParams(protein)
+        _, wt_idx = load_wt(protein)
+        self.model = HipModel(wt_idx[0], device)
+        self.model.set_potts(params.J, params.h, params.win_start)
+        self.potts = PottsWindow(params, self.model)
+        lin = load_linear(protein)
+        dev = self.model.device
+        r_ev = float(params.reg_coef)
+        # y_k = W_k . [sqrt(1/r_ev) dH, sqrt(1/r_k) x] + b_k ; fold the scalings into the coefficients
+        self.reg_coef = [r for _, _, r in lin]
+        self.coef_ = [torch.from_numpy(c) for c, _, _ in lin]
+        self.intercept_ = [torch.tensor([b]) for _, b, _ in lin]
+        self._w_ev = torch.tensor([float(c[0]) * math.sqrt(1.0 / r_ev) for c, _, _ in lin], dtype=torch.float32, device=dev)
+        self._w_x = torch.stack([torch.from_numpy(c[1:].astype(np.float32)) * math.sqrt(1.0 / r) for c, _, r in lin]).to(dev)
+        self._b = torch.tensor([b for _, b, _ in lin], dtype=torch.float32, device=dev)
+
+    def to(self, *a, **k):
+        return self
+
+    def forward(self, x):
+        """x: one-hot [n, L, 20] (or flattened [n, L*20]) -> fitness [n]."""
+        n = x.shape[0]
+        x = x.reshape(n, self.model.L, 20)
+        idx = self.model.onehot_to_idx(x)
+        dH, _, _ = self.model.energy_grad(idx, WHICH_POTTS, want_grad=False)
+        xf = x.to(self.model.device, torch.float32).reshape(n, -1)
+        y = dH.reshape(1, n) * self._w_ev.reshape(-1, 1) + self._w_x @ xf.t() + self._b.reshape(-1, 1)   # [20, n]
+        return y.mean(0)
+
+
+def proteins_potts_score(population, dataset_name, device=None):
+    """Delta-H of a one-hot population [n, L, 20] under the Potts model stored in `dataset_name`."""
+    params = PottsParams(dataset_name)
+    _, wt_idx = load_wt(dataset_name)
+    dev = device if device is not None else (population.device if population.device.type == "cuda" else "cuda")
+    m = HipModel(wt_idx[0], dev)
+    m.set_potts(params.J, params.h, params.win_start)
+    e, _, _ = m.energy_grad(m.onehot_to_idx(population), WHICH_POTTS, want_grad=False)
+    return e

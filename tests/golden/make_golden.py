@@ -234,12 +234,49 @@ def run_case(root, protein, lamda, n, T, seed, pas, nmut, paper, out, store_q):
     print("wrote", out, f"({os.path.getsize(out) / 1e3:.0f} kB)")
 
 
+def script_case(root, protein, n_chains, n_iters, seed, out):
+    """The reference's own command line (BASELINE.json configs[0]): scripts/directed_evolution.py end to end."""
+    import glob
+    import runpy
+    sys.modules.setdefault("cma", types.ModuleType("cma"))          # imported by a baseline sampler, never used here
+    res = tempfile.mkdtemp()
+    argv = ["directed_evolution.py", "--protein_weights", root, "--protein", protein, "--results_path", res,
+            "--hub_dir", res, "--device", "cpu", "--disable_MSA_transformer_scoring", "--sampler", "PPDE",
+            "--unsupervised_expert", "potts", "--n_chains", str(n_chains), "--n_iters", str(n_iters),
+            "--seed", str(seed), "--log_every", "50"]
+    old = sys.argv
+    sys.argv = argv
+    buf = io.StringIO()
+    try:
+        with contextlib.redirect_stdout(buf):
+            runpy.run_path("/root/reference/scripts/directed_evolution.py", run_name="__main__")
+    finally:
+        sys.argv = old
+    d = glob.glob(os.path.join(res, protein, "*"))[0]
+    ld = lambda f: np.load(os.path.join(d, f))
+    log = [l for l in buf.getvalue().splitlines() if l.startswith("[Iteration") or l.startswith("WT protein")]
+    np.savez_compressed(
+        out, protein=protein, n=n_chains, T=n_iters, seed=seed, argv=np.array(argv[1:]),
+        population=ld("population.npy").argmax(-1).astype(np.uint8), pred_fitness=ld("pred_fitness_scores.npy"),
+        oracle_fitness=ld("oracle_fitness_scores.npy"), potts_scores=ld("potts_scores.npy"),
+        energy_scores=ld("energy_scores.npy"), energy_history=ld("energy_history.npy"),
+        fitness_history=ld("fitness_history.npy"), log=np.array(log))
+    print("wrote", out, f"({os.path.getsize(out) / 1e3:.0f} kB); reference log head:", log[:2])
+
+
 def main():
     if not os.path.isdir("/root/reference/ppde"):
         sys.exit("the reference is not mounted here; fixtures can only be regenerated in the build container")
     sys.path.insert(0, "/root/reference")
     install_stubs()
+    only = sys.argv[1:]
     torch.set_num_threads(1)  # reference CPU path is bit-stable at a fixed thread count
+    if only and "script" in only:
+        with tempfile.TemporaryDirectory() as root:
+            synthetic.write_weights_dir(root, "PABP_YEAST_Fields2013", potts_seed=1234)
+            torch.set_num_threads(8)
+            script_case(root, "PABP_YEAST_Fields2013", 16, 100, 7, os.path.join(HERE, "script_pabp_config1.npz"))
+        return
     with tempfile.TemporaryDirectory() as root:
         synthetic.write_weights_dir(root, "TOY24", potts_seed=7)
         synthetic.write_weights_dir(root, "PABP_YEAST_Fields2013", potts_seed=1234)
@@ -263,6 +300,10 @@ def main():
         # couplings that are NOT symmetric: autograd still yields the symmetrised gradient
         synthetic.write_weights_dir(root, "TOY24", potts_seed=8, symmetric=False)
         ops_case(root, "TOY24", 8, False, 5.0, 8, 14, os.path.join(HERE, "ops_toy24_nonsym.npz"))
+    with tempfile.TemporaryDirectory() as root:
+        synthetic.write_weights_dir(root, "PABP_YEAST_Fields2013", potts_seed=1234)
+        torch.set_num_threads(8)
+        script_case(root, "PABP_YEAST_Fields2013", 16, 100, 7, os.path.join(HERE, "script_pabp_config1.npz"))
 
 
 if __name__ == "__main__":
