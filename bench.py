@@ -111,31 +111,42 @@ def main():
     m, wt, J, h, i0, Lp, cnn = build_model(args.workload, device)
     n, L = args.chains, wt.shape[0]
     which = 3 if args.workload == "potts+cnn" else 1
-    T = args.warmup + args.steps
-    ch = Chains(m, n, T, args.pas, args.nmut, False, i0, i0 + Lp - 1, which, 1, reuse_grad=bool(args.reuse_grad),
-                random_chain=0, use_graph=True, seed=1, chain_offset=rank * n, n_streams=args.streams)
-    ch.init(torch.as_tensor(np.tile(wt, (n, 1))).to(device))
+    IN_SITU = 200
+    T = args.warmup + args.steps + IN_SITU
 
     def barrier():
         if world > 1:
             torch.distributed.barrier()
 
-    ch.run(args.warmup)
-    ch.sync()
-    torch.cuda.synchronize()
-    barrier()
-    t0 = time.perf_counter()
-    ch.run(args.steps)
-    ch.sync()
-    torch.cuda.synchronize()
-    barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], device=device, dtype=torch.float64)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        dt = float(t.item())
+    def timed_run(reuse):
+        ch = Chains(m, n, T, args.pas, args.nmut, False, i0, i0 + Lp - 1, which, 1, reuse_grad=reuse,
+                    random_chain=0, use_graph=True, seed=1, chain_offset=rank * n, n_streams=args.streams)
+        ch.init(torch.as_tensor(np.tile(wt, (n, 1))).to(device))
+        ch.run(args.warmup)
+        ch.sync()
+        torch.cuda.synchronize()
+        barrier()
+        t0 = time.perf_counter()
+        ch.run(args.steps)
+        ch.sync()
+        torch.cuda.synchronize()
+        barrier()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], device=device, dtype=torch.float64)
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            dt = float(t.item())
+        return ch, dt
 
-    # dominant kernel: potts_energy_grad, timed live with HIP events on the stream it is launched on
+    ch, dt = timed_run(bool(args.reuse_grad))
+    ch_other, dt_other = timed_run(not bool(args.reuse_grad))      # the other evaluation policy, for the record
+    del ch_other
+
+    # dominant kernel: potts_energy_grad, timed live with HIP events on the stream it is launched on: 500 launches
+    # between one event pair (this is what rocprofv3's per-kernel average reports too: in its trace a kernel's
+    # interval starts where its predecessor ends). For the record also an event pair around EVERY launch inside
+    # real, eagerly launched iterations; that figure includes the two event packets themselves.
+    pk_situ_us, pk_launches = ch.time_potts_in_situ(IN_SITU)
     pk_us = ch.time_potts_kernel(500)
     alg_bytes = 4 * (Lp * 20) ** 2 + 4 * Lp * 20 + n * Lp + 4 * n * L * 20 + 8 * n
     achieved = alg_bytes / (pk_us * 1e-6) / 1e9
@@ -172,7 +183,9 @@ def main():
             "chain_steps_per_s": world * n * args.steps / dt,
             "roofline": {"kernel": "potts_energy_grad_kernel", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_us": pk_us},
+                         "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_us": pk_us, "launches_timed": 500,
+                         "avg_launch_us_event_pair_per_launch_in_situ": pk_situ_us},
+            ("value_reuse_grad" if not args.reuse_grad else "value_reevaluate"): world * args.steps / dt_other,
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, wt, J, h, i0, Lp, cnn, n)

@@ -105,9 +105,19 @@ struct EvalTargets {
 static int potts_ng_for(int n) { return n <= 64 ? 1 : n <= 128 ? 2 : n <= 256 ? 4 : 8; }
 
 
+// When set, every Potts launch is bracketed by a pair of events taken from this pool (in-situ timing).
+struct EventPool {
+    std::vector<hipEvent_t> ev;
+    size_t used = 0;
+};
+static thread_local EventPool* g_potts_events = nullptr;
+
 static int launch_potts(const ppde_model* m, const uint8_t* states, int n, const EvalTargets& t, hipStream_t s,
                         int b_off = 0, int n_sub = -1) {
     if (n_sub < 0) n_sub = n;
+    EventPool* ep = g_potts_events;
+    if (ep && ep->used + 2 <= ep->ev.size()) HIPCHK(hipEventRecord(ep->ev[ep->used++], s));
+    else ep = nullptr;
     PottsArgs a{};
     a.b_off = b_off; a.n_sub = n_sub; a.dbg = t.dbg;
     a.Jt = m->d_Jt; a.h = m->d_h; a.idx = states; a.grad = t.grad; a.epart = t.epart;
@@ -136,6 +146,7 @@ static int launch_potts(const ppde_model* m, const uint8_t* states, int n, const
     }
 #undef PPDE_LAUNCH
     HIPCHK(hipGetLastError());
+    if (ep) HIPCHK(hipEventRecord(ep->ev[ep->used++], s));
     return PPDE_OK;
 }
 
@@ -799,6 +810,37 @@ int ppde_debug_read_stamps(ppde_chains* c, unsigned long long* out128) {
     return PPDE_OK;
 }
 #endif
+
+int ppde_chains_time_potts_in_situ(ppde_chains* c, int iters, float* avg_us, int* launches) {
+    ARGCHK(c && c->initialised && avg_us && launches && iters >= 1, "bad argument");
+    ARGCHK(c->cfg.which & 1, "no Potts expert in this energy");
+    ARGCHK(c->cfg.rng_mode == 1, "in-situ timing needs the device RNG");
+    ARGCHK(c->steps_done + iters <= c->T, "run would exceed max_steps");
+    HIPCHK(hipSetDevice(c->m->device));
+    EventPool pool;
+    pool.ev.resize((size_t)iters * 2 * 2 * c->streams.size());
+    for (auto& e : pool.ev) HIPCHK(hipEventCreate(&e));
+    g_potts_events = &pool;
+    int rc = enqueue_block(c, nullptr, c->steps_done, iters);
+    g_potts_events = nullptr;
+    if (rc == PPDE_OK) {
+        c->steps_done += iters;
+        rc = ppde_chains_sync(c);
+    }
+    double tot = 0.0;
+    int cnt = 0;
+    if (rc == PPDE_OK)
+        for (size_t i = 0; i + 1 < pool.used; i += 2) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, pool.ev[i], pool.ev[i + 1]) == hipSuccess) { tot += ms; ++cnt; }
+        }
+    for (auto& e : pool.ev) hipEventDestroy(e);
+    if (rc) return rc;
+    ARGCHK(cnt > 0, "no Potts launch was timed");
+    *avg_us = (float)(tot * 1000.0 / cnt);
+    *launches = cnt;
+    return PPDE_OK;
+}
 
 int ppde_chains_time_potts_kernel(ppde_chains* c, int reps, float* avg_us) {
     ARGCHK(c && c->initialised && avg_us && reps >= 1, "bad argument");

@@ -122,6 +122,12 @@ class Chains:
         _hip.check(self.lib.ppde_chains_philox_dump(self.handle, int(it), int(s), _hip.ptr(q), _hip.ptr(u), _hip.ptr(U)))
         return q, u, U
 
+    def time_potts_in_situ(self, iters=200):
+        """Mean duration (us) of the Potts kernel launches inside `iters` real iterations, and how many were timed."""
+        v, k = C.c_float(), C.c_int()
+        _hip.check(self.lib.ppde_chains_time_potts_in_situ(self.handle, int(iters), C.byref(v), C.byref(k)))
+        return v.value, k.value
+
     def time_potts_kernel(self, reps=200):
         v = C.c_float()
         _hip.check(self.lib.ppde_chains_time_potts_kernel(self.handle, int(reps), C.byref(v)))
