@@ -6,27 +6,31 @@
 //   h1 = relu(pre1);  pre2 = h1 We^T + be;  h2 = relu(pre2);  m[f] = max_t h2[t,f] (first arg-max t*)
 //   out = bd + wd . m
 //   d out/d x[p,c] = sum_kappa sum_o [pre1>0][p-kappa,o] * ( sum_{f: t*_f = p-kappa, m_f>0} wd_f We[f,o] ) * Wc[o,c,kappa]
-// h1 and the routed gradient live in LDS; both dense contractions ([T x C] x [C x F] and [T x C] x [C x 5*20])
-// run as register-blocked fp32 FMA with the activations broadcast from LDS. Arithmetic per chain does not
-// depend on the batch, so sharding chains over GPUs cannot change a bit.
+// h1 and the routed gradient live in LDS. The two dense contractions, [T x C] x [C x F] (with the max over t taken
+// straight from the accumulators) and [T x C] x [C x 5*20], run on the matrix cores with the exact-fp32 MFMA
+// (v_mfma_f32_16x16x4_f32: a k-ordered fmaf chain, same rate as packed fp32 FMA but 1/8 of the LDS traffic of
+// a broadcast-operand FMA loop). A operands are read from LDS one dword per lane (row stride = 2 mod 4 dwords:
+// conflict-free), B operands stream from L2 in [k][n] layout. Arithmetic per chain does not depend on the batch.
 #pragma once
 #include "common.h"
+
+typedef __attribute__((ext_vector_type(4))) float f32x4;
 
 struct CnnNet {
     const float* WcT;    // [K][20][CP]   conv weights, table form (channel-contiguous), zero padded
     const float* bc;     // [CP]
-    const float4* WeT4;  // [CP/4][F][4]  embedding weights, k-interleaved for 16-byte lane loads
-    const float* We;     // [F][CP]
-    const float* be;     // [F]
-    const float* wd;     // [F]
-    const float4* Wf4;   // [CP/4][J][4]  conv weights as [C] x [kappa*20 + c], k-interleaved
+    const float* WeT;    // [CP][FP]      embedding weights, k-major (B operand of the forward contraction)
+    const float* We;     // [F][CP]       embedding weights, feature-major (rows routed by the backward)
+    const float* be;     // [FP]
+    const float* wd;     // [FP]
+    const float* Wf;     // [CP][JP]      conv weights as [channel] x [kappa*20 + c] (B operand of the backward)
     float bd;
 };
 
 struct CnnArgs {
     CnnNet net[4];
     int n_nets;
-    int C, CP, K, F, T, J;          // J = K*20
+    int C, CP, K, KT, F, FP, T, J, JP;  // KT = taps the tables hold (K or CNN_MAX_K); J = KT*20; FP / JP rounded up to 16
     const uint8_t* idx;             // states [n][Ls]
     float* gradC;                   // [slots][nets][n][N]
     float* fitC;                    // [slots][nets][n]
@@ -35,138 +39,273 @@ struct CnnArgs {
     int b_off;                      // first chain of this launch
     int want_grad;
     float scale;                    // upstream gradient of every network output: lamda / nets (or 1 / nets)
+    unsigned long long* dbg;        // stamp buffer (diagnostic build)
     Geom g;
 };
 
-#define CNN_TB 16
+#define CNN_MAX_K 8                 // convolution taps (the reference uses 5)
+#define CNN_MAX_RT 8                // row tiles of 16: T <= 128 (one kernel instantiation per tile count)
 
-__host__ __device__ inline size_t cnn_lds_bytes(int T, int CP, int F, int J, int L) {
-    size_t rows = (size_t)((T + CNN_TB - 1) / CNN_TB) * CNN_TB;
-    size_t a = rows * (CP + 4) * 4;                    // h1 (later: routed output O, needs rows*J <= rows*(CP+4))
-    size_t o = rows * (size_t)((J > CP + 4) ? J : (CP + 4)) * 4;
-    return o + a + (size_t)F * 8 + 64 + ((L + 15) & ~15);
+__host__ __device__ inline int cnn_rows(int T) { return ((T + 15) / 16) * 16; }
+__host__ __device__ inline int cnn_astride(int CP) { return CP + 2; }   // = 2 mod 4 dwords
+__host__ __device__ inline size_t cnn_lds_bytes(int T, int CP, int FP, int J, int L) {
+    const size_t rows = cnn_rows(T), AS = cnn_astride(CP), OS = J;
+    const size_t r0 = rows * (AS > OS ? AS : OS) * 4;      // h1, later second route accumulator, later O
+    const size_t r1 = rows * AS * 4;                        // routed gradient
+    const size_t bits = rows * ((CP + 31) / 32) * 4;        // ReLU gate of h1
+    return r0 + r1 + bits + (size_t)FP * 8 + 64 + ((L + CNN_MAX_K + 15) & ~15);
 }
 
-// acc[r] += sum_o A[t0+r][o] * W[o][col]   for r < CNN_TB, with A broadcast from LDS and the weight column
-// streamed as k-interleaved float4s (W4[(o/4)][col]).
-__device__ __forceinline__ void fma_block(float (&acc)[CNN_TB], const float* A, int AS, int t0,
-                                          const float4* W4, int ncols, int col, int CP) {
-    for (int o4 = 0; o4 < CP / 4; ++o4) {
-        const float4 w = W4[(size_t)o4 * ncols + col];
+// One wave: C[rows x 16] (+)= A[rows x CP] (LDS, stride AS) * B[CP x 16] (global, leading dimension ldb, first
+// column n0). acc[rt] is the 16x16 tile of row tile rt: lane l holds rows 4*(l>>4) .. +3 of column l&15.
+// The whole B strip (one dword per lane per k-step, CP/4 <= 32 steps) is requested up front, so the strip pays
+// one L2 round trip instead of one per k-step.
+#define CNN_KB 8                    // k-steps per B burst; the contraction length is padded to 4*CNN_KB channels
+template <int RT>
+__device__ __forceinline__ void mfma_strip(f32x4 (&acc)[RT], const float* A, int AS, const float* B, int ldb, int n0,
+                                           int KSP) {
+    const int lane = threadIdx.x & 63, r = lane & 15, kq = lane >> 4;
+    const float* bp = B + (size_t)kq * ldb + n0 + r;
+    const float* ap = A + r * AS + kq;
+    float bn[CNN_KB];
 #pragma unroll
-        for (int r = 0; r < CNN_TB; ++r) {
-            const float4 h = *(const float4*)(A + (t0 + r) * AS + 4 * o4);
-            acc[r] = fmaf(h.x, w.x, acc[r]);
-            acc[r] = fmaf(h.y, w.y, acc[r]);
-            acc[r] = fmaf(h.z, w.z, acc[r]);
-            acc[r] = fmaf(h.w, w.w, acc[r]);
+    for (int u = 0; u < CNN_KB; ++u) bn[u] = bp[(size_t)u * 4 * ldb];
+    for (int kb = 0; kb < KSP; kb += CNN_KB) {
+        float bv[CNN_KB];
+#pragma unroll
+        for (int u = 0; u < CNN_KB; ++u) bv[u] = bn[u];
+        if (kb + CNN_KB < KSP) {                                // next burst is in flight while this one multiplies
+#pragma unroll
+            for (int u = 0; u < CNN_KB; ++u) bn[u] = bp[(size_t)(kb + CNN_KB + u) * 4 * ldb];
+        }
+#pragma unroll
+        for (int u = 0; u < CNN_KB; ++u) {
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) {
+                const float av = ap[rt * 16 * AS + (kb + u) * 4];
+                acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv[u], acc[rt], 0, 0, 0);
+            }
         }
     }
 }
 
-__global__ __launch_bounds__(256) void k_cnn(CnnArgs a) {
+// KT = convolution taps the tables are laid out for (the real kernel size, or zero-padded to CNN_MAX_K): a
+// compile-time trip count keeps the table loads branch-free, so they issue back to back.
+template <int RT, int KT>
+__global__ __launch_bounds__(256, 2) void k_cnn(CnnArgs a) {
     extern __shared__ unsigned char smem_raw[];
     const Geom g = a.g;
-    const int b = a.b_off + blockIdx.x, ni = blockIdx.y, tid = threadIdx.x;
+    const int b = a.b_off + blockIdx.x, ni = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const CnnNet net = a.net[ni];
-    const int T = a.T, CP = a.CP, F = a.F, J = a.J, K = a.K;
-    const int AS = CP + 4;                                     // LDS row stride of h1 / dH1
-    const int rows = ((T + CNN_TB - 1) / CNN_TB) * CNN_TB;
-    const int OS = (J > AS) ? J : AS;
-    float* sH = (float*)smem_raw;                               // [rows][AS]  h1, later O [rows][J]
-    float* sD = sH + (size_t)rows * OS;                         // [rows][AS]  routed gradient
-    float* sM = sD + (size_t)rows * AS;                         // [F] max values
-    int* sTs = (int*)(sM + F);                                  // [F] arg-max rows
-    float* red = (float*)(sTs + F);                             // 8 floats
-    uint8_t* sSt = (uint8_t*)(red + 16);                        // [L] letters
+    const int T = a.T, CP = a.CP, F = a.F, FP = a.FP, J = a.J, JP = a.JP;
+    const int AS = cnn_astride(CP);
+    const int rows = RT * 16;
+    const int KSP = CP / 4;                                         // CP is padded to a multiple of 4*CNN_KB
+    const int OS = J;
+    const int BW = (CP + 31) / 32;                                  // gate words per row
+    float* sH = (float*)smem_raw;                                   // [rows][AS] h1 | route accumulator 2 | O [rows][J]
+    float* sD = sH + (size_t)rows * (AS > OS ? AS : OS);            // [rows][AS] routed gradient
+    uint32_t* sG = (uint32_t*)(sD + (size_t)rows * AS);             // [rows][BW] bit o of word: h1[t][o] > 0
+    float* sM = (float*)(sG + (size_t)rows * BW);                   // [FP] max values
+    int* sTs = (int*)(sM + FP);                                     // [FP] arg-max rows
+    float* red = (float*)(sTs + FP);                                // 16 floats
+    uint8_t* sSt = (uint8_t*)(red + 16);                            // [L] letters
     int phase = 0;
-
     const int slot = a.slot;
 
-    for (int l = tid; l < g.L; l += 256) sSt[l] = min((int)a.idx[(size_t)b * g.Ls + g.sh + l], 19);
+    const bool stamp = blockIdx.x == 0 && blockIdx.y == 0;
+    PPDE_STAMP(a.dbg, 40, stamp);
+    for (int l = tid; l < g.L + CNN_MAX_K; l += 256) sSt[l] = l < g.L ? min((int)a.idx[(size_t)b * g.Ls + g.sh + l], 19) : 0;
     __syncthreads();
+    PPDE_STAMP(a.dbg, 41, stamp);
 
-    // ---- h1 = relu(conv): five table rows per (t, channel); padded rows/channels are zero
-    for (int e = tid; e < rows * AS; e += 256) {
-        const int t = e / AS, o = e - t * AS;
-        float v = 0.f;
-        if (t < T && o < CP) {
-            v = net.bc[o];
-            for (int kp = 0; kp < K; ++kp) v += net.WcT[((size_t)kp * 20 + sSt[t + kp]) * CP + o];
-            v = fmaxf(v, 0.f);
+    // ---- h1 = relu(conv): KT table rows per (t, channel); padded rows/channels are zero. Thread = (4 consecutive
+    //      channels, row): 16-byte table loads (a quarter of the load instructions of a dword gather), two rows per
+    //      round = 2*KT independent L2 loads in flight, addresses clamped and values masked (no branches). The ReLU
+    //      gate bits are OR-ed into sG with LDS atomics.
+    const int oc = tid & 127, th = tid >> 7;                        // (channel mod 128, row phase) of the elementwise passes
+    for (int w = tid; w < rows * BW; w += 256) sG[w] = 0u;
+    for (int e = tid; e < rows * 2; e += 256) { sH[(e >> 1) * AS + CP + (e & 1)] = 0.f; sD[(e >> 1) * AS + CP + (e & 1)] = 0.f; }
+    __syncthreads();
+    {
+        const int G4 = CP / 4;                                       // float4 groups per row
+        const int RPR = 256 / G4;                                    // rows per round (threads beyond RPR*G4 idle)
+        const int g4 = tid % G4, tr = tid / G4;
+        if (tr < RPR) {
+            const float4 bias4 = *(const float4*)(net.bc + 4 * g4);
+            for (int t0 = tr; t0 < rows; t0 += 2 * RPR) {
+                float4 wv[2][KT];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int tt = min(t0 + u * RPR, T - 1);
+#pragma unroll
+                    for (int kp = 0; kp < KT; ++kp)
+                        wv[u][kp] = *(const float4*)(net.WcT + ((size_t)kp * 20 + sSt[tt + kp]) * CP + 4 * g4);
+                }
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int t = t0 + u * RPR;
+                    if (t >= rows) continue;
+                    float4 x = bias4;
+#pragma unroll
+                    for (int kp = 0; kp < KT; ++kp) { x.x += wv[u][kp].x; x.y += wv[u][kp].y; x.z += wv[u][kp].z; x.w += wv[u][kp].w; }
+                    const bool live = t < T;
+                    x.x = live ? fmaxf(x.x, 0.f) : 0.f; x.y = live ? fmaxf(x.y, 0.f) : 0.f;
+                    x.z = live ? fmaxf(x.z, 0.f) : 0.f; x.w = live ? fmaxf(x.w, 0.f) : 0.f;
+                    float* hp = sH + t * AS + 4 * g4;                 // AS = 2 mod 4: rows are only 8-byte aligned
+                    *(float2*)hp = make_float2(x.x, x.y);
+                    *(float2*)(hp + 2) = make_float2(x.z, x.w);
+                    float* dp = sD + t * AS + 4 * g4;
+                    *(float2*)dp = make_float2(0.f, 0.f);
+                    *(float2*)(dp + 2) = make_float2(0.f, 0.f);
+                    const uint32_t nib = (x.x > 0.f ? 1u : 0u) | (x.y > 0.f ? 2u : 0u) | (x.z > 0.f ? 4u : 0u) | (x.w > 0.f ? 8u : 0u);
+                    if (nib) atomicOr(&sG[t * BW + (g4 >> 3)], nib << (4 * (g4 & 7)));
+                }
+            }
         }
-        sH[t * AS + o] = v;
-        sD[t * AS + o] = 0.f;
     }
     __syncthreads();
-
-    // ---- pre2 = h1 We^T + be, relu, running max over t (strict >: first index wins, like torch.max)
-    for (int f = tid; f < F; f += 256) {
+    PPDE_STAMP(a.dbg, 42, stamp);
+    // ---- pre2 = h1 We^T + be on the matrix cores; relu and the running max over t straight from the accumulators
+    //      (strict >, rows ascending: the first index wins, like torch.max)
+    for (int ct = wave; ct < FP / 16; ct += 4) {
+        f32x4 acc[RT];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) acc[rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        mfma_strip<RT>(acc, sH, AS, net.WeT, FP, ct * 16, KSP);
+        const int f = ct * 16 + (lane & 15);
         const float bias = net.be[f];
         float m = -INFINITY;
         int ts = 0;
-        for (int t0 = 0; t0 < rows; t0 += CNN_TB) {
-            float acc[CNN_TB];
 #pragma unroll
-            for (int r = 0; r < CNN_TB; ++r) acc[r] = bias;
-            fma_block(acc, sH, AS, t0, net.WeT4, F, f, CP);
+        for (int rt = 0; rt < RT; ++rt) {
 #pragma unroll
-            for (int r = 0; r < CNN_TB; ++r) {
-                const float v = fmaxf(acc[r], 0.f);
-                if (t0 + r < T && v > m) { m = v; ts = t0 + r; }
+            for (int j = 0; j < 4; ++j) {
+                const int t = rt * 16 + (lane >> 4) * 4 + j;
+                const float v = fmaxf(acc[rt][j] + bias, 0.f);
+                if (t < T && v > m) { m = v; ts = t; }
             }
         }
-        sM[f] = m;
-        sTs[f] = ts;
+        // the four lane groups hold disjoint row sets of the same column: combine, smaller row on ties
+#pragma unroll
+        for (int o = 16; o < 64; o <<= 1) {
+            const float om = __shfl_xor(m, o);
+            const int ot = __shfl_xor(ts, o);
+            if (om > m || (om == m && ot < ts)) { m = om; ts = ot; }
+        }
+        if (lane < 16) { sM[f] = m; sTs[f] = ts; }
     }
     __syncthreads();
 
-    // ---- out = bd + wd . m  (fixed tree)
+    PPDE_STAMP(a.dbg, 43, stamp);
+    // ---- out = bd + wd . m  (fixed tree); the routing coefficients scale * wd_f (0 for features whose max is not
+    //      positive) replace m in LDS so that the route loop touches LDS only
     {
         float s = 0.f;
-        for (int f = tid; f < F; f += 256) s += net.wd[f] * sM[f];
-        const float tot = block_sum<4>(s, red, phase);
+        float cf[2] = {0.f, 0.f};
+        int k = 0;
+        for (int f = tid; f < FP; f += 256, ++k) {
+            const float wdf = f < F ? net.wd[f] : 0.f, mf = sM[f];
+            s += wdf * mf;
+            if (k < 2) cf[k] = (f < F && mf > 0.f) ? a.scale * wdf : 0.f;
+        }
+        const float tot = block_sum<4>(s, red, phase);             // (its barrier also orders the sM rewrite below)
         if (tid == 0) a.fitC[((size_t)slot * a.n_nets + ni) * a.n + b] = tot + net.bd;
+        k = 0;
+        for (int f = tid; f < FP; f += 256, ++k)
+            if (k < 2) sM[f] = cf[k];
     }
+    PPDE_STAMP(a.dbg, 44, stamp);
     if (!a.want_grad) return;
 
-    // ---- route: dH1[t*_f][o] += scale * wd_f * We[f][o] for every feature whose max is positive;
-    //      thread = channel, features in index order (deterministic)
-    for (int o = tid; o < CP; o += 256) {
-        for (int f = 0; f < F; ++f) {
-            if (sM[f] > 0.f) {
-                const float c = a.scale * net.wd[f];
-                sD[sTs[f] * AS + o] += c * net.We[(size_t)f * CP + o];
+    // ---- clear the second route accumulator (h1's storage: its ReLU gate is already in sG)
+    float* sD2 = sH;
+    for (int o = oc; o < AS; o += 128) {
+#pragma unroll 8
+        for (int t = th; t < rows; t += 2) sD2[t * AS + o] = 0.f;
+    }
+    __syncthreads();
+    PPDE_STAMP(a.dbg, 45, stamp);
+    // ---- route: dH1[t*_f][o] += coef_f * We[f][o]. Thread = (channel, half of the features); each half accumulates
+    //      in feature order into its own array (deterministic); the next batch of We rows is in flight while the
+    //      current one is added. (LDS float atomics instead of the read-modify-write were measured 4.5x SLOWER.)
+    for (int wi = tid; wi < 2 * CP; wi += 256) {
+        const int half = wi >= CP ? 1 : 0, o = wi - half * CP;
+        float* dst = half ? sD2 : sD;
+        const int f_lo = half ? FP / 2 : 0, f_hi = half ? FP : FP / 2;    // FP is a multiple of 16: whole batches of 8
+        float wn[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) wn[j] = net.We[(size_t)(f_lo + j) * CP + o];   // We has FP rows (zero padded)
+        for (int f0 = f_lo; f0 < f_hi; f0 += 8) {
+            float w[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) w[j] = wn[j];
+            if (f0 + 8 < f_hi) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) wn[j] = net.We[(size_t)(f0 + 8 + j) * CP + o];
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float c = sM[f0 + j];
+                if (c != 0.f) dst[sTs[f0 + j] * AS + o] += c * w[j];
             }
         }
     }
     __syncthreads();
-    // ---- gate by the first ReLU
-    for (int e = tid; e < rows * AS; e += 256) {
-        if (!(sH[e] > 0.f)) sD[e] = 0.f;
-    }
+    PPDE_STAMP(a.dbg, 46, stamp);
+    // ---- d pre1 = gate * (half 0 + half 1)
+    for (int o = oc; o < AS; o += 128)
+        for (int t0 = th; t0 < rows; t0 += 8) {                // four rows per round: all LDS reads, then all writes
+            float x[4], y[4];
+            uint32_t gb[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int e = (t0 + 2 * u) * AS + o;
+                x[u] = sD[e]; y[u] = sD2[e];
+                gb[u] = sG[(t0 + 2 * u) * BW + (min(o, CP - 1) >> 5)];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const bool on = o < CP && ((gb[u] >> (o & 31)) & 1u);
+                sD[(t0 + 2 * u) * AS + o] = on ? x[u] + y[u] : 0.f;
+            }
+        }
     __syncthreads();
-    // ---- O[t][kappa*20 + c] = sum_o dpre1[t][o] Wc[o][c][kappa]   (O aliases h1)
+    PPDE_STAMP(a.dbg, 47, stamp);
+    // ---- O[t][kappa*20 + c] = sum_o dpre1[t][o] Wc[o][c][kappa] on the matrix cores (O takes h1's storage)
     float* sO = sH;
-    for (int w = tid; w < J * (rows / CNN_TB); w += 256) {
-        const int j = w % J, t0 = (w / J) * CNN_TB;
-        float acc[CNN_TB];
+    for (int ct = wave; ct < JP / 16; ct += 4) {
+        f32x4 acc[RT];
 #pragma unroll
-        for (int r = 0; r < CNN_TB; ++r) acc[r] = 0.f;
-        fma_block(acc, sD, AS, t0, net.Wf4, J, j, CP);
+        for (int rt = 0; rt < RT; ++rt) acc[rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        mfma_strip<RT>(acc, sD, AS, net.Wf, JP, ct * 16, KSP);
+        const int j = ct * 16 + (lane & 15);
+        if (j < J) {
 #pragma unroll
-        for (int r = 0; r < CNN_TB; ++r) sO[(t0 + r) * OS + j] = acc[r];
+            for (int rt = 0; rt < RT; ++rt) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) sO[(rt * 16 + (lane >> 4) * 4 + q) * OS + j] = acc[rt][q];
+            }
+        }
     }
     __syncthreads();
+    PPDE_STAMP(a.dbg, 48, stamp);
     // ---- transposed convolution: dx[p][c] = sum_kappa O[p - kappa][kappa*20 + c]
     float* out = a.gradC + (((size_t)slot * a.n_nets + ni) * a.n + b) * g.N;
     for (int e = tid; e < g.N; e += 256) {
         const int p = e / 20, c = e - 20 * p;
-        float v = 0.f;
-        for (int kp = 0; kp < K; ++kp) {
-            const int t = p - kp;
-            if (t >= 0 && t < T) v += sO[t * OS + kp * 20 + c];
+        float ov[KT];
+#pragma unroll
+        for (int kp = 0; kp < KT; ++kp) {
+            const int t = min(max(p - kp, 0), T - 1);               // clamped address, masked value: no branch
+            const float x = sO[t * OS + kp * 20 + c];
+            ov[kp] = (p - kp >= 0 && p - kp < T) ? x : 0.f;
         }
+        float v = 0.f;
+#pragma unroll
+        for (int kp = 0; kp < KT; ++kp) v += ov[kp];
         out[e] = v;
     }
+    PPDE_STAMP(a.dbg, 49, stamp);
 }

@@ -53,7 +53,7 @@ struct ppde_model {
     float wt_H = 0.f;
     // CNN
     bool has_cnn = false;
-    int n_nets = 0, C = 0, CP = 0, K = 0, F = 0, T = 0, J = 0;
+    int n_nets = 0, C = 0, CP = 0, K = 0, KT = 0, F = 0, FP = 0, T = 0, J = 0, JP = 0;
     CnnNet nets[4]{};
     std::vector<void*> cnn_allocs;
     float lamda = 0.f;
@@ -154,15 +154,29 @@ static int launch_cnn(const ppde_model* m, const uint8_t* states, int n, const E
                       float scale, hipStream_t s, int b_off = 0, int n_sub = -1) {
     if (n_sub < 0) n_sub = n;
     CnnArgs a{};
-    a.b_off = b_off;
+    a.b_off = b_off; a.dbg = t.dbg;
     for (int k = 0; k < m->n_nets; ++k) a.net[k] = m->nets[k];
-    a.n_nets = m->n_nets; a.C = m->C; a.CP = m->CP; a.K = m->K; a.F = m->F; a.T = m->T; a.J = m->J;
+    a.n_nets = m->n_nets; a.C = m->C; a.CP = m->CP; a.K = m->K; a.KT = m->KT; a.F = m->F; a.FP = m->FP; a.T = m->T; a.J = m->J; a.JP = m->JP;
     a.idx = states; a.gradC = t.gradC; a.fitC = t.fitC;
     a.slot = t.slot; a.n = n; a.want_grad = want_grad; a.scale = scale;
     a.g = m->g;
-    size_t lds = cnn_lds_bytes(m->T, m->CP, m->F, m->J, m->L);
-    ARGCHK(lds <= 160 * 1024, "sequence too long for the LDS-resident CNN kernel");
-    hipLaunchKernelGGL(k_cnn, dim3(n_sub, m->n_nets), dim3(256), lds, s, a);
+    size_t lds = cnn_lds_bytes(m->T, m->CP, m->FP, m->J, m->L);
+    ARGCHK(lds <= 160 * 1024 && cnn_rows(m->T) <= 16 * CNN_MAX_RT, "sequence too long for the LDS-resident CNN kernel (L <= 132)");
+    const dim3 grid(n_sub, m->n_nets);
+#define PPDE_CNN(RTV)                                                                           \
+    if (m->KT == 5) hipLaunchKernelGGL((k_cnn<RTV, 5>), grid, dim3(256), lds, s, a);              \
+    else hipLaunchKernelGGL((k_cnn<RTV, CNN_MAX_K>), grid, dim3(256), lds, s, a);
+    switch (cnn_rows(m->T) / 16) {
+        case 1: PPDE_CNN(1) break;
+        case 2: PPDE_CNN(2) break;
+        case 3: PPDE_CNN(3) break;
+        case 4: PPDE_CNN(4) break;
+        case 5: PPDE_CNN(5) break;
+        case 6: PPDE_CNN(6) break;
+        case 7: PPDE_CNN(7) break;
+        default: PPDE_CNN(8) break;
+    }
+#undef PPDE_CNN
     HIPCHK(hipGetLastError());
     return PPDE_OK;
 }
@@ -286,13 +300,18 @@ int ppde_model_set_cnn(ppde_model* m, int n_nets, int C, int K, int F, const flo
                        const float* const* dec_w, const float* const* dec_b) {
     ARGCHK(m && conv_w && conv_b && lin_w && lin_b && dec_w && dec_b, "null argument");
     ARGCHK(n_nets >= 1 && n_nets <= 4, "1..4 networks supported");
-    ARGCHK(K >= 1 && K <= m->L && C >= 1 && F >= 1, "bad CNN shape");
+    ARGCHK(K >= 1 && K <= CNN_MAX_K && K <= m->L && C >= 1 && F >= 1, "bad CNN shape (kernel size 1..8)");
     HIPCHK(hipSetDevice(m->device));
     for (void* p : m->cnn_allocs) hipFree(p);
     m->cnn_allocs.clear();
-    m->n_nets = n_nets; m->C = C; m->K = K; m->F = F; m->T = m->L - K + 1; m->J = K * 20;
-    const int CP = (C + 3) & ~3;
+    m->n_nets = n_nets; m->C = C; m->K = K; m->F = F; m->T = m->L - K + 1;
+    m->KT = (K == 5) ? 5 : CNN_MAX_K;            // tables hold KT taps (zero padded beyond K)
+    m->J = m->KT * 20;
+    const int KT = m->KT;
+    const int CP = (C + 4 * CNN_KB - 1) / (4 * CNN_KB) * (4 * CNN_KB);   // contraction length: whole B bursts
     m->CP = CP;
+    const int FP = (F + 15) & ~15, JP = (m->J + 15) & ~15;
+    m->FP = FP; m->JP = JP;
     auto up = [&](const std::vector<float>& v, const float** out) -> int {
         float* d = nullptr;
         HIPCHK(dalloc(&d, v.size()));
@@ -303,33 +322,35 @@ int ppde_model_set_cnn(ppde_model* m, int n_nets, int C, int K, int F, const flo
     };
     for (int k = 0; k < n_nets; ++k) {
         CnnNet& nt = m->nets[k];
-        std::vector<float> WcT((size_t)K * 20 * CP, 0.f), bc(CP, 0.f), WeT4((size_t)CP * F, 0.f), We((size_t)F * CP, 0.f),
-            Wf4((size_t)CP * m->J, 0.f);
+        std::vector<float> WcT((size_t)KT * 20 * CP, 0.f), bc(CP, 0.f), WeT((size_t)CP * FP, 0.f), We((size_t)FP * CP, 0.f),
+            Wf((size_t)CP * JP, 0.f), be(FP, 0.f), wd(FP, 0.f);
         for (int o = 0; o < C; ++o) {
             bc[o] = conv_b[k][o];
             for (int c = 0; c < 20; ++c)
                 for (int kp = 0; kp < K; ++kp) {
                     const float w = conv_w[k][((size_t)o * 20 + c) * K + kp];
                     WcT[((size_t)kp * 20 + c) * CP + o] = w;
-                    Wf4[(((size_t)(o / 4)) * m->J + (kp * 20 + c)) * 4 + (o & 3)] = w;
+                    Wf[(size_t)o * JP + (kp * 20 + c)] = w;
                 }
         }
-        for (int f = 0; f < F; ++f)
+        for (int f = 0; f < F; ++f) {
+            be[f] = lin_b[k][f];
+            wd[f] = dec_w[k][f];
             for (int o = 0; o < C; ++o) {
                 const float w = lin_w[k][(size_t)f * C + o];
                 We[(size_t)f * CP + o] = w;
-                WeT4[(((size_t)(o / 4)) * F + f) * 4 + (o & 3)] = w;
+                WeT[(size_t)o * FP + f] = w;
             }
-        std::vector<float> be(lin_b[k], lin_b[k] + F), wd(dec_w[k], dec_w[k] + F);
+        }
         const float* p;
         int rc;
         if ((rc = up(WcT, &p))) return rc; nt.WcT = p;
         if ((rc = up(bc, &p))) return rc; nt.bc = p;
-        if ((rc = up(WeT4, &p))) return rc; nt.WeT4 = (const float4*)p;
+        if ((rc = up(WeT, &p))) return rc; nt.WeT = p;
         if ((rc = up(We, &p))) return rc; nt.We = p;
         if ((rc = up(be, &p))) return rc; nt.be = p;
         if ((rc = up(wd, &p))) return rc; nt.wd = p;
-        if ((rc = up(Wf4, &p))) return rc; nt.Wf4 = (const float4*)p;
+        if ((rc = up(Wf, &p))) return rc; nt.Wf = p;
         nt.bd = dec_b[k][0];
     }
     free_scratch(m);

@@ -18,10 +18,11 @@ _hip.LIB_PATH = dbg
 from bench import build_model
 from ppde_amd.sampler import Chains
 
-m, wt, J, h, i0, Lp, cnn = build_model("potts", "cuda:0")
+WORK = "potts+cnn" if "--cnn" in sys.argv else "potts"
+m, wt, J, h, i0, Lp, cnn = build_model(WORK, "cuda:0")
 n = 128
-pas = int(sys.argv[1]) if len(sys.argv) > 1 else 2
-ch = Chains(m, n, 64, pas, 0, False, i0, i0 + Lp - 1, 1, 1, reuse_grad=False, use_graph=False, seed=1)
+pas = 2
+ch = Chains(m, n, 64, pas, 0, False, i0, i0 + Lp - 1, 3 if cnn else 1, 1, reuse_grad=False, use_graph=False, seed=1)
 ch.init(torch.as_tensor(np.tile(wt, (n, 1))).cuda())
 lib = _hip.load()
 lib.ppde_debug_read_stamps.restype = C.c_int
@@ -33,14 +34,16 @@ NAMES = {0: "potts entry", 1: "potts DMAs issued", 2: "potts states landed+barri
          16: "propose s>=1 merged2", 17: "propose s>=1 end", 18: "propose loop done", 19: "propose end",
          24: "accept entry", 25: "accept row staged", 26: "accept loop done", 27: "accept decision", 28: "accept count done",
          29: "accept end", 30: "accept row loads issued", 31: "accept prefetch issued", 32: "accept path staged",
-         33: "accept row committed"}
+         33: "accept row committed", 40: "cnn entry", 41: "cnn letters staged", 42: "cnn h1 built", 43: "cnn forward contraction + max",
+         44: "cnn output written", 45: "cnn gate bits + clear", 46: "cnn routed", 47: "cnn gated", 48: "cnn backward contraction",
+         49: "cnn end"}
 acc = {}
 for rep in range(20):
     ch.run(1)
     out = np.zeros(128, dtype=np.uint64)
     _hip.check(lib.ppde_debug_read_stamps(ch.handle, out.ctypes.data))
     st = out.reshape(64, 2)
-    for grp in ((0, 1, 2, 3, 4, 5), (8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19), (24, 30, 31, 32, 33, 25, 26, 27, 28, 29)):
+    for grp in ((0, 1, 2, 3, 4, 5), (8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19), (24, 30, 31, 32, 33, 25, 26, 27, 28, 29), (40, 41, 42, 43, 44, 45, 46, 47, 48, 49)):
         prev = None
         for k in grp:
             if st[k, 0] == 0:

@@ -1,0 +1,92 @@
+"""GPU parity at the other proteins' shapes (BASELINE.json configs 4/5 sizes) and odd geometries: every kernel
+instantiation (chain groups per thread, Potts chunk counts, CNN row tiles, padded convolution taps) against the oracle."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import ppde_oracle as orc
+from helpers import oracle_energy
+from ppde_amd import synthetic
+from ppde_amd.encoding import seqs_to_idx
+
+
+def _model(L, Lp, i0, with_cnn, lam, seed=5, K=5):
+    from ppde_amd.energy import HipModel
+    rng = np.random.default_rng(seed)
+    wt = rng.integers(0, 20, L).astype(np.uint8)
+    J, h = synthetic.make_potts(Lp, seed=seed, symmetric=False)
+    cnn = None
+    if with_cnn:
+        cnn = [synthetic.make_cnn_state(L, s, kernel_size=K) for s in range(3)]
+    m = HipModel(wt, "cuda:0")
+    m.set_potts(J, h, i0)
+    if cnn:
+        m.set_cnn(cnn)
+    m.set_lamda(lam)
+    return m, wt, J, h, cnn
+
+
+@pytest.mark.parametrize("L,Lp,i0,with_cnn", [(237, 237, 0, False),      # GFP: window = whole protein
+                                               (104, 76, 23, True),       # UBE4B: odd window start
+                                               (237, 100, 77, False), (40, 7, 31, True), (24, 16, 4, True)])
+def test_energy_grad_shapes(L, Lp, i0, with_cnn):
+    lam = 3.0 if with_cnn else 0.0
+    m, wt, J, h, cnn = _model(L, Lp, i0, with_cnn, lam)
+    en = oracle_energy(J, h, i0, wt, cnn, lam)
+    rng = np.random.default_rng(L)
+    idx = np.tile(wt, (20, 1))
+    for b in range(20):
+        pos = rng.choice(L, size=min(L, b), replace=False)
+        idx[b, pos] = rng.integers(0, 20, len(pos))
+    which = 3 if with_cnn else 1
+    e, f, g = m.energy_grad(torch.as_tensor(idx).cuda(), which)
+    eo, fo, go = en.energy_grad(torch.as_tensor(idx.astype(np.int64)))
+    scale = abs(float(en.potts.wt_H)) + 1.0
+    assert np.abs(e.cpu().numpy() - eo.numpy()).max() <= 2e-6 * 8 * (scale + np.abs(eo.numpy()).max()) + 1e-5 * lam
+    assert np.abs(f.cpu().numpy() - fo.numpy()).max() <= 5e-6
+    assert np.abs(g.cpu().numpy() - go.numpy()).max() <= 2e-5 * max(1.0, lam)
+
+
+def test_cnn_other_kernel_size():
+    """kernel size 3 goes through the zero-padded 8-tap instantiation"""
+    m, wt, J, h, cnn = _model(50, 30, 10, True, 2.0, K=3)
+    en = oracle_energy(J, h, 10, wt, cnn, 2.0)
+    idx = np.random.default_rng(0).integers(0, 20, (6, 50)).astype(np.uint8)
+    e, f, g = m.energy_grad(torch.as_tensor(idx).cuda(), 2)
+    fo, go = en.cnn.fit_grad(torch.as_tensor(idx.astype(np.int64)))
+    assert np.abs(f.cpu().numpy() - fo.numpy()).max() <= 5e-6
+    assert np.abs(g.cpu().numpy() - go.numpy()).max() <= 5e-6
+
+
+@pytest.mark.parametrize("L,Lp,i0,n,with_cnn", [(237, 237, 0, 24, False), (104, 76, 23, 20, True), (40, 7, 31, 1, True)])
+def test_sampler_vs_oracle_shapes(L, Lp, i0, n, with_cnn):
+    """Trajectories at GFP / UBE4B sizes and with a single chain, host-drawn noise into both implementations."""
+    from ppde_amd.sampler import Chains
+    lam = 2.0 if with_cnn else 0.0
+    m, wt, J, h, cnn = _model(L, Lp, i0, with_cnn, lam)
+    en = oracle_energy(J, h, i0, wt, cnn, lam)
+    T, pas, nmut = 12, 2, 4
+    torch.manual_seed(L + n)
+    noise = [orc.draw_noise_torch(n, L * 20, pas) for _ in range(T)]
+    ref = orc.run(en, np.tile(wt.astype(np.int64), (n, 1)), wt, lambda t: noise[t], T, i0, i0 + Lp - 1, pas, nmut, False, trace=True)
+    ch = Chains(m, n, T, pas, nmut, False, i0, i0 + Lp - 1, 3 if with_cnn else 1, 0, trace=True, random_chain=0)
+    ch.init(torch.as_tensor(np.tile(wt, (n, 1))).cuda())
+    for U, q, u in noise:
+        ch.run(1, (U.to(torch.int32).reshape(1, -1), q, u.reshape(1, -1), [int(q.shape[0])]))
+    tr, res = ch.trace(), ch.collect()
+    for t in range(T):
+        U = noise[t][0].numpy()
+        for s in range(int(U.max())):
+            act = s < U
+            assert np.array_equal(tr["flat"][t, s][act], ref["traces"][t]["flat"][s].numpy()[act]), (t, s)
+    assert np.array_equal(tr["accepted"].astype(bool), ref["accepted"].numpy())
+    assert np.array_equal(res["best_idx"], ref["best_idx"].numpy())
+    assert np.abs(res["energy_history"] - ref["energy_history"].numpy()).max() <= 1e-4
+    # and the device-RNG path runs at this shape (graph + fused kernels)
+    ch2 = Chains(m, n, 45, pas, nmut, False, i0, i0 + Lp - 1, 3 if with_cnn else 1, 1, seed=4)
+    ch2.init(torch.as_tensor(np.tile(wt, (n, 1))).cuda())
+    ch2.run(45)
+    r2 = ch2.collect()
+    assert np.isfinite(r2["energy_history"]).all() and np.array_equal(r2["best_energy"], r2["energy_history"].max(0))
