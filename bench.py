@@ -41,6 +41,7 @@ def parse():
     p.add_argument("--nmut", type=int, default=0)
     p.add_argument("--pas", type=int, default=2, help="ppde_pas_length (reference default 2)")
     p.add_argument("--streams", type=int, default=1, help="sub-populations run on separate HIP streams")
+    p.add_argument("--graph", type=int, default=1, help="replay iterations from a captured hipGraph")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-seconds", type=float, default=15.0)
     return p.parse_args()
@@ -99,10 +100,16 @@ def main():
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
+    backend = os.environ.get("PPDE_BENCH_BACKEND", "nccl")          # "gloo" + PPDE_BENCH_ONE_GPU=1: rehearse N ranks on one card
+    if os.environ.get("PPDE_BENCH_ONE_GPU"):
+        local = 0
     if world > 1:
         import torch.distributed as dist
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
     assert torch.cuda.is_available(), "bench.py needs a HIP device; there is no CPU fallback for the product path"
     device = f"cuda:{local}"
     torch.cuda.set_device(local)
@@ -120,7 +127,7 @@ def main():
 
     def timed_run(reuse):
         ch = Chains(m, n, T, args.pas, args.nmut, False, i0, i0 + Lp - 1, which, 1, reuse_grad=reuse,
-                    random_chain=0, use_graph=True, seed=1, chain_offset=rank * n, n_streams=args.streams)
+                    random_chain=0, use_graph=bool(args.graph), seed=1, chain_offset=rank * n, n_streams=args.streams)
         ch.init(torch.as_tensor(np.tile(wt, (n, 1))).to(device))
         ch.run(args.warmup)
         ch.sync()
@@ -133,7 +140,7 @@ def main():
         barrier()
         dt = time.perf_counter() - t0
         if world > 1:
-            t = torch.tensor([dt], device=device, dtype=torch.float64)
+            t = torch.tensor([dt], device=device if backend == "nccl" else "cpu", dtype=torch.float64)
             torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
             dt = float(t.item())
         return ch, dt
