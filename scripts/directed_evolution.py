@@ -48,13 +48,15 @@ def main(args):
         unique_token = "{}_{}_{}_{}".format(args.sampler, args.run_signature, args.seed,
                                             datetime.datetime.now().strftime("%Y-%m-%d_%H-%M-%S"))
     results_path = Path(args.results_path, args.protein, unique_token)
-    results_path.mkdir(parents=True, exist_ok=True)
+    if int(os.environ.get("RANK", 0)) == 0 or not args.ppde_shard:
+        results_path.mkdir(parents=True, exist_ok=True)
 
     if args.ppde_shard and "RANK" in os.environ and not torch.distributed.is_initialized():
-        local = int(os.environ.get("LOCAL_RANK", 0))
+        # one process per GPU; PPDE_ONE_GPU=1 + PPDE_DIST_BACKEND=gloo rehearse several ranks on a single card
+        local = 0 if os.environ.get("PPDE_ONE_GPU") else int(os.environ.get("LOCAL_RANK", 0))
         torch.cuda.set_device(local)
         args.device = f"cuda:{local}"
-        torch.distributed.init_process_group("nccl")
+        torch.distributed.init_process_group(os.environ.get("PPDE_DIST_BACKEND", "nccl"))
 
     if args.energy_function == "product_of_experts":
         energy_func = ProteinProductOfExperts(args)
@@ -102,6 +104,8 @@ def main(args):
     if not args.disable_MSA_transformer_scoring:
         print("MSA-Transformer scoring is not part of this build (needs the ESM-MSA-1b weights); skipped")
     print("done")
+    if args.ppde_shard and torch.distributed.is_initialized():
+        torch.distributed.barrier()
     return results_path
 
 
