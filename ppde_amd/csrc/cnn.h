@@ -309,3 +309,254 @@ __global__ __launch_bounds__(256, 2) void k_cnn(CnnArgs a) {
     }
     PPDE_STAMP(a.dbg, 49, stamp);
 }
+
+// =====================================================================================================
+// Long sequences (the [T x C] activations of one chain do not fit LDS next to the routed gradient, e.g. GFP,
+// L = 237): the same arithmetic cut along the length axis into two launches.
+//   k_cnn_fwd_chunk  grid (chain, network, NCH): rows [c*96, c*96+96): conv gather, forward contraction, the
+//                    chunk's max / arg-max per feature -> global scratch
+//   k_cnn_bwd_chunk  grid (chain, network, NCB): merges the chunk maxima (first index on ties), chunk 0 writes
+//                    the network output; then routes / gates / contracts the rows its OUTPUT positions
+//                    [c*PO, c*PO+PO) depend on, PO = 96 - (KT-1): the KT-1 halo rows are recomputed instead
+//                    of exchanged, so every output element has exactly one writer.
+// =====================================================================================================
+#define CNN_CH_RT 6                                   // 96 rows per chunk
+__host__ __device__ inline int cnn_fwd_chunks(int T) { return (T + CNN_CH_RT * 16 - 1) / (CNN_CH_RT * 16); }
+__host__ __device__ inline int cnn_bwd_out_per_chunk(int KT) { return CNN_CH_RT * 16 - (KT - 1); }
+__host__ __device__ inline int cnn_bwd_chunks(int L, int KT) { return (L + cnn_bwd_out_per_chunk(KT) - 1) / cnn_bwd_out_per_chunk(KT); }
+__host__ __device__ inline size_t cnn_fwd_chunk_lds(int CP) { return (size_t)CNN_CH_RT * 16 * cnn_astride(CP) * 4 + 256; }
+__host__ __device__ inline size_t cnn_bwd_chunk_lds(int CP, int FP, int J) {
+    const size_t rows = CNN_CH_RT * 16;
+    return rows * cnn_astride(CP) * 4 + rows * J * 4 + rows * ((CP + 31) / 32) * 4 + (size_t)FP * 12 + 512;
+}
+
+struct CnnChunkArgs {
+    CnnArgs a;
+    float* cmax;        // [nets][n][NCH][FP] chunk maxima of relu(pre2)
+    int* carg;          // [nets][n][NCH][FP] their rows
+    int NCH;
+};
+
+// h1 rows [t0, t0 + rows) of one chain into LDS (optionally only their ReLU gate bits)
+template <int KT, bool BITS_ONLY>
+__device__ __forceinline__ void cnn_build_rows(const CnnNet& net, const uint8_t* sSt, int t0, int rows, int T, int CP, int AS,
+                                               float* sH, uint32_t* sG, int BW) {
+    const int tid = threadIdx.x;
+    const int G4 = CP / 4, RPR = 256 / G4 > 0 ? 256 / G4 : 1;
+    for (int g4 = tid % (G4 < 256 ? G4 : 256); g4 < G4; g4 += 256) {
+        const int tr = tid / G4;
+        if (G4 < 256 && tr >= RPR) continue;
+        const float4 bias4 = *(const float4*)(net.bc + 4 * g4);
+        for (int r0 = (G4 < 256 ? tr : 0); r0 < rows; r0 += 2 * RPR) {
+            float4 wv[2][KT];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int tt = min(max(t0 + r0 + u * RPR, 0), T - 1);      // sSt is indexed by absolute residue
+#pragma unroll
+                for (int kp = 0; kp < KT; ++kp)
+                    wv[u][kp] = *(const float4*)(net.WcT + ((size_t)kp * 20 + sSt[tt + kp]) * CP + 4 * g4);
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int r = r0 + u * RPR, t = t0 + r;
+                if (r >= rows) continue;
+                float4 x = bias4;
+#pragma unroll
+                for (int kp = 0; kp < KT; ++kp) { x.x += wv[u][kp].x; x.y += wv[u][kp].y; x.z += wv[u][kp].z; x.w += wv[u][kp].w; }
+                const bool live = t >= 0 && t < T;
+                x.x = live ? fmaxf(x.x, 0.f) : 0.f; x.y = live ? fmaxf(x.y, 0.f) : 0.f;
+                x.z = live ? fmaxf(x.z, 0.f) : 0.f; x.w = live ? fmaxf(x.w, 0.f) : 0.f;
+                if constexpr (!BITS_ONLY) {
+                    float* hp = sH + r * AS + 4 * g4;
+                    *(float2*)hp = make_float2(x.x, x.y);
+                    *(float2*)(hp + 2) = make_float2(x.z, x.w);
+                } else {
+                    const uint32_t nib = (x.x > 0.f ? 1u : 0u) | (x.y > 0.f ? 2u : 0u) | (x.z > 0.f ? 4u : 0u) | (x.w > 0.f ? 8u : 0u);
+                    if (nib) atomicOr(&sG[r * BW + (g4 >> 3)], nib << (4 * (g4 & 7)));
+                }
+            }
+        }
+    }
+}
+
+template <int KT>
+__global__ __launch_bounds__(256) void k_cnn_fwd_chunk(CnnChunkArgs ca) {
+    extern __shared__ unsigned char smem_raw[];
+    const CnnArgs& a = ca.a;
+    const Geom g = a.g;
+    constexpr int RT = CNN_CH_RT, rows = RT * 16;
+    const int b = a.b_off + blockIdx.x, ni = blockIdx.y, c = blockIdx.z, tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const CnnNet net = a.net[ni];
+    const int T = a.T, CP = a.CP, FP = a.FP, AS = cnn_astride(CP), KSP = CP / 4;
+    float* sH = (float*)smem_raw;
+    uint8_t* sSt = (uint8_t*)(sH + (size_t)rows * AS);               // letters t0 .. t0 + rows + KT (relative index)
+    const int t0 = c * rows;
+    for (int l = tid; l < rows + CNN_MAX_K; l += 256) {
+        const int res = t0 + l;
+        sSt[l] = res < g.L ? min((int)a.idx[(size_t)b * g.Ls + g.sh + res], 19) : 0;
+    }
+    for (int e = tid; e < rows * 2; e += 256) sH[(e >> 1) * AS + CP + (e & 1)] = 0.f;
+    __syncthreads();
+    // sSt is relative to t0 here: shift the pointer so that cnn_build_rows can index by absolute residue
+    cnn_build_rows<KT, false>(net, sSt - t0, t0, rows, T, CP, AS, sH, nullptr, 0);
+    __syncthreads();
+    for (int ct = wave; ct < FP / 16; ct += 4) {
+        f32x4 acc[RT];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) acc[rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        mfma_strip<RT>(acc, sH, AS, net.WeT, FP, ct * 16, KSP);
+        const int f = ct * 16 + (lane & 15);
+        const float bias = net.be[f];
+        float m = -INFINITY;
+        int ts = 0;
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int t = t0 + rt * 16 + (lane >> 4) * 4 + j;
+                const float v = fmaxf(acc[rt][j] + bias, 0.f);
+                if (t < T && v > m) { m = v; ts = t; }
+            }
+        }
+#pragma unroll
+        for (int o = 16; o < 64; o <<= 1) {
+            const float om = __shfl_xor(m, o);
+            const int ot = __shfl_xor(ts, o);
+            if (om > m || (om == m && ot < ts)) { m = om; ts = ot; }
+        }
+        if (lane < 16) {
+            const size_t at = ((((size_t)ni * a.n + b) * ca.NCH) + c) * FP + f;
+            ca.cmax[at] = m;
+            ca.carg[at] = ts;
+        }
+    }
+}
+
+template <int KT>
+__global__ __launch_bounds__(256) void k_cnn_bwd_chunk(CnnChunkArgs ca) {
+    extern __shared__ unsigned char smem_raw[];
+    const CnnArgs& a = ca.a;
+    const Geom g = a.g;
+    constexpr int RT = CNN_CH_RT, rows = RT * 16;
+    const int b = a.b_off + blockIdx.x, ni = blockIdx.y, c = blockIdx.z, tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const CnnNet net = a.net[ni];
+    const int T = a.T, CP = a.CP, F = a.F, FP = a.FP, J = a.J, JP = a.JP, AS = cnn_astride(CP), KSP = CP / 4;
+    const int OS = J, BW = (CP + 31) / 32;
+    float* sD = (float*)smem_raw;                                     // [rows][AS] routed gradient
+    float* sO = sD + (size_t)rows * AS;                               // [rows][J]
+    uint32_t* sG = (uint32_t*)(sO + (size_t)rows * OS);               // [rows][BW]
+    float* sM = (float*)(sG + (size_t)rows * BW);                     // [FP] coefficients
+    int* sTs = (int*)(sM + FP);                                       // [FP] arg-max rows
+    int* sList = sTs + FP;                                            // [FP] features routed into this window, in order
+    float* red = (float*)(sList + FP);                                // 16 floats + 1 int
+    int* sCnt = (int*)(red + 16);
+    uint8_t* sSt = (uint8_t*)(sCnt + 4);                              // letters (relative to r0 - 0)
+    int phase = 0;
+    const int PO = cnn_bwd_out_per_chunk(KT);
+    const int p0 = c * PO, r0 = p0 - (KT - 1);                        // window rows r0 .. r0 + rows
+    const int slot = a.slot;
+
+    // ---- merge the forward chunks: first index on ties (chunks ascending, strict >)
+    float part = 0.f;
+    for (int f = tid; f < FP; f += 256) {
+        const size_t base = (((size_t)ni * a.n + b) * ca.NCH) * FP + f;
+        float m = -INFINITY;
+        int ts = 0;
+        for (int k = 0; k < ca.NCH; ++k) {
+            const float v = ca.cmax[base + (size_t)k * FP];
+            if (v > m) { m = v; ts = ca.carg[base + (size_t)k * FP]; }
+        }
+        const float wdf = f < F ? net.wd[f] : 0.f;
+        part += wdf * m;
+        sM[f] = (f < F && m > 0.f) ? a.scale * wdf : 0.f;
+        sTs[f] = ts;
+    }
+    const float tot = block_sum<4>(part, red, phase);
+    if (c == 0 && tid == 0) a.fitC[((size_t)slot * a.n_nets + ni) * a.n + b] = tot + net.bd;
+    if (!a.want_grad) return;
+
+    for (int l = tid; l < rows + CNN_MAX_K; l += 256) {
+        const int res = r0 + l;
+        sSt[l] = (res >= 0 && res < g.L) ? min((int)a.idx[(size_t)b * g.Ls + g.sh + res], 19) : 0;
+    }
+    for (int w = tid; w < rows * BW; w += 256) sG[w] = 0u;
+    for (int e = tid; e < rows * AS; e += 256) sD[e] = 0.f;
+    if (tid == 0) *sCnt = 0;
+    __syncthreads();
+    // ---- ReLU gate bits of the window's rows (h1 itself is not needed again)
+    cnn_build_rows<KT, true>(net, sSt - r0, r0, rows, T, CP, AS, nullptr, sG, BW);
+    // ---- features whose arg-max row lies in the window, compacted in feature order (one wave, ballot + prefix)
+    if (wave == 0) {
+        int cnt = 0;
+        for (int f0 = 0; f0 < FP; f0 += 64) {
+            const int f = f0 + lane;
+            const bool in = f < F && sM[f] != 0.f && sTs[f] >= r0 && sTs[f] < r0 + rows;
+            const unsigned long long bal = __ballot(in);
+            if (in) sList[cnt + __popcll(bal & ((1ull << lane) - 1ull))] = f;
+            cnt += __popcll(bal);
+        }
+        if (lane == 0) *sCnt = cnt;
+    }
+    __syncthreads();
+    const int nlist = *sCnt;
+    // ---- route (thread = channel, features in order), batches of 8 rows of We in flight
+    for (int o = tid; o < CP; o += 256) {
+        for (int k0 = 0; k0 < nlist; k0 += 8) {
+            float w[8], cf[8];
+            int rr[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int f = sList[min(k0 + j, nlist - 1)];
+                w[j] = net.We[(size_t)f * CP + o];
+                cf[j] = k0 + j < nlist ? sM[f] : 0.f;
+                rr[j] = sTs[f] - r0;
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (cf[j] != 0.f) sD[rr[j] * AS + o] += cf[j] * w[j];
+        }
+    }
+    __syncthreads();
+    // ---- gate
+    for (int o = tid & 127; o < AS; o += 128)
+        for (int r = tid >> 7; r < rows; r += 2) {
+            const bool on = o < CP && ((sG[r * BW + (min(o, CP - 1) >> 5)] >> (o & 31)) & 1u);
+            if (!on) sD[r * AS + o] = 0.f;
+        }
+    __syncthreads();
+    // ---- O = dpre1 x Wf on the matrix cores
+    for (int ct = wave; ct < JP / 16; ct += 4) {
+        f32x4 acc[RT];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) acc[rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        mfma_strip<RT>(acc, sD, AS, net.Wf, JP, ct * 16, KSP);
+        const int j = ct * 16 + (lane & 15);
+        if (j < J) {
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) sO[(rt * 16 + (lane >> 4) * 4 + q) * OS + j] = acc[rt][q];
+            }
+        }
+    }
+    __syncthreads();
+    // ---- transposed convolution for this chunk's own output positions
+    float* out = a.gradC + (((size_t)slot * a.n_nets + ni) * a.n + b) * g.N;
+    const int p1 = min(p0 + PO, g.L);
+    for (int e = p0 * 20 + tid; e < p1 * 20; e += 256) {
+        const int p = e / 20, cc = e - 20 * p;
+        float ov[KT];
+#pragma unroll
+        for (int kp = 0; kp < KT; ++kp) {
+            const int t = p - kp;                                       // absolute row; window row t - r0 is in [0, rows)
+            const float x = sO[(t - r0) * OS + kp * 20 + cc];
+            ov[kp] = (t >= 0 && t < T) ? x : 0.f;
+        }
+        float v = 0.f;
+#pragma unroll
+        for (int kp = 0; kp < KT; ++kp) v += ov[kp];
+        out[e] = v;
+    }
+}

@@ -62,6 +62,10 @@ struct ppde_model {
     uint8_t* s_state = nullptr;
     float *s_grad = nullptr, *s_epart = nullptr, *s_gradC = nullptr, *s_fitC = nullptr;
     int* s_flag = nullptr;
+    // chunk maxima of the long-sequence CNN path, sized for `cnn_scratch_n` chains
+    float* cnn_cmax = nullptr;
+    int* cnn_carg = nullptr;
+    int cnn_scratch_n = 0;
 };
 
 static void set_geom(ppde_model* m, int Lp, int i0) {
@@ -150,6 +154,20 @@ static int launch_potts(const ppde_model* m, const uint8_t* states, int n, const
     return PPDE_OK;
 }
 
+static bool cnn_single_launch(const ppde_model* m) {
+    return cnn_rows(m->T) <= 16 * CNN_MAX_RT && cnn_lds_bytes(m->T, m->CP, m->FP, m->J, m->L) <= 160 * 1024;
+}
+
+static int ensure_cnn_scratch(ppde_model* m, int n) {
+    if (cnn_single_launch(m) || n <= m->cnn_scratch_n) return PPDE_OK;
+    hipFree(m->cnn_cmax); hipFree(m->cnn_carg);
+    const size_t cnt = (size_t)m->n_nets * n * cnn_fwd_chunks(m->T) * m->FP;
+    HIPCHK(dalloc(&m->cnn_cmax, cnt));
+    HIPCHK(dalloc(&m->cnn_carg, cnt));
+    m->cnn_scratch_n = n;
+    return PPDE_OK;
+}
+
 static int launch_cnn(const ppde_model* m, const uint8_t* states, int n, const EvalTargets& t, int want_grad,
                       float scale, hipStream_t s, int b_off = 0, int n_sub = -1) {
     if (n_sub < 0) n_sub = n;
@@ -160,8 +178,24 @@ static int launch_cnn(const ppde_model* m, const uint8_t* states, int n, const E
     a.idx = states; a.gradC = t.gradC; a.fitC = t.fitC;
     a.slot = t.slot; a.n = n; a.want_grad = want_grad; a.scale = scale;
     a.g = m->g;
+    if (!cnn_single_launch(m)) {
+        // long sequences: forward chunks, then merge + backward chunks
+        ARGCHK(m->cnn_scratch_n >= n, "CNN chunk scratch not allocated for this batch size");
+        ARGCHK(cnn_fwd_chunk_lds(m->CP) <= 160 * 1024 && cnn_bwd_chunk_lds(m->CP, m->FP, m->J) <= 160 * 1024,
+               "sequence too long for the chunked CNN kernels");
+        CnnChunkArgs ca{a, m->cnn_cmax, m->cnn_carg, cnn_fwd_chunks(m->T)};
+        const dim3 gf(n_sub, m->n_nets, ca.NCH), gb(n_sub, m->n_nets, want_grad ? cnn_bwd_chunks(m->L, m->KT) : 1);
+        if (m->KT == 5) {
+            hipLaunchKernelGGL(k_cnn_fwd_chunk<5>, gf, dim3(256), cnn_fwd_chunk_lds(m->CP), s, ca);
+            hipLaunchKernelGGL(k_cnn_bwd_chunk<5>, gb, dim3(256), cnn_bwd_chunk_lds(m->CP, m->FP, m->J), s, ca);
+        } else {
+            hipLaunchKernelGGL((k_cnn_fwd_chunk<CNN_MAX_K>), gf, dim3(256), cnn_fwd_chunk_lds(m->CP), s, ca);
+            hipLaunchKernelGGL((k_cnn_bwd_chunk<CNN_MAX_K>), gb, dim3(256), cnn_bwd_chunk_lds(m->CP, m->FP, m->J), s, ca);
+        }
+        HIPCHK(hipGetLastError());
+        return PPDE_OK;
+    }
     size_t lds = cnn_lds_bytes(m->T, m->CP, m->FP, m->J, m->L);
-    ARGCHK(lds <= 160 * 1024 && cnn_rows(m->T) <= 16 * CNN_MAX_RT, "sequence too long for the LDS-resident CNN kernel (L <= 132)");
     const dim3 grid(n_sub, m->n_nets);
 #define PPDE_CNN(RTV)                                                                           \
     if (m->KT == 5) hipLaunchKernelGGL((k_cnn<RTV, 5>), grid, dim3(256), lds, s, a);              \
@@ -237,7 +271,7 @@ int ppde_model_destroy(ppde_model* m) {
     hipSetDevice(m->device);
     free_scratch(m);
     hipFree(m->s_flag);
-    hipFree(m->d_wt); hipFree(m->d_Jt); hipFree(m->d_h);
+    hipFree(m->d_wt); hipFree(m->d_Jt); hipFree(m->d_h); hipFree(m->cnn_cmax); hipFree(m->cnn_carg);
     for (void* p : m->cnn_allocs) hipFree(p);
     delete m;
     return PPDE_OK;
@@ -354,6 +388,8 @@ int ppde_model_set_cnn(ppde_model* m, int n_nets, int C, int K, int F, const flo
         nt.bd = dec_b[k][0];
     }
     free_scratch(m);
+    hipFree(m->cnn_cmax); hipFree(m->cnn_carg);
+    m->cnn_cmax = nullptr; m->cnn_carg = nullptr; m->cnn_scratch_n = 0;
     m->has_cnn = true;
     return PPDE_OK;
 }
@@ -416,6 +452,7 @@ int ppde_energy_grad(ppde_model* m, const uint8_t* idx_dev, int n, int which, fl
     hipStream_t s = (hipStream_t)stream;
     int rc = ensure_scratch(m, n);
     if (rc) return rc;
+    if ((which & 2) && m->has_cnn && (rc = ensure_cnn_scratch(m, n))) return rc;
     const Geom& g = m->g;
     hipLaunchKernelGGL(k_pack_state, dim3((n * g.Ls + 255) / 256), dim3(256), 0, s, idx_dev, m->s_state, n, g.L, g.Ls, g.sh);
     HIPCHK(hipGetLastError());
@@ -580,6 +617,10 @@ int ppde_chains_create(ppde_chains** out, ppde_model* m, const ppde_chain_config
     ARGCHK(cfg->chain_offset + (uint64_t)cfg->n_chains <= 0xffffffffull, "chain_offset + n_chains must fit 32 bits");
     ARGCHK(pas_lds_bytes(m->g) <= 160 * 1024 && m->g.N / 4 <= 3 * PPDE_BLOCK, "sequence too long for the chain kernels (L <= 307)");
     HIPCHK(hipSetDevice(m->device));
+    if (cfg->which & 2) {
+        int rc0 = ensure_cnn_scratch(m, cfg->n_chains);
+        if (rc0) return rc0;
+    }
     ppde_chains* c = new ppde_chains();
     c->m = m; c->cfg = *cfg; c->n = cfg->n_chains; c->T = cfg->max_steps; c->mu_max = 2 * cfg->pas_length - 1;
     const Geom& g = m->g;

@@ -28,7 +28,9 @@ def _model(L, Lp, i0, with_cnn, lam, seed=5, K=5):
     return m, wt, J, h, cnn
 
 
-@pytest.mark.parametrize("L,Lp,i0,with_cnn", [(237, 237, 0, False),      # GFP: window = whole protein
+@pytest.mark.parametrize("L,Lp,i0,with_cnn", [(237, 237, 0, True),       # GFP with its CNN: the chunked long-sequence kernels
+                                               (150, 60, 20, True), (133, 133, 0, True),
+                                               (237, 237, 0, False),      # GFP: window = whole protein
                                                (104, 76, 23, True),       # UBE4B: odd window start
                                                (237, 100, 77, False), (40, 7, 31, True), (24, 16, 4, True)])
 def test_energy_grad_shapes(L, Lp, i0, with_cnn):
@@ -60,7 +62,8 @@ def test_cnn_other_kernel_size():
     assert np.abs(g.cpu().numpy() - go.numpy()).max() <= 5e-6
 
 
-@pytest.mark.parametrize("L,Lp,i0,n,with_cnn", [(237, 237, 0, 24, False), (104, 76, 23, 20, True), (40, 7, 31, 1, True)])
+@pytest.mark.parametrize("L,Lp,i0,n,with_cnn", [(237, 237, 0, 24, False), (237, 237, 0, 6, True), (104, 76, 23, 20, True),
+                                                 (40, 7, 31, 1, True)])
 def test_sampler_vs_oracle_shapes(L, Lp, i0, n, with_cnn):
     """Trajectories at GFP / UBE4B sizes and with a single chain, host-drawn noise into both implementations."""
     from ppde_amd.sampler import Chains
