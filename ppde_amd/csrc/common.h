@@ -132,8 +132,6 @@ __device__ __forceinline__ float row8_max(float v) {
     v = fmaxf(v, dpp_f<DPP_HALF_MIRROR>(v));
     return lane_f(v, 0);
 }
-__device__ __forceinline__ unsigned long long row8_max_u64(unsigned long long v);
-
 // Block-wide reductions for NW waves. `scratch` holds 2 x NW floats; `phase` alternates the half in use so
 // that ONE barrier per reduction suffices. Every thread returns the same value; the tree (lane mirror steps,
 // rows, then waves pairwise in index order) does not depend on the data or on the launch.
@@ -166,40 +164,6 @@ __device__ __forceinline__ float block_max(float v, float* scratch, int& phase) 
     return tree_max<NW>(s);
 }
 
-// arg-max of (value, index) with the smaller index winning ties (what argmax over a row returns).
-__device__ __forceinline__ void argmax_combine(float& v, int& i, float ov, int oi) {
-    if (ov > v || (ov == v && oi < i)) { v = ov; i = oi; }
-}
-template <int CTRL>
-__device__ __forceinline__ void argmax_dpp(float& v, int& i) {
-    const float ov = dpp_f<CTRL>(v);
-    const int oi = dpp_i<CTRL>(i);
-    argmax_combine(v, i, ov, oi);
-}
-// wave-wide arg-max carrying two payloads (probability of the winner, letter it replaces); every lane ends
-// with the winner's tuple
-template <int CTRL>
-__device__ __forceinline__ void argmax_p_dpp(float& v, int& i, float& p, int& o) {
-    const float ov = dpp_f<CTRL>(v), op = dpp_f<CTRL>(p);
-    const int oi = dpp_i<CTRL>(i), oo = dpp_i<CTRL>(o);
-    if (ov > v || (ov == v && oi < i)) { v = ov; i = oi; p = op; o = oo; }
-}
-__device__ __forceinline__ void wave_argmax_p(float& v, int& i, float& p, int& o) {
-    argmax_p_dpp<DPP_XOR1>(v, i, p, o);
-    argmax_p_dpp<DPP_XOR2>(v, i, p, o);
-    argmax_p_dpp<DPP_HALF_MIRROR>(v, i, p, o);
-    argmax_p_dpp<DPP_MIRROR>(v, i, p, o);
-    float bv = lane_f(v, 0), bp = lane_f(p, 0);
-    int bi = __builtin_amdgcn_readlane(i, 0), bo = __builtin_amdgcn_readlane(o, 0);
-#pragma unroll
-    for (int r = 16; r < 64; r += 16) {
-        const float ov = lane_f(v, r);
-        const int oi = __builtin_amdgcn_readlane(i, r);
-        if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; bp = lane_f(p, r); bo = __builtin_amdgcn_readlane(o, r); }
-    }
-    v = bv; i = bi; p = bp; o = bo;
-}
-
 __device__ __forceinline__ unsigned long long row8_max_u64(unsigned long long v) {
     v = umax64(v, dpp_u64<DPP_XOR1>(v));
     v = umax64(v, dpp_u64<DPP_XOR2>(v));
@@ -207,29 +171,6 @@ __device__ __forceinline__ unsigned long long row8_max_u64(unsigned long long v)
     const unsigned int lo = (unsigned int)__builtin_amdgcn_readlane((int)(v & 0xffffffffull), 0);
     const unsigned int hi = (unsigned int)__builtin_amdgcn_readlane((int)(v >> 32), 0);
     return ((unsigned long long)hi << 32) | lo;
-}
-
-template <int NW>
-__device__ __forceinline__ void block_argmax(float& v, int& i, float* scratch_v, int* scratch_i, int& phase) {
-    argmax_dpp<DPP_XOR1>(v, i);
-    argmax_dpp<DPP_XOR2>(v, i);
-    argmax_dpp<DPP_HALF_MIRROR>(v, i);
-    argmax_dpp<DPP_MIRROR>(v, i);
-    {
-        float bv = lane_f(v, 0);
-        int bi = __builtin_amdgcn_readlane(i, 0);
-#pragma unroll
-        for (int r = 16; r < 64; r += 16) argmax_combine(bv, bi, lane_f(v, r), __builtin_amdgcn_readlane(i, r));
-        v = bv; i = bi;
-    }
-    float* sv = scratch_v + NW * (phase & 1);
-    int* si = scratch_i + NW * (phase & 1);
-    if ((threadIdx.x & 63) == 0) { sv[threadIdx.x >> 6] = v; si[threadIdx.x >> 6] = i; }
-    __syncthreads();
-    phase++;
-    v = sv[0]; i = si[0];
-#pragma unroll
-    for (int w = 1; w < NW; ++w) argmax_combine(v, i, sv[w], si[w]);
 }
 
 // ---------------------------------------------------------------------------------------------

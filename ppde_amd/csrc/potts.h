@@ -60,9 +60,6 @@ struct PottsArgs {
     Geom g;
 };
 
-typedef __attribute__((address_space(3))) void* lds_vptr;
-typedef const __attribute__((address_space(1))) void* glb_vptr;
-
 // s_waitcnt vmcnt(n) with a run-time n (the instruction takes an immediate)
 __device__ __forceinline__ void wait_vmcnt(int n) {
 #define PPDE_W(k) case k: __builtin_amdgcn_s_waitcnt(((k) & 0xF) | (((k) >> 4) << 14) | 0x0F70); break;
@@ -77,8 +74,8 @@ __device__ __forceinline__ void wait_vmcnt(int n) {
 }
 
 // LDS-DMA issued from inline asm is invisible to hipcc's wait-count bookkeeping, so the counted vmcnt waits
-// below are the only ones in the gather loop (with the builtin form hipcc drains vmcnt(0) before the first
-// ds_read of every chunk). M0 carries the wave-uniform LDS base and is restored (cdna_hip_programming.md §5.7).
+// below are the only ones in the gather loop (with __builtin_amdgcn_global_load_lds hipcc drains vmcnt(0) before
+// the first ds_read of every chunk). M0 carries the wave-uniform LDS base and is restored (cdna_hip_programming.md §5.7).
 // (gfx9 LDS instructions do not read M0, so it is not restored: nothing else in these kernels uses it.)
 __device__ __forceinline__ void glds16_asm(const void* gsrc, uint32_t lds_base) {
     asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(gsrc), "s"(lds_base) : "memory");
@@ -92,7 +89,7 @@ __host__ __device__ inline size_t potts_lds_bytes(int NC, int NG, int Ls) {
     return ((size_t)4 * NC * 80 + (size_t)4 * NG * 64) * 16 + (((size_t)NG * 64 * Ls + 1023) & ~(size_t)1023) + 1024;
 }
 
-template <int NG, int MODE>   // NG groups of 64 chains per workgroup; MODE 0 register staging, 1 LDS-DMA (asm), 2 LDS-DMA (builtin)
+template <int NG>   // NG groups of 64 chains per workgroup
 __global__ __launch_bounds__(256) void potts_energy_grad_kernel(PottsArgs a) {
     extern __shared__ float4 smem[];
     const Geom g = a.g;
@@ -109,67 +106,27 @@ __global__ __launch_bounds__(256) void potts_energy_grad_kernel(PottsArgs a) {
     float4* sR = smem + (size_t)4 * NC * 80;                    // [4][CPB]
     uint8_t* sS = (uint8_t*)(sR + 4 * CPB);                     // raw state rows of this chain block [CPB][Ls]
 
-    // ---- staging. REG path (default): plain 16-byte loads into registers, all issued up front (a load costs a
-    //      few issue cycles, an LDS-DMA piece 100+), then ds_write_b128 as each lands; this wave's slab rows are
-    //      private to it, so only the shared state rows need the barrier. DMA path (ASM/builtin): LDS-DMA pieces.
+    // ---- LDS-DMA, 1 KiB a piece: first the chain block's state rows (one contiguous, coalesced range shared by
+    //      the four waves), then this wave's own slab rows. Ls/4 is odd, so the strided letter reads below are
+    //      bank-conflict free. (Plain register staging + ds_write in this structure measured 8.7 us vs 5.0.)
     const int state_bytes = min(CPB, b_end - b0) * g.Ls;
     const char* ssrc = (const char*)(a.idx + (size_t)b0 * g.Ls);
     const int region_bytes = NC * 1280;
     const int npieces = (region_bytes + 1023) >> 10;
     const char* src = (const char*)(a.Jt + ((size_t)tile * 4 + part) * NC * 80);
-    if constexpr (MODE == 0) {
-        constexpr int SMAX = 4;                                 // state float4s per thread kept in flight (16 KiB per block)
-        float4 sv[SMAX];
-#pragma unroll
-        for (int k = 0; k < SMAX; ++k) {
-            const int off = (k * 256 + tid) * 16;
-            sv[k] = off < state_bytes ? *(const float4*)(ssrc + off) : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-        float4 jv[8];
-#pragma unroll
-        for (int p = 0; p < 8; ++p) {
-            const int off = p * 1024 + lane * 16;
-            if (p < npieces && off < region_bytes) jv[p] = *(const float4*)(src + off);
-        }
-#pragma unroll
-        for (int k = 0; k < SMAX; ++k) {
-            const int off = (k * 256 + tid) * 16;
-            if (off < state_bytes) *(float4*)(sS + off) = sv[k];
-        }
-        for (int off = (SMAX * 256 + tid) * 16; off < state_bytes; off += 4096)      // big chain blocks: the rest
-            *(float4*)(sS + off) = *(const float4*)(ssrc + off);
-        __syncthreads();
-#pragma unroll
-        for (int p = 0; p < 8; ++p) {
-            const int off = p * 1024 + lane * 16;
-            if (p < npieces && off < region_bytes) sT[p * 64 + lane] = jv[p];
-        }
-        for (int p = 8; p < npieces; ++p) {                     // long windows: the rest, synchronously
-            const int off = p * 1024 + lane * 16;
-            if (off < region_bytes) sT[p * 64 + lane] = *(const float4*)(src + off);
-        }
-    } else {
-        constexpr bool ASM = (MODE == 1);
-        const int spieces = (state_bytes + 1023) >> 10;
-        for (int p = part; p < spieces; p += 4) {
-            const int off = p * 1024 + lane * 16;
-            if (off < state_bytes) {
-                if constexpr (ASM) glds16_asm(ssrc + off, lds_offset_of(sS + p * 1024));
-                else __builtin_amdgcn_global_load_lds((glb_vptr)(ssrc + off), (lds_vptr)(sS + p * 1024), 16, 0, 0);
-            }
-        }
-        for (int p = 0; p < npieces; ++p) {
-            const int off = p * 1024 + lane * 16;
-            if (off < region_bytes) {
-                if constexpr (ASM) glds16_asm(src + off, lds_offset_of(sT + p * 64));
-                else __builtin_amdgcn_global_load_lds((glb_vptr)(src + off), (lds_vptr)(sT + p * 64), 16, 0, 0);
-            }
-        }
-        PPDE_STAMP(a.dbg, 1, stamp);
-        wait_vmcnt(npieces);                                    // my state pieces have landed (issued first) ...
-        if constexpr (ASM) asm volatile("" ::: "memory");
-        __builtin_amdgcn_s_barrier();                           // ... and so have the other waves'
+    const int spieces = (state_bytes + 1023) >> 10;
+    for (int p = part; p < spieces; p += 4) {
+        const int off = p * 1024 + lane * 16;
+        if (off < state_bytes) glds16_asm(ssrc + off, lds_offset_of(sS + p * 1024));
     }
+    for (int p = 0; p < npieces; ++p) {
+        const int off = p * 1024 + lane * 16;
+        if (off < region_bytes) glds16_asm(src + off, lds_offset_of(sT + p * 64));
+    }
+    PPDE_STAMP(a.dbg, 1, stamp);
+    wait_vmcnt(npieces);                                        // my state pieces have landed (issued first) ...
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_barrier();                               // ... and so have the other waves'
     PPDE_STAMP(a.dbg, 2, stamp);
     const uint8_t* myrow = sS + (size_t)lane * g.Ls + g.sh + g.i0 + 4 * part * NC;
 
@@ -178,11 +135,9 @@ __global__ __launch_bounds__(256) void potts_energy_grad_kernel(PottsArgs a) {
 #pragma unroll
     for (int gi = 0; gi < NG; ++gi) acc[gi] = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int ck = 0; ck < NC; ++ck) {
-        if constexpr (MODE != 0) {
-            const int need = min(((ck + 1) * 1280 + 1023) >> 10, npieces);
-            wait_vmcnt(npieces - need);
-            if constexpr (MODE == 1) asm volatile("" ::: "memory");
-        }
+        const int need = min(((ck + 1) * 1280 + 1023) >> 10, npieces);
+        wait_vmcnt(npieces - need);
+        asm volatile("" ::: "memory");
         const float4* rows = sT + ck * 80;
 #pragma unroll
         for (int gi = 0; gi < NG; ++gi) {
@@ -198,7 +153,7 @@ __global__ __launch_bounds__(256) void potts_energy_grad_kernel(PottsArgs a) {
     PPDE_STAMP(a.dbg, 3, stamp);
 #pragma unroll
     for (int gi = 0; gi < NG; ++gi) sR[part * CPB + gi * 64 + lane] = acc[gi];
-    if constexpr (MODE == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
     PPDE_STAMP(a.dbg, 4, stamp);

@@ -136,19 +136,14 @@ static int launch_potts(const ppde_model* m, const uint8_t* states, int n, const
     ARGCHK(((m->g.NC * 1280 + 1023) >> 10) <= 32, "Potts window too long for the LDS-DMA pipeline");
     ARGCHK(lds <= 160 * 1024, "Potts window too long for one LDS slab");
     dim3 grid(m->g.Lp * 5, (n_sub + NG * 64 - 1) / (NG * 64));
-    static const int mode = []() { const char* e = getenv("PPDE_POTTS_MODE"); return e ? atoi(e) : 1; }();
     ARGCHK(m->g.Ls <= 512, "state rows longer than 512 bytes are not supported by the Potts kernel staging");
-#define PPDE_LAUNCH(NGV)                                                                                     \
-    if (mode == 1) hipLaunchKernelGGL((potts_energy_grad_kernel<NGV, 1>), grid, dim3(256), lds, s, a);      \
-    else if (mode == 2) hipLaunchKernelGGL((potts_energy_grad_kernel<NGV, 2>), grid, dim3(256), lds, s, a); \
-    else hipLaunchKernelGGL((potts_energy_grad_kernel<NGV, 0>), grid, dim3(256), lds, s, a);
     switch (NG) {
-        case 1: PPDE_LAUNCH(1) break;
-        case 2: PPDE_LAUNCH(2) break;
-        case 4: PPDE_LAUNCH(4) break;
-        default: PPDE_LAUNCH(8) break;
+        case 1: hipLaunchKernelGGL(potts_energy_grad_kernel<1>, grid, dim3(256), lds, s, a); break;
+        case 2: hipLaunchKernelGGL(potts_energy_grad_kernel<2>, grid, dim3(256), lds, s, a); break;
+        case 4: hipLaunchKernelGGL(potts_energy_grad_kernel<4>, grid, dim3(256), lds, s, a); break;
+        default: hipLaunchKernelGGL(potts_energy_grad_kernel<8>, grid, dim3(256), lds, s, a); break;
     }
-#undef PPDE_LAUNCH
+
     HIPCHK(hipGetLastError());
     if (ep) HIPCHK(hipEventRecord(ep->ev[ep->used++], s));
     return PPDE_OK;

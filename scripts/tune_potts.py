@@ -22,14 +22,14 @@ if os.environ.get("PPDE_TUNE_CHILD"):
             ch.init(torch.as_tensor(idx).cuda())
             ts = [ch.time_potts_kernel(300) for _ in range(3)]
             alg = 4 * (Lp * 20) ** 2 + 4 * Lp * 20 + n * Lp + 4 * n * L * 20 + 8 * n
-            print(f"mode={os.environ.get('PPDE_POTTS_MODE','0')} NG={os.environ.get('PPDE_POTTS_NG','auto')} n={n} {kind}: "
+            print(f"NG={os.environ.get('PPDE_POTTS_NG','auto')} n={n} {kind}: "
                   f"{min(ts):.2f} us  -> {alg / min(ts) / 1e3:.0f} GB/s algorithmic", flush=True)
     sys.exit(0)
 
 ns = ",".join(sys.argv[1:]) or "128"
-for mode in ("0", "1"):
-    for ng in ("auto", "1"):
-        env = dict(os.environ, PPDE_TUNE_CHILD="1", PPDE_POTTS_MODE=mode, PPDE_TUNE_N=ns)
+for _ in (0,):
+    for ng in ("auto", "1", "2", "4"):
+        env = dict(os.environ, PPDE_TUNE_CHILD="1", PPDE_TUNE_N=ns)
         if ng != "auto":
             env["PPDE_POTTS_NG"] = ng
         r = subprocess.run([sys.executable, os.path.abspath(__file__)], env=env, capture_output=True, text=True)

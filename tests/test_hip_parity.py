@@ -266,3 +266,32 @@ def test_full_size_properties():
     same = (eh[1:] == eh[:-1]) | (eh[1:] == e_wt)
     assert same[~acc].all()
     assert 0.02 < acc.mean() < 0.98
+
+
+def test_error_paths():
+    """The reference's only runtime failure on this path is torch.distributions' ValueError on an undefined categorical
+    (every move masked out); the HIP path reports the same condition. API misuse returns errors instead of faulting."""
+    from ppde_amd._hip import PpdeHipError
+    from ppde_amd.sampler import Chains
+    fx = load("ops_toy24_lam5.npz")
+    J, h, i0, wt_idx, cnn = model_from_fixture(fx)
+    m = hip_model(J, h, i0, wt_idx, cnn, 5.0)
+    Lp = J.shape[0]
+    # a chain at the mutation cap whose only mutation lies outside [min_pos, max_pos]: no admissible move at all
+    start = np.tile(wt_idx, (4, 1))
+    start[:, 0] = (wt_idx[0] + 1) % 20
+    ch = Chains(m, 4, 3, 2, 1, False, i0, i0 + Lp - 1, 3, 1, seed=1)
+    ch.init(torch.as_tensor(start).cuda())
+    ch.run(1)
+    with pytest.raises(ValueError):
+        ch.sync()
+    ch2 = Chains(m, 4, 3, 2, 0, False, i0, i0 + Lp - 1, 3, 1, seed=1)
+    ch2.init(torch.as_tensor(start).cuda())
+    with pytest.raises(PpdeHipError):
+        ch2.run(5)                                   # beyond max_steps
+    with pytest.raises(PpdeHipError):
+        Chains(m, 4, 3, 2, 0, False, 5, 2, 3, 1)     # min_pos > max_pos
+    with pytest.raises(PpdeHipError):
+        m.energy_grad(torch.zeros(2, 24, dtype=torch.uint8).cuda(), 7)
+    with pytest.raises(ValueError):
+        m.onehot_to_idx(torch.zeros(2, 23, 20).cuda())
