@@ -8,7 +8,7 @@ import os
 import torch  # imported first on purpose: the library then binds to the HIP runtime torch already loaded
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libppde_hip.so")
+LIB_PATH = os.environ.get("PPDE_HIP_LIB") or os.path.join(_HERE, "libppde_hip.so")   # PPDE_HIP_LIB: tuning builds only
 
 OK, ERR_INVALID, ERR_HIP, ERR_NOT_ONEHOT, ERR_NUMERIC = 0, -1, -2, -3, -4
 

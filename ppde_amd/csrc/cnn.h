@@ -114,7 +114,7 @@ __global__ __launch_bounds__(256, 2) void k_cnn(CnnArgs a) {
     int phase = 0;
     const int slot = a.slot;
 
-    const bool stamp = blockIdx.x == 0 && blockIdx.y == 0;
+    [[maybe_unused]] const bool stamp = blockIdx.x == 0 && blockIdx.y == 0;
     PPDE_STAMP(a.dbg, 40, stamp);
     for (int l = tid; l < g.L + CNN_MAX_K; l += 256) sSt[l] = l < g.L ? min((int)a.idx[(size_t)b * g.Ls + g.sh + l], 19) : 0;
     __syncthreads();

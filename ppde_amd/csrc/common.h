@@ -5,7 +5,9 @@
 #include <stdint.h>
 
 #define PPDE_A 20
+#ifndef PPDE_BLOCK
 #define PPDE_BLOCK 512           // threads per workgroup of the chain-parallel kernels (8 waves, 2 per SIMD)
+#endif
 #define PPDE_NW (PPDE_BLOCK / 64)
 #define PPDE_EPS 1.1920928955078125e-07f   // 2^-23, clamp floor of torch.distributions.utils.clamp_probs
 
@@ -119,17 +121,20 @@ __device__ __forceinline__ float wave_max(float v) {
     return fmaxf(fmaxf(lane_f(v, 0), lane_f(v, 16)), fmaxf(lane_f(v, 32), lane_f(v, 48)));
 }
 
-// reductions over lanes 0..7 only (the cross-wave merges: one entry per wave); the result is valid in every lane
+// reductions over lanes 0..PPDE_NW-1 only (the cross-wave merges: one entry per wave, PPDE_NW in {4, 8, 16});
+// the result is valid in every lane
 __device__ __forceinline__ float row8_sum(float v) {
     v += dpp_f<DPP_XOR1>(v);
     v += dpp_f<DPP_XOR2>(v);
-    v += dpp_f<DPP_HALF_MIRROR>(v);
+    if (PPDE_NW > 4) v += dpp_f<DPP_HALF_MIRROR>(v);
+    if (PPDE_NW > 8) v += dpp_f<DPP_MIRROR>(v);
     return lane_f(v, 0);
 }
 __device__ __forceinline__ float row8_max(float v) {
     v = fmaxf(v, dpp_f<DPP_XOR1>(v));
     v = fmaxf(v, dpp_f<DPP_XOR2>(v));
-    v = fmaxf(v, dpp_f<DPP_HALF_MIRROR>(v));
+    if (PPDE_NW > 4) v = fmaxf(v, dpp_f<DPP_HALF_MIRROR>(v));
+    if (PPDE_NW > 8) v = fmaxf(v, dpp_f<DPP_MIRROR>(v));
     return lane_f(v, 0);
 }
 // Block-wide reductions for NW waves. `scratch` holds 2 x NW floats; `phase` alternates the half in use so
@@ -167,7 +172,8 @@ __device__ __forceinline__ float block_max(float v, float* scratch, int& phase) 
 __device__ __forceinline__ unsigned long long row8_max_u64(unsigned long long v) {
     v = umax64(v, dpp_u64<DPP_XOR1>(v));
     v = umax64(v, dpp_u64<DPP_XOR2>(v));
-    v = umax64(v, dpp_u64<DPP_HALF_MIRROR>(v));
+    if (PPDE_NW > 4) v = umax64(v, dpp_u64<DPP_HALF_MIRROR>(v));
+    if (PPDE_NW > 8) v = umax64(v, dpp_u64<DPP_MIRROR>(v));
     const unsigned int lo = (unsigned int)__builtin_amdgcn_readlane((int)(v & 0xffffffffull), 0);
     const unsigned int hi = (unsigned int)__builtin_amdgcn_readlane((int)(v >> 32), 0);
     return ((unsigned long long)hi << 32) | lo;

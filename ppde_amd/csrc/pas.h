@@ -226,7 +226,7 @@ __device__ __forceinline__ void row_max_sumexp(const RowLds& lds, const float4 (
     __syncthreads();
     const float mj = lane < PPDE_NW ? lds.xa[2 * (lane & (PPDE_NW - 1))] : -INFINITY;
     const float sj = lane < PPDE_NW ? lds.xa[2 * (lane & (PPDE_NW - 1)) + 1] : 0.f;
-    static_assert(PPDE_NW == 8, "the cross-wave merges assume 8 waves");
+    static_assert(PPDE_NW == 4 || PPDE_NW == 8 || PPDE_NW == 16, "the cross-wave merges cover 4, 8 or 16 waves");
     m = row8_max(mj);
     const float term = (mj == -INFINITY) ? 0.f : sj * expf(mj - m);
     S1 = row8_sum(term);

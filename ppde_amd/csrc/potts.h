@@ -100,7 +100,7 @@ __global__ __launch_bounds__(256) void potts_energy_grad_kernel(PottsArgs a) {
     const int tile = blockIdx.x;
     const int b0 = a.b_off + blockIdx.y * CPB;
     const int b_end = a.b_off + a.n_sub;
-    const bool stamp = blockIdx.x == 0 && blockIdx.y == 0;
+    [[maybe_unused]] const bool stamp = blockIdx.x == 0 && blockIdx.y == 0;
     PPDE_STAMP(a.dbg, 0, stamp);
     float4* sT = smem + (size_t)part * NC * 80;                 // this wave's rows of the slab
     float4* sR = smem + (size_t)4 * NC * 80;                    // [4][CPB]
