@@ -128,9 +128,8 @@ static int launch_potts(const ppde_model* m, const uint8_t* states, int n, const
     a.slot = t.slot; a.n = n;
     a.g = m->g;
     int NG = potts_ng_for(n_sub);
-    if (const char* e = getenv("PPDE_POTTS_NG")) NG = std::max(1, std::min(8, atoi(e)));   // tuning knob
-    if (NG == 3) NG = 2;
-    if (NG > 4 && NG < 8) NG = 4;
+    static const int ng_override = []() { const char* e = getenv("PPDE_POTTS_NG"); return e ? atoi(e) : 0; }();   // tuning knob
+    if (ng_override == 1 || ng_override == 2 || ng_override == 4 || ng_override == 8) NG = ng_override;
     size_t lds = potts_lds_bytes(m->g.NC, NG, m->g.Ls);
     while (lds > 150 * 1024 && NG > 1) { NG >>= 1; lds = potts_lds_bytes(m->g.NC, NG, m->g.Ls); }
     ARGCHK(((m->g.NC * 1280 + 1023) >> 10) <= 32, "Potts window too long for the LDS-DMA pipeline");
