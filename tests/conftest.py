@@ -13,6 +13,9 @@ GOLDEN = os.path.join(REPO, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # the CPU oracle runs small torch ops: a 256-thread intra-op pool (the GPU box's default) makes them far slower
+    import torch
+    torch.set_num_threads(min(8, os.cpu_count() or 1))
 
 
 @pytest.fixture(scope="session")

@@ -295,3 +295,26 @@ def test_error_paths():
         m.energy_grad(torch.zeros(2, 24, dtype=torch.uint8).cuda(), 7)
     with pytest.raises(ValueError):
         m.onehot_to_idx(torch.zeros(2, 23, 20).cuda())
+
+
+def test_long_replay_stays_on_the_oracle_trajectory():
+    """300 iterations x 16 chains (about 10k categorical draws, 4.8k accept decisions) on host-drawn noise: the HIP path
+    stays on the oracle's trajectory to the end -- draws can only differ on ~1e-6-wide near-ties."""
+    fx = load("ops_pabp_lam5.npz")
+    J, h, i0, wt_idx, cnn = model_from_fixture(fx)
+    lam, n, T, pas, nmut = 5.0, 16, 300, 2, 6
+    Lp, L = J.shape[0], wt_idx.shape[0]
+    torch.manual_seed(2024)
+    noise = [orc.draw_noise_torch(n, L * 20, pas) for _ in range(T)]
+    en = oracle_energy(J, h, i0, wt_idx, cnn, lam)
+    ref = orc.run(en, np.tile(wt_idx.astype(np.int64), (n, 1)), wt_idx, lambda t: noise[t], T, i0, i0 + Lp - 1, pas, nmut, False)
+    from ppde_amd.sampler import Chains
+    m = hip_model(J, h, i0, wt_idx, cnn, lam)
+    ch = Chains(m, n, T, pas, nmut, False, i0, i0 + Lp - 1, 3, 0, trace=True, random_chain=3)
+    ch.init(torch.as_tensor(np.tile(wt_idx, (n, 1))).cuda())
+    _feed(ch, noise, n)
+    tr, res = ch.trace(), ch.collect()
+    assert np.array_equal(tr["accepted"].astype(bool), ref["accepted"].numpy())
+    assert np.array_equal(res["best_idx"], ref["best_idx"].numpy())
+    assert np.array_equal(res["random_traj"], ref["states"][:, 3].numpy())
+    assert np.abs(res["energy_history"] - ref["energy_history"].numpy()).max() <= 5e-5
