@@ -119,6 +119,10 @@ class HipModel:
         """idx uint8 [n, L] on the device -> (e [n], fit [n], grad [n, L, 20] or None)."""
         idx = idx.to(self.device, torch.uint8).contiguous()
         n = idx.shape[0]
+        if idx.dim() != 2 or idx.shape[1] != self.L:
+            raise ValueError(f"states must be [n, {self.L}] residue indices, got {tuple(idx.shape)}")
+        if n and int(idx.max()) >= 20:
+            raise ValueError("residue indices must be in 0..19")
         e = torch.empty(n, dtype=torch.float32, device=self.device)
         fit = torch.empty(n, dtype=torch.float32, device=self.device)
         grad = torch.empty(n, self.L, 20, dtype=torch.float32, device=self.device) if want_grad else None

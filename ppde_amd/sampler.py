@@ -64,7 +64,10 @@ class Chains:
 
     def init(self, idx0):
         idx0 = idx0.to(self.model.device, torch.uint8).contiguous()
-        assert idx0.shape == (self.n, self.model.L)
+        if tuple(idx0.shape) != (self.n, self.model.L):
+            raise ValueError(f"initial states must be [{self.n}, {self.model.L}] residue indices, got {tuple(idx0.shape)}")
+        if int(idx0.max()) >= 20:
+            raise ValueError("residue indices must be in 0..19")
         torch.cuda.current_stream(self.model.device).synchronize()
         _hip.check(self.lib.ppde_chains_init(self.handle, _hip.ptr(idx0)))
 
