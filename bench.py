@@ -88,7 +88,7 @@ def cpu_baseline(args, wt, J, h, i0, Lp, cnn, n):
         return time.perf_counter() - t0
 
     t_probe = timed(3)
-    T = int(max(5, min(400, args.cpu_seconds / max(t_probe / 3, 1e-4))))
+    T = int(max(5, min(2000, args.cpu_seconds / max(t_probe / 3, 1e-4))))
     dt = timed(T)
     return {"value": T / dt, "unit": "MCMC steps/s", "cores": int(torch.get_num_threads()), "kind": "port",
             "sample": f"{T} iterations of the same workload ({n} chains, pas_length {args.pas}, noise drawn with torch's CPU "
