@@ -36,17 +36,11 @@ struct PasArgs {
     const float* fitC;          // [2][nets][n]     per-network predictions
     int n_nets;
     float* grad_cur;            // [n][N] combined gradient row of the CURRENT state (gradient-reuse mode)
-    float* cur_e;               // [n] energy / fitness of the current state (reuse mode)
-    float* cur_f;
+    unsigned char* rec;         // [n] ChainRec records (+ the pending path), stride rec_stride bytes
+    int rec_stride;
+    float wt_e, wt_f;           // energy / fitness of the wild type (what a mutation-cap reset continues from)
     const float* fb_grad;       // fallback gradient rows
     size_t fb_grad_stride;
-    const float* fb_e;
-    const float* fb_f;
-    int fb_ef_stride;
-    // hand-off between propose and accept
-    int* flat;                  // [n][mu_max]
-    float* logp_fwd;            // [n][mu_max]
-    int* Ucur;                  // [n]
     // caller-supplied noise of this iteration (rng_mode 0)
     const int* U_in;            // [n]
     const float* q_in;          // [max_u][n][N]
@@ -55,11 +49,7 @@ struct PasArgs {
     float* e_hist;              // [T+1][n]
     float* f_hist;
     uint8_t* best_state;        // [n][L]
-    float* best_e;
-    float* best_f;
-    int* best_t;
     uint8_t* rtraj;             // [T+1][L]
-    uint8_t* acc_last;          // [n]
     // trace (NULL when disabled)
     int* tr_flat;               // [T][mu_max][n]
     uint8_t* tr_acc;            // [T][n]
@@ -71,6 +61,24 @@ struct PasArgs {
 
 // LDS of a chain workgroup: the gradient row (float4[N/4]), the letters of the start state and of the wild
 // type, and two small exchange areas for the two reductions of a sub-step.
+// One record per chain: every per-chain scalar the chain kernels read or write in an iteration sits in one or
+// two cache lines (one vector load instead of ten scattered ones, and one kernel argument instead of twelve).
+struct ChainRec {
+    float cur_e, cur_f;         // energy / fitness of the state the chain continues from
+    float best_e, best_f;       // running best over the history (ppde.py:172-183)
+    int best_t;
+    int Ucur;                   // path length of the pending proposal
+    int dist_cur, dist_prop;    // mutation counts of the current state / of the pending proposal
+    float fb_e, fb_f;           // energy / fitness / mutation count of the chain's INITIAL state
+    int dist_fb;                //   (what a rejected chain falls back to under paper_results)
+    int acc_last;               // last accept bit (for the periodic log)
+    // followed by  int flat[mu_max]  and  float logp_fwd[mu_max]  of the pending path
+};
+__host__ __device__ inline int chain_rec_stride(int mu_max) { return ((int)sizeof(ChainRec) + 8 * mu_max + 15) & ~15; }
+__device__ __forceinline__ ChainRec* rec_of(const PasArgs& a, int b) { return (ChainRec*)(a.rec + (size_t)b * a.rec_stride); }
+__device__ __forceinline__ int* rec_flat(ChainRec* r) { return (int*)(r + 1); }
+__device__ __forceinline__ float* rec_logp(ChainRec* r, int mu_max) { return (float*)(rec_flat(r) + mu_max); }
+
 struct RowLds {
     float4* G;      // gradient row [N/4]
     float* xa;      // exchange A: NW x (max, sum)
@@ -196,13 +204,6 @@ __device__ __forceinline__ void load_row(const RowLds& lds, const Geom& g, const
     row_commit<GPT>(lds, g, q, R);
 }
 
-// number of residues where the staged state differs from the wild type (every wave computes it for itself)
-__device__ __forceinline__ int wave_mut_count(const RowLds& lds, int L) {
-    float c = 0.f;
-    for (int l = threadIdx.x & 63; l < L; l += 64) c += (lds.St[l] != lds.Wt[l]) ? 1.f : 0.f;
-    return (int)wave_sum(c);
-}
-
 // ---- reduction 1 of a sub-step: logits z (registers) -> (m, S1) with m = max z, S1 = sum exp(z - m).
 // Each wave reduces against its own maximum; the NW (max, sum) pairs are merged after ONE barrier as
 // S1 = sum_w s_w * exp(m_w - m) by lanes 0..NW-1 of every wave (same tree everywhere).
@@ -269,6 +270,7 @@ __device__ __forceinline__ void race_variates(const PasArgs& a, int b, int it, i
 template <int GPT>
 struct ProposePrefetch {
     int Ub;
+    int dist;                   // mutation count of the current state (from the chain record)
     float4 q0[GPT];
 };
 template <int GPT>
@@ -277,6 +279,7 @@ __device__ __forceinline__ ProposePrefetch<GPT> propose_prefetch(const PasArgs& 
     if (a.rng_mode == 0) p.Ub = a.U_in[b + opaque_zero()];
     else p.Ub = pathlen_from_bits(philox4x32_10(U4{a.key.chain_lo + (uint32_t)b, (uint32_t)it, 0u, 0u}, a.key.k0, a.key.k1).x, a.pas);
     p.Ub = min(max(p.Ub, 1), a.mu_max);
+    p.dist = rec_of(a, b + opaque_zero())->dist_cur;
     race_variates<GPT>(a, b, it, 0, p.q0);
     return p;
 }
@@ -285,8 +288,9 @@ __device__ __forceinline__ ProposePrefetch<GPT> propose_prefetch(const PasArgs& 
 // The forward path of one iteration (ppde.py:67-116). Expects lds.G / lds.St / lds.Wt staged and visible, R
 // holding the current letters, `dist` = mutation count of that state.
 template <int GPT>
-__device__ __forceinline__ void propose_body(const PasArgs& a, const RowLds& lds, RowRegs<GPT>& R, int b, int it, int dist,
+__device__ __forceinline__ void propose_body(const PasArgs& a, const RowLds& lds, RowRegs<GPT>& R, int b, int it, int dist0,
                                              const ProposePrefetch<GPT>& pp, bool stamp) {
+    int dist = dist0;
     const Geom g = a.g;
     const int tid = threadIdx.x, lane = tid & 63;
     const float* G = (const float*)lds.G;
@@ -373,8 +377,9 @@ __device__ __forceinline__ void propose_body(const PasArgs& a, const RowLds& lds
         dist += (int)(ks != wl) - (int)(old != wl);
         if (tid == 0) {
             lds.mv[2 * s] = ls; lds.mv[2 * s + 1] = ks;      // read one barrier later at the earliest
-            a.flat[b * a.mu_max + s] = win;
-            a.logp_fwd[b * a.mu_max + s] = logp;
+            ChainRec* rc = rec_of(a, b);
+            rec_flat(rc)[s] = win;
+            rec_logp(rc, a.mu_max)[s] = logp;
             if (a.tr_flat) a.tr_flat[((size_t)it * a.mu_max + s) * a.n + b] = win;
         }
         if (s + 1 < Ub) {
@@ -385,10 +390,12 @@ __device__ __forceinline__ void propose_body(const PasArgs& a, const RowLds& lds
     }
     PPDE_STAMP(a.dbg, 18, stamp);
     if (tid == 0) {
-        a.Ucur[b] = Ub;
+        ChainRec* rc = rec_of(a, b);
+        rc->Ucur = Ub;
+        rc->dist_prop = dist;
         if (a.tr_U) a.tr_U[(size_t)it * a.n + b] = Ub;
         for (int s = Ub; s < a.mu_max; ++s) {
-            a.flat[b * a.mu_max + s] = -1;
+            rec_flat(rc)[s] = -1;
             if (a.tr_flat) a.tr_flat[((size_t)it * a.mu_max + s) * a.n + b] = -1;
         }
     }
@@ -411,7 +418,7 @@ __global__ __launch_bounds__(PPDE_BLOCK) void k_propose(PasArgs a) {
     const ProposePrefetch<GPT> pp = propose_prefetch<GPT>(a, b, it);
     row_commit<GPT>(lds, a.g, rl, R);
     PPDE_STAMP(a.dbg, 9, stamp);
-    propose_body<GPT>(a, lds, R, b, it, wave_mut_count(lds, a.g.L), pp, stamp);
+    propose_body<GPT>(a, lds, R, b, it, __builtin_amdgcn_readfirstlane(pp.dist), pp, stamp);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -479,9 +486,9 @@ struct AcceptOut {
 
 // Loads issued at kernel entry for the accept phase (one round trip instead of ten).
 struct AcceptPrefetch {
-    int Ub;
+    int Ub, dist_cur, dist_prop, dist_fb;
     EnergyPrefetch py, px;
-    float cur_e, cur_f, best_e, u;
+    float cur_e, cur_f, best_e, fb_e, fb_f, u;
     int flat_v;      // thread t < mu_max: move t of the path
     float lpf_v;     //                    and its forward log-probability
 };
@@ -491,16 +498,19 @@ __device__ __forceinline__ AcceptPrefetch accept_prefetch(const PasArgs& a, cons
     q.cur_e = q.cur_f = q.u = q.lpf_v = 0.f;
     q.flat_v = 0;
     const int b = b0 + opaque_zero();               // keep these loads independent vector loads (see opaque_zero)
-    q.Ub = a.Ucur[b];
+    ChainRec* rc = rec_of(a, b);
+    q.Ub = rc->Ucur;
+    q.dist_cur = rc->dist_cur; q.dist_prop = rc->dist_prop; q.dist_fb = rc->dist_fb;
     q.py = prefetch_energy(a, 1, b);
-    if (a.reuse) { q.cur_e = a.cur_e[b]; q.cur_f = a.cur_f[b]; }
-    else q.px = prefetch_energy(a, 0, b);
-    q.best_e = a.best_e[b];
+    q.cur_e = rc->cur_e; q.cur_f = rc->cur_f;
+    q.fb_e = rc->fb_e; q.fb_f = rc->fb_f;
+    if (!a.reuse) q.px = prefetch_energy(a, 0, b);
+    q.best_e = rc->best_e;
     if (a.rng_mode == 0) q.u = a.u_in[b];
     else q.u = unif_from_bits(philox4x32_10(U4{a.key.chain_lo + (uint32_t)b0, (uint32_t)iteration_of(a), 1u, 0u}, a.key.k0, a.key.k1).x);
     if ((int)threadIdx.x < a.mu_max) {
-        q.flat_v = a.flat[b * a.mu_max + threadIdx.x];
-        q.lpf_v = a.logp_fwd[b * a.mu_max + threadIdx.x];
+        q.flat_v = rec_flat(rc)[threadIdx.x];
+        q.lpf_v = rec_logp(rc, a.mu_max)[threadIdx.x];
     }
     return q;
 }
@@ -525,8 +535,10 @@ __device__ __forceinline__ AcceptOut accept_body(const PasArgs& a, const RowLds&
     constexpr int sloty = 1;
     const EnergyPrefetch& py = pf.py;
     const EnergyPrefetch& px = pf.px;
-    const float cur_e = pf.cur_e, cur_f = pf.cur_f, best_e = pf.best_e;
+    const float cur_e = pf.cur_e, cur_f = pf.cur_f, best_e = pf.best_e, fb_e = pf.fb_e, fb_f = pf.fb_f;
     const float u = pf.u;
+    // plain copies: selecting between members of `pf` later would become an indexed (scratch) load
+    const int d_cur = pf.dist_cur, d_prop = pf.dist_prop, d_fb = pf.dist_fb;
     PPDE_STAMP(a.dbg, 25, stamp);
     float log_ratio = 0.f;
     for (int s = 0; s < Ub; ++s) {
@@ -574,24 +586,18 @@ __device__ __forceinline__ AcceptOut accept_body(const PasArgs& a, const RowLds&
     const float e_new = acc ? e_y : e_x, f_new = acc ? f_y : f_x;
 
     PPDE_STAMP(a.dbg, 27, stamp);
-    // ---- new state, mutation-cap reset, records
+    // ---- new state, mutation-cap reset, records. The mutation count comes from the records (the proposal's was
+    //      tracked along its path), so no block-wide count is needed here.
     const uint8_t* rej = a.paper ? a.fb_state + (size_t)b * a.fb_state_stride : nullptr;
-    float c = 0.f;
     int nv[GPT];
 #pragma unroll
     for (int r = 0; r < GPT; ++r) {
         nv[r] = 0;
-        if (R.valid[r] && R.kb[r] == 0) {
-            // rejected: back to x (still staged in LDS), or to the initial population under paper_results
-            nv[r] = acc ? R.cur[r] : (rej ? (int)rej[g.sh + R.l[r]] : (int)lds.St[R.l[r]]);
-            c += (nv[r] != R.wt[r]) ? 1.f : 0.f;
-        }
+        // rejected: back to x (still staged in LDS), or to the initial population under paper_results
+        if (R.valid[r] && R.kb[r] == 0) nv[r] = acc ? R.cur[r] : (rej ? (int)rej[g.sh + R.l[r]] : (int)lds.St[R.l[r]]);
     }
-    const float cw = wave_sum(c);
-    __syncthreads();                                 // xa is free again (all waves are past the last merge)
-    if (lane == 0) lds.xa[tid >> 6] = cw;
-    __syncthreads();
-    const int dist = (int)row8_sum(lane < PPDE_NW ? lds.xa[lane & (PPDE_NW - 1)] : 0.f);
+    const int d_rej = a.paper ? d_fb : d_cur;
+    const int dist = __builtin_amdgcn_readfirstlane(acc ? d_prop : d_rej);
     const bool reset = (!a.paper) & (dist >= a.thr);
     PPDE_STAMP(a.dbg, 28, stamp);
     const bool better = e_new > best_e;             // strict: first index on ties, like torch.max over history
@@ -608,13 +614,15 @@ __device__ __forceinline__ AcceptOut accept_body(const PasArgs& a, const RowLds&
     if (tid == 0) {
         a.e_hist[(size_t)(it + 1) * a.n + b] = e_new;
         a.f_hist[(size_t)(it + 1) * a.n + b] = f_new;
-        if (better) { a.best_e[b] = e_new; a.best_f[b] = f_new; a.best_t[b] = it + 1; }
-        a.acc_last[b] = acc ? 1 : 0;
+        ChainRec* rc = rec_of(a, b);
+        if (better) { rc->best_e = e_new; rc->best_f = f_new; rc->best_t = it + 1; }
+        rc->acc_last = acc ? 1 : 0;
+        rc->dist_cur = reset ? 0 : dist;
         if (a.tr_acc) { a.tr_acc[(size_t)it * a.n + b] = acc ? 1 : 0; a.tr_logacc[(size_t)it * a.n + b] = log_acc; }
         if (a.reuse) {                               // energy / fitness of the state the chain continues from
-            if (reset) { a.cur_e[b] = a.fb_e[0]; a.cur_f[b] = a.fb_f[0]; }
-            else if (acc) { a.cur_e[b] = e_y; a.cur_f[b] = f_y; }
-            else if (a.paper) { a.cur_e[b] = a.fb_e[b]; a.cur_f[b] = a.fb_f[b]; }
+            if (reset) { rc->cur_e = a.wt_e; rc->cur_f = a.wt_f; }
+            else if (acc) { rc->cur_e = e_y; rc->cur_f = f_y; }
+            else if (a.paper) { rc->cur_e = fb_e; rc->cur_f = fb_f; }
         }
     }
     PPDE_STAMP(a.dbg, 29, stamp);
@@ -718,15 +726,33 @@ __global__ void k_init_chain(PasArgs a) {
         a.best_state[(size_t)b * a.g.L + l] = v;
         if (b == a.random_chain) a.rtraj[l] = v;
     }
+    float c = 0.f;
+    for (int l = lane; l < a.g.L; l += 64)
+        c += (a.cur[(size_t)b * a.g.Ls + a.g.sh + l] != a.wt[a.g.sh + l]) ? 1.f : 0.f;
+    const int dist = (int)wave_sum(c);
     if (lane == 0) {
         a.e_hist[b] = e; a.f_hist[b] = f;
-        a.best_e[b] = e; a.best_f[b] = f; a.best_t[b] = 0;
-        a.cur_e[b] = e; a.cur_f[b] = f;
-        a.acc_last[b] = 0;
+        ChainRec* rc = rec_of(a, b);
+        rc->cur_e = e; rc->cur_f = f;
+        rc->best_e = e; rc->best_f = f; rc->best_t = 0;
+        rc->Ucur = 0; rc->dist_cur = dist; rc->dist_prop = dist;
+        rc->fb_e = e; rc->fb_f = f; rc->dist_fb = dist;
+        rc->acc_last = 0;
     }
 }
 
 __global__ void k_bump(int* it_base, int by) { *it_base += by; }
+
+// records -> plain arrays for the host (final collect / periodic log)
+__global__ void k_rec_gather(PasArgs a, float* best_e, float* best_f, int* best_t, uint8_t* acc) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= a.n) return;
+    const ChainRec* rc = rec_of(a, b);
+    if (best_e) best_e[b] = rc->best_e;
+    if (best_f) best_f[b] = rc->best_f;
+    if (best_t) best_t[b] = rc->best_t;
+    if (acc) acc[b] = (uint8_t)rc->acc_last;
+}
 
 // Combine gradient sources of slot 0 into plain rows (API edge, fallback rows): out[b][:] = row(b)
 __global__ void k_combine_rows(PasArgs a, float* out) {

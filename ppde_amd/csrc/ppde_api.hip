@@ -481,11 +481,14 @@ struct ppde_chains {
     bool initialised = false;
     // device buffers
     uint8_t *cur = nullptr, *prop = nullptr, *fb_state = nullptr, *best_state = nullptr,
-            *rtraj = nullptr, *acc_last = nullptr, *tr_acc = nullptr, *tmp_idx = nullptr;
-    float *grad_cur = nullptr, *grad = nullptr, *epart = nullptr, *gradC = nullptr, *fitC = nullptr, *cur_e = nullptr, *cur_f = nullptr,
-          *fb_grad = nullptr, *fb_e = nullptr, *fb_f = nullptr, *logp_fwd = nullptr, *e_hist = nullptr,
-          *f_hist = nullptr, *best_e = nullptr, *best_f = nullptr, *tr_logacc = nullptr;
-    int *flat = nullptr, *Ucur = nullptr, *best_t = nullptr, *tr_flat = nullptr, *tr_U = nullptr, *err_flag = nullptr,
+            *rtraj = nullptr, *tmp_acc = nullptr, *tr_acc = nullptr, *tmp_idx = nullptr;
+    unsigned char* rec = nullptr;                // [n] chain records
+    int rec_stride = 0;
+    float wt_e = 0.f, wt_f = 0.f;                // wild type's energy / fitness (mutation-cap reset under gradient reuse)
+    float *grad_cur = nullptr, *grad = nullptr, *epart = nullptr, *gradC = nullptr, *fitC = nullptr,
+          *fb_grad = nullptr, *fb_e = nullptr, *fb_f = nullptr, *e_hist = nullptr,
+          *f_hist = nullptr, *tmp_be = nullptr, *tmp_bf = nullptr, *tr_logacc = nullptr;
+    int *tmp_bt = nullptr, *tr_flat = nullptr, *tr_U = nullptr, *err_flag = nullptr,
         *d_it = nullptr, *tmp_dist = nullptr;
     unsigned long long* dbg = nullptr;           // stamps of the diagnostic build (64 x (cycles, 100 MHz ticks))
     // graph replay
@@ -509,12 +512,9 @@ static PasArgs chain_args(const ppde_chains* c) {
     a.cur = c->cur; a.prop = c->prop; a.fb_state = c->fb_state;
     a.fb_state_stride = c->cfg.paper_results ? m->g.Ls : 0;
     a.grad = c->grad; a.epart = c->epart; a.gradC = c->gradC; a.fitC = c->fitC;
-    a.grad_cur = c->grad_cur; a.cur_e = c->cur_e; a.cur_f = c->cur_f;
+    a.grad_cur = c->grad_cur; a.rec = c->rec; a.rec_stride = c->rec_stride; a.wt_e = c->wt_e; a.wt_f = c->wt_f;
     a.fb_grad = c->fb_grad; a.fb_grad_stride = c->cfg.paper_results ? (size_t)m->g.N : 0;
-    a.fb_e = c->fb_e; a.fb_f = c->fb_f; a.fb_ef_stride = c->cfg.paper_results ? 1 : 0;
-    a.flat = c->flat; a.logp_fwd = c->logp_fwd; a.Ucur = c->Ucur;
-    a.e_hist = c->e_hist; a.f_hist = c->f_hist; a.best_state = c->best_state; a.best_e = c->best_e;
-    a.best_f = c->best_f; a.best_t = c->best_t; a.rtraj = c->rtraj; a.acc_last = c->acc_last;
+    a.e_hist = c->e_hist; a.f_hist = c->f_hist; a.best_state = c->best_state; a.rtraj = c->rtraj;
     a.tr_flat = c->tr_flat; a.tr_acc = c->tr_acc; a.tr_logacc = c->tr_logacc; a.tr_U = c->tr_U;
     a.err_flag = c->err_flag;
     a.dbg = c->dbg;
@@ -629,16 +629,16 @@ int ppde_chains_create(ppde_chains** out, ppde_model* m, const ppde_chain_config
     };
     A(&c->cur, n * g.Ls, true); A(&c->prop, n * g.Ls, true);
     A(&c->fb_state, (cfg->paper_results ? n : 1) * g.Ls, true);
-    A(&c->grad_cur, cfg->reuse_grad ? n * g.N : 1, true); A(&c->best_state, n * g.L, true); A(&c->rtraj, T1 * g.L, true); A(&c->acc_last, n, true);
+    c->rec_stride = chain_rec_stride(c->mu_max);
+    A(&c->rec, n * c->rec_stride, true);
+    A(&c->grad_cur, cfg->reuse_grad ? n * g.N : 1, true); A(&c->best_state, n * g.L, true); A(&c->rtraj, T1 * g.L, true); A(&c->tmp_acc, n, true);
     A(&c->tmp_idx, n * g.L, true); A(&c->tmp_dist, n, true);
     A(&c->grad, 2 * n * g.N, true); A(&c->epart, 2 * n * std::max(g.Lp, 1), true);
     if (cfg->which & 2) { A(&c->gradC, 2 * nets * n * g.N, true); A(&c->fitC, 2 * nets * n, true); }
-    A(&c->cur_e, n, true); A(&c->cur_f, n, true);
     A(&c->fb_grad, (cfg->paper_results ? n : 1) * g.N, true);
     A(&c->fb_e, cfg->paper_results ? n : 1, true); A(&c->fb_f, cfg->paper_results ? n : 1, true);
-    A(&c->logp_fwd, n * c->mu_max, true); A(&c->flat, n * c->mu_max, true); A(&c->Ucur, n, true);
     A(&c->e_hist, T1 * n, true); A(&c->f_hist, T1 * n, true);
-    A(&c->best_e, n, true); A(&c->best_f, n, true); A(&c->best_t, n, true);
+    A(&c->tmp_be, n, true); A(&c->tmp_bf, n, true); A(&c->tmp_bt, n, true);
     A(&c->err_flag, 1, true); A(&c->d_it, 1, true); A(&c->dbg, 128, true);
     if (cfg->trace) {
         A(&c->tr_flat, (size_t)c->T * c->mu_max * n, true); A(&c->tr_acc, (size_t)c->T * n, true);
@@ -712,6 +712,12 @@ int ppde_chains_init(ppde_chains* c, const uint8_t* idx0_dev) {
         }
     } else {
         HIPCHK(hipMemcpyAsync(c->fb_state, m->d_wt, (size_t)g.Ls, hipMemcpyDeviceToDevice, s));
+    }
+    if (c->cfg.reuse_grad && !c->cfg.paper_results) {   // what a mutation-cap reset continues from
+        HIPCHK(hipMemcpyAsync(&c->wt_e, c->fb_e, sizeof(float), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipMemcpyAsync(&c->wt_f, c->fb_f, sizeof(float), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        a.wt_e = c->wt_e; a.wt_f = c->wt_f;
     }
     // energies (and, when gradients are reused, the gradient) of the initial population -> slot 0
     rc = eval_experts(m, c->cfg.which, c->cur, n, chain_targets(c, 0), 1, s);
@@ -810,7 +816,12 @@ int ppde_chains_peek(ppde_chains* c, uint8_t* idx, float* energy, float* fitness
     }
     if (energy) HIPCHK(hipMemcpyAsync(energy, c->e_hist + (size_t)c->steps_done * n, n * sizeof(float), hipMemcpyDeviceToHost, s));
     if (fitness) HIPCHK(hipMemcpyAsync(fitness, c->f_hist + (size_t)c->steps_done * n, n * sizeof(float), hipMemcpyDeviceToHost, s));
-    if (accepted) HIPCHK(hipMemcpyAsync(accepted, c->acc_last, n, hipMemcpyDeviceToHost, s));
+    if (accepted) {
+        hipLaunchKernelGGL(k_rec_gather, dim3((n + 255) / 256), dim3(256), 0, s, chain_args(c), (float*)nullptr, (float*)nullptr,
+                           (int*)nullptr, c->tmp_acc);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(accepted, c->tmp_acc, n, hipMemcpyDeviceToHost, s));
+    }
     HIPCHK(hipStreamSynchronize(s));
     return PPDE_OK;
 }
@@ -823,9 +834,13 @@ int ppde_chains_collect(ppde_chains* c, uint8_t* best_idx, float* best_energy, f
     const Geom& g = c->m->g;
     const size_t n = c->n, rows = (size_t)c->steps_done + 1;
     if (best_idx) HIPCHK(hipMemcpy(best_idx, c->best_state, n * g.L, hipMemcpyDeviceToHost));
-    if (best_energy) HIPCHK(hipMemcpy(best_energy, c->best_e, n * sizeof(float), hipMemcpyDeviceToHost));
-    if (best_fitness) HIPCHK(hipMemcpy(best_fitness, c->best_f, n * sizeof(float), hipMemcpyDeviceToHost));
-    if (best_step) HIPCHK(hipMemcpy(best_step, c->best_t, n * sizeof(int), hipMemcpyDeviceToHost));
+    hipLaunchKernelGGL(k_rec_gather, dim3(((int)n + 255) / 256), dim3(256), 0, c->stream, chain_args(c), c->tmp_be, c->tmp_bf,
+                       c->tmp_bt, (uint8_t*)nullptr);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (best_energy) HIPCHK(hipMemcpy(best_energy, c->tmp_be, n * sizeof(float), hipMemcpyDeviceToHost));
+    if (best_fitness) HIPCHK(hipMemcpy(best_fitness, c->tmp_bf, n * sizeof(float), hipMemcpyDeviceToHost));
+    if (best_step) HIPCHK(hipMemcpy(best_step, c->tmp_bt, n * sizeof(int), hipMemcpyDeviceToHost));
     if (energy_history) HIPCHK(hipMemcpy(energy_history, c->e_hist, rows * n * sizeof(float), hipMemcpyDeviceToHost));
     if (fitness_history) HIPCHK(hipMemcpy(fitness_history, c->f_hist, rows * n * sizeof(float), hipMemcpyDeviceToHost));
     if (random_traj) {

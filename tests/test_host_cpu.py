@@ -30,6 +30,30 @@ def test_library_exports_every_declared_symbol():
     assert _hip.load().ppde_abi_version() == 1
 
 
+def test_no_kernel_uses_scratch_memory(tmp_path):
+    """A struct the compiler could not keep in registers (run-time indexing, a select between members) shows up as
+    private-segment memory and costs microseconds per launch: every kernel of the library must use none."""
+    import shutil
+    from ppde_amd import _hip, build
+    build.build()
+    llvm = "/opt/rocm/lib/llvm/bin"
+    if not os.path.exists(os.path.join(llvm, "llvm-objdump")):
+        pytest.skip("ROCm llvm tools not installed")
+    so = shutil.copy(_hip.LIB_PATH, tmp_path / "lib.so")
+    subprocess.run([os.path.join(llvm, "llvm-objdump"), "--offloading", so], check=True, capture_output=True)
+    obj = [p for p in os.listdir(tmp_path) if "gfx950" in p]
+    assert len(obj) == 1, os.listdir(tmp_path)
+    notes = subprocess.run([os.path.join(llvm, "llvm-readelf"), "--notes", str(tmp_path / obj[0])], check=True,
+                           capture_output=True, text=True).stdout
+    names = re.findall(r"\.name:\s+(\S+)", notes)
+    scratch = [int(v) for v in re.findall(r"\.private_segment_fixed_size:\s+(\d+)", notes)]
+    spills = [int(v) for v in re.findall(r"\.vgpr_spill_count:\s+(\d+)", notes)]
+    kernels = [n for n in names if n.startswith("_Z")]
+    assert len(kernels) == len(scratch) == len(spills) and len(kernels) >= 40
+    bad = [(k, s, v) for k, s, v in zip(kernels, scratch, spills) if s or v]
+    assert not bad, bad
+
+
 def test_product_path_has_no_cpu_fallback():
     from ppde_amd.energy import HipModel
     with pytest.raises(RuntimeError):
