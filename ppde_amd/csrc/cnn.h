@@ -93,6 +93,7 @@ __device__ __forceinline__ void mfma_strip(f32x4 (&acc)[RT], const float* A, int
 // compile-time trip count keeps the table loads branch-free, so they issue back to back.
 template <int RT, int KT>
 __global__ __launch_bounds__(256, 2) void k_cnn(CnnArgs a) {
+    warm_kernargs<sizeof(CnnArgs)>();
     extern __shared__ unsigned char smem_raw[];
     const Geom g = a.g;
     const int b = a.b_off + blockIdx.x, ni = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
@@ -381,6 +382,7 @@ __device__ __forceinline__ void cnn_build_rows(const CnnNet& net, const uint8_t*
 
 template <int KT>
 __global__ __launch_bounds__(256) void k_cnn_fwd_chunk(CnnChunkArgs ca) {
+    warm_kernargs<sizeof(CnnChunkArgs)>();
     extern __shared__ unsigned char smem_raw[];
     const CnnArgs& a = ca.a;
     const Geom g = a.g;
@@ -435,6 +437,7 @@ __global__ __launch_bounds__(256) void k_cnn_fwd_chunk(CnnChunkArgs ca) {
 
 template <int KT>
 __global__ __launch_bounds__(256) void k_cnn_bwd_chunk(CnnChunkArgs ca) {
+    warm_kernargs<sizeof(CnnChunkArgs)>();
     extern __shared__ unsigned char smem_raw[];
     const CnnArgs& a = ca.a;
     const Geom g = a.g;

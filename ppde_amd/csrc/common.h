@@ -35,6 +35,26 @@ __device__ __forceinline__ int opaque_zero() {
     return z;
 }
 
+// Make a prefetched value opaque at its point of use: without it hipcc hoists speculatable arithmetic on a loaded
+// value (a conversion, a select) up into the block that issued the load and waits for the load there.
+__device__ __forceinline__ void use_here(float& v) { asm volatile("" : "+v"(v)); }
+__device__ __forceinline__ void use_here(int& v) { asm volatile("" : "+v"(v)); }
+
+// Touch every 64-byte line of the kernel-argument segment at kernel entry. hipcc loads a by-value argument struct
+// lazily, field group by field group, each behind its own s_waitcnt: with a 350-byte struct that is five or six
+// SERIAL scalar-cache misses before the first vector load is issued (0.6-0.9 us per launch). One dword per line,
+// pinned in an SGPR by an empty asm, makes all lines arrive in one round trip; the later field loads hit the cache.
+template <int BYTES>
+__device__ __forceinline__ void warm_kernargs() {
+    const __attribute__((address_space(4))) int* p =
+        (const __attribute__((address_space(4))) int*)__builtin_amdgcn_kernarg_segment_ptr();
+    int v[(BYTES + 63) / 64];
+#pragma unroll
+    for (int i = 0; i < (BYTES + 63) / 64; ++i) v[i] = p[16 * i];
+#pragma unroll
+    for (int i = 0; i < (BYTES + 63) / 64; ++i) asm volatile("" :: "s"(v[i]));
+}
+
 // Problem geometry shared by every kernel (passed by value).
 struct Geom {
     int L;        // sequence length

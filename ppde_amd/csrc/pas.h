@@ -79,9 +79,12 @@ __device__ __forceinline__ ChainRec* rec_of(const PasArgs& a, int b) { return (C
 __device__ __forceinline__ int* rec_flat(ChainRec* r) { return (int*)(r + 1); }
 __device__ __forceinline__ float* rec_logp(ChainRec* r, int mu_max) { return (float*)(rec_flat(r) + mu_max); }
 
+// sub-steps of the reverse path evaluated together (they do not depend on each other)
+#define PAS_SB 3
+
 struct RowLds {
     float4* G;      // gradient row [N/4]
-    float* xa;      // exchange A: NW x (max, sum)
+    float* xa;      // exchange A: NW x PAS_SB x (max, sum)
     float* xb;      // exchange B: NW x 8 floats (sum, race value, index, prob, replaced letter)
     int* mv;        // moves of the current path: (residue, new letter) pairs [2 * 128]
     uint8_t* St;    // letters of the start state [L]
@@ -92,14 +95,14 @@ __device__ __forceinline__ RowLds carve_lds(unsigned char* base, const Geom& g) 
     RowLds r;
     r.G = (float4*)base;
     r.xa = (float*)(r.G + g.N / 4);
-    r.xb = r.xa + 2 * PPDE_NW;
+    r.xb = r.xa + 8 * PPDE_NW;
     r.mv = (int*)(r.xb + 8 * PPDE_NW);
     r.St = (uint8_t*)(r.mv + 256);
     r.Wt = r.St + ((g.L + 15) & ~15);
     return r;
 }
 __host__ __device__ inline size_t pas_lds_bytes(const Geom& g) {
-    return (size_t)g.N * 4 + 10 * PPDE_NW * 4 + 1024 + 2 * (size_t)((g.L + 15) & ~15);
+    return (size_t)g.N * 4 + 16 * PPDE_NW * 4 + 1024 + 2 * (size_t)((g.L + 15) & ~15);
 }
 
 __device__ __forceinline__ float clampp(float p) { return fminf(fmaxf(p, PPDE_EPS), 1.0f - PPDE_EPS); }
@@ -120,6 +123,27 @@ __device__ __forceinline__ float4 row_value(const RowSrc& r, int g4) {
     if (r.nc > 2) v = add4(v, r.c[2][g4]);
     if (r.nc > 3) v = add4(v, r.c[3][g4]);
     return r.p ? add4(v, r.p[g4]) : v;
+}
+// The same in two halves for the kernels' prologues: row_parts_issue() only LOADS (a use of a loaded value in the
+// issuing basic block makes hipcc wait right there, before the loads that follow), row_parts_sum() adds later.
+struct RowParts { float4 v, e1, e2, e3, ep; };
+__device__ __forceinline__ RowParts row_parts_issue(const RowSrc& r, int g4) {
+    RowParts q;                                       // members stay unset where the component is absent
+    if (r.nc == 0) { q.v = r.p[g4]; return q; }
+    q.v = r.c[0][g4];
+    if (r.nc > 1) q.e1 = r.c[1][g4];
+    if (r.nc > 2) q.e2 = r.c[2][g4];
+    if (r.nc > 3) q.e3 = r.c[3][g4];
+    if (r.p) q.ep = r.p[g4];
+    return q;
+}
+__device__ __forceinline__ float4 row_parts_sum(const RowParts& q, int nc, bool has_p) {
+    if (nc == 0) return q.v;
+    float4 v = q.v;
+    if (nc > 1) v = add4(v, q.e1);
+    if (nc > 2) v = add4(v, q.e2);
+    if (nc > 3) v = add4(v, q.e3);
+    return has_p ? add4(v, q.ep) : v;
 }
 
 __device__ __forceinline__ RowSrc slot_row(const PasArgs& a, int slot, int b) {
@@ -148,8 +172,22 @@ __device__ __forceinline__ RowSrc current_grad_row(const PasArgs& a, int b) {
     return slot_row(a, 0, b);
 }
 
+// Everything the kernels' load-issuing prologues read from the argument struct, made live at kernel entry: hipcc
+// otherwise loads argument fields in the basic block of their first use, each group behind its own
+// s_waitcnt lgkmcnt(0) (eight to ten serial scalar round trips before the first vector load).
+__device__ __forceinline__ void args_up_front(const PasArgs& a) {
+    asm volatile("" :: "s"(a.g.L), "s"(a.g.N), "s"(a.g.Ls), "s"(a.g.sh), "s"(a.g.Lp), "s"(a.n), "s"(a.b_off), "s"(a.wt),
+                 "s"(a.which), "s"(a.rng_mode), "s"(a.reuse), "s"(a.mu_max), "s"(a.pas), "s"(a.it_base), "s"(a.it_local));
+    asm volatile("" :: "s"(a.cur), "s"(a.grad), "s"(a.epart), "s"(a.gradC), "s"(a.fitC), "s"(a.n_nets), "s"(a.grad_cur),
+                 "s"(a.rec), "s"(a.rec_stride), "s"(a.key.chain_lo), "s"(a.key.k0), "s"(a.key.k1));
+}
+
+// Iteration index = device counter (graph replay) + node-local offset. The counter only changes between launches,
+// so it is read through the constant address space: a scalar load, counted apart from the vector loads, whose
+// result every Philox call of the kernel takes straight from an SGPR.
 __device__ __forceinline__ int iteration_of(const PasArgs& a) {
-    return (a.it_base ? *a.it_base : 0) + a.it_local;
+    typedef const __attribute__((address_space(4))) int* cptr;
+    return (a.it_base ? *(cptr)(a.it_base) : 0) + a.it_local;
 }
 
 // Per-thread view of the row: thread t owns the 4-logit groups g4 = t + r*PPDE_BLOCK (r < GPT). A group lies
@@ -166,29 +204,38 @@ struct RowRegs {
 // Row staging in two halves so that a kernel can put ALL its global loads in flight before the first wait:
 // row_issue() only loads (gradient groups, one state and one wild-type letter per thread) into registers,
 // row_commit() writes them to LDS, synchronises and fills the per-thread letters.
-struct RowLetters { uint8_t st, wt; };
 template <int GPT>
-__device__ __forceinline__ RowLetters row_issue(const Geom& g, const RowSrc& src, const uint8_t* state_row,
-                                                const uint8_t* wt_row, RowRegs<GPT>& R) {
+struct RowLetters {
+    uint8_t st, wt;
+    int nc; bool has_p;
+    RowParts parts[GPT];
+};
+template <int GPT>
+__device__ __forceinline__ RowLetters<GPT> row_issue(const Geom& g, const RowSrc& src, const uint8_t* state_row,
+                                                     const uint8_t* wt_row, RowRegs<GPT>& R) {
     const int tid = threadIdx.x, n4 = g.N / 4;
+    RowLetters<GPT> q;
+    q.nc = src.nc; q.has_p = src.p != nullptr;
 #pragma unroll
     for (int r = 0; r < GPT; ++r) {
         const int g4 = tid + r * PPDE_BLOCK;
         R.valid[r] = g4 < n4;
         R.l[r] = R.valid[r] ? g4 / 5 : 0;
         R.kb[r] = (g4 - 5 * R.l[r]) * 4;
-        R.gv[r] = R.valid[r] ? row_value(src, g4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        q.parts[r] = row_parts_issue(src, min(g4, n4 - 1));
     }
-    RowLetters q{0, 0};
-    if (tid < g.L) { q.st = state_row[g.sh + tid]; q.wt = wt_row[g.sh + tid]; }   // L <= 307 < PPDE_BLOCK
+    const int t = min(tid, g.L - 1);                  // L <= 307 < PPDE_BLOCK; threads past L re-read the last letter
+    q.st = state_row[g.sh + t]; q.wt = wt_row[g.sh + t];
     return q;
 }
 template <int GPT>
-__device__ __forceinline__ void row_commit(const RowLds& lds, const Geom& g, const RowLetters& q, RowRegs<GPT>& R) {
+__device__ __forceinline__ void row_commit(const RowLds& lds, const Geom& g, const RowLetters<GPT>& q, RowRegs<GPT>& R) {
     const int tid = threadIdx.x;
 #pragma unroll
-    for (int r = 0; r < GPT; ++r)
+    for (int r = 0; r < GPT; ++r) {
+        R.gv[r] = R.valid[r] ? row_parts_sum(q.parts[r], q.nc, q.has_p) : make_float4(0.f, 0.f, 0.f, 0.f);
         if (R.valid[r]) lds.G[tid + r * PPDE_BLOCK] = R.gv[r];
+    }
     if (tid < g.L) { lds.St[tid] = q.st; lds.Wt[tid] = q.wt; }
     __syncthreads();
 #pragma unroll
@@ -200,7 +247,7 @@ __device__ __forceinline__ void row_commit(const RowLds& lds, const Geom& g, con
 template <int GPT>
 __device__ __forceinline__ void load_row(const RowLds& lds, const Geom& g, const RowSrc& src, const uint8_t* state_row,
                                          const uint8_t* wt_row, RowRegs<GPT>& R) {
-    const RowLetters q = row_issue<GPT>(g, src, state_row, wt_row, R);
+    const RowLetters<GPT> q = row_issue<GPT>(g, src, state_row, wt_row, R);
     row_commit<GPT>(lds, g, q, R);
 }
 
@@ -231,6 +278,98 @@ __device__ __forceinline__ void row_max_sumexp(const RowLds& lds, const float4 (
     m = row8_max(mj);
     const float term = (mj == -INFINITY) ? 0.f : sj * expf(mj - m);
     S1 = row8_sum(term);
+}
+
+// The same for NR independent rows at once (the reverse path): per row the operations and their order are those
+// of row_max_sumexp, so the results are bit-identical; the rows share the barrier and overlap their chains.
+template <int GPT, int NR>
+__device__ __forceinline__ void row_max_sumexp_batch(const RowLds& lds, const float4 (&z)[NR][GPT], const bool (&valid)[GPT],
+                                                     float (&m)[NR], float (&S1)[NR]) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    float mw[NR], sw[NR];
+#pragma unroll
+    for (int j = 0; j < NR; ++j) {
+        float lm = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < GPT; ++r)
+            if (valid[r]) lm = fmaxf(fmaxf(lm, fmaxf(z[j][r].x, z[j][r].y)), fmaxf(z[j][r].z, z[j][r].w));
+        mw[j] = wave_max(lm);
+    }
+#pragma unroll
+    for (int j = 0; j < NR; ++j) {
+        float sm = 0.f;
+        const float mref = mw[j] != -INFINITY ? mw[j] : 0.f;    // (an all-masked wave contributes exp(-inf) = 0 terms)
+#pragma unroll
+        for (int r = 0; r < GPT; ++r)
+            if (valid[r]) { sm += expf(z[j][r].x - mref); sm += expf(z[j][r].y - mref); sm += expf(z[j][r].z - mref); sm += expf(z[j][r].w - mref); }
+        sw[j] = wave_sum(sm);
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (int j = 0; j < NR; ++j) { lds.xa[2 * (w * PAS_SB + j)] = mw[j]; lds.xa[2 * (w * PAS_SB + j) + 1] = sw[j]; }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < NR; ++j) {
+        const int wj = lane & (PPDE_NW - 1);
+        const float mj = lane < PPDE_NW ? lds.xa[2 * (wj * PAS_SB + j)] : -INFINITY;
+        const float sj = lane < PPDE_NW ? lds.xa[2 * (wj * PAS_SB + j) + 1] : 0.f;
+        m[j] = row8_max(mj);
+        const float term = (mj == -INFINITY) ? 0.f : sj * expf(mj - m[j]);
+        S1[j] = row8_sum(term);
+    }
+}
+
+// NR consecutive sub-steps s0.. of the reverse path (ppde.py:122-132): returns their summed log-ratio terms in
+// path order. lds.G = gradient at the proposal, R.cur = letters before sub-step s0 (advanced on return).
+template <int GPT, int NR>
+__device__ __forceinline__ void reverse_rows(const RowLds& lds, RowRegs<GPT>& R, int s0, float& log_ratio) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    const float* G = (const float*)lds.G;
+    const float* lpf = (const float*)(lds.mv + 128);
+    float4 z[NR][GPT];
+#pragma unroll
+    for (int j = 0; j < NR; ++j) {
+        const int win = lds.mv[s0 + j];
+        const int ls = win / 20, ks = win - 20 * ls;
+#pragma unroll
+        for (int r = 0; r < GPT; ++r) {
+            if (R.l[r] == ls) R.cur[r] = ks;            // state after sub-step s0 + j
+            const float gc = G[R.l[r] * 20 + R.cur[r]];
+            const float4 gv = R.gv[r];
+            z[j][r] = make_float4((gv.x - gc) * 0.5f, (gv.y - gc) * 0.5f, (gv.z - gc) * 0.5f, (gv.w - gc) * 0.5f);
+        }
+    }
+    float m[NR], S1[NR], lse[NR], mp[NR], inv[NR], s3w[NR];
+    row_max_sumexp_batch<GPT, NR>(lds, z, R.valid, m, S1);
+#pragma unroll
+    for (int j = 0; j < NR; ++j) {
+        lse[j] = logf(S1[j]) + m[j];
+        mp[j] = m[j] - lse[j];
+        inv[j] = 1.0f / S1[j];
+        float s3 = 0.f;
+#pragma unroll
+        for (int r = 0; r < GPT; ++r) {
+            if (!R.valid[r]) continue;
+            s3 += clampp(expf((z[j][r].x - lse[j]) - mp[j]) * inv[j]); s3 += clampp(expf((z[j][r].y - lse[j]) - mp[j]) * inv[j]);
+            s3 += clampp(expf((z[j][r].z - lse[j]) - mp[j]) * inv[j]); s3 += clampp(expf((z[j][r].w - lse[j]) - mp[j]) * inv[j]);
+        }
+        s3w[j] = wave_sum(s3);
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (int j = 0; j < NR; ++j) lds.xb[8 * (tid >> 6) + j] = s3w[j];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < NR; ++j) {
+        // probability of the recorded move under the reverse proposal: its residue now holds letter ks, so the
+        // logit is (g[win] - g[win]) / 2 = 0 exactly
+        const float pwin = clampp(expf((0.f - lse[j]) - mp[j]) * inv[j]);
+        const float S3 = row8_sum(lane < PPDE_NW ? lds.xb[8 * (lane & (PPDE_NW - 1)) + j] : 0.f);
+        const float logp_rev = logf(clampp(pwin / S3));
+        log_ratio += logp_rev - lpf[s0 + j];
+    }
 }
 
 // logits of one 4-letter group of residue l: (g - g[current letter]) / 2 with the forward masks
@@ -407,6 +546,7 @@ __device__ __forceinline__ void propose_body(const PasArgs& a, const RowLds& lds
 
 template <int GPT>
 __global__ __launch_bounds__(PPDE_BLOCK) void k_propose(PasArgs a) {
+    args_up_front(a);
     extern __shared__ unsigned char smem_raw[];
     const RowLds lds = carve_lds(smem_raw, a.g);
     const int b = a.b_off + blockIdx.x;
@@ -414,7 +554,7 @@ __global__ __launch_bounds__(PPDE_BLOCK) void k_propose(PasArgs a) {
     PPDE_STAMP(a.dbg, 8, stamp);
     RowRegs<GPT> R;
     const int it = iteration_of(a);
-    const RowLetters rl = row_issue<GPT>(a.g, current_grad_row(a, b), a.cur + (size_t)b * a.g.Ls, a.wt, R);
+    const RowLetters<GPT> rl = row_issue<GPT>(a.g, current_grad_row(a, b), a.cur + (size_t)b * a.g.Ls, a.wt, R);
     const ProposePrefetch<GPT> pp = propose_prefetch<GPT>(a, b, it);
     row_commit<GPT>(lds, a.g, rl, R);
     PPDE_STAMP(a.dbg, 9, stamp);
@@ -443,10 +583,10 @@ __device__ __forceinline__ EnergyPrefetch prefetch_energy(const PasArgs& a, int 
     p.e0 = p.e1 = 0.f;
     p.f0 = p.f1 = p.f2 = p.f3 = 0.f;
     const int lane = threadIdx.x & 63;
-    if (a.which & 1) {
+    if (a.which & 1) {                               // clamped addresses + selects: no branch, so no wait between the loads
         const float* ep = a.epart + ((size_t)slot * a.n + b) * a.g.Lp;
-        if (lane < a.g.Lp) p.e0 = ep[lane];
-        if (lane + 64 < a.g.Lp) p.e1 = ep[lane + 64];
+        p.e0 = ep[min(lane, a.g.Lp - 1)];            // raw; finish_energy() drops the lanes past L'
+        p.e1 = ep[min(lane + 64, a.g.Lp - 1)];
     }
     if (a.which & 2) {
         const float* fc = a.fitC + (size_t)slot * a.n_nets * a.n + b;
@@ -457,10 +597,13 @@ __device__ __forceinline__ EnergyPrefetch prefetch_energy(const PasArgs& a, int 
     }
     return p;
 }
-__device__ __forceinline__ void finish_energy(const PasArgs& a, int slot, int b, const EnergyPrefetch& p, float& e, float& f) {
+__device__ __forceinline__ void finish_energy(const PasArgs& a, int slot, int b, EnergyPrefetch p, float& e, float& f) {
     float dH = 0.f;
+    use_here(p.e0); use_here(p.e1); use_here(p.f0); use_here(p.f1); use_here(p.f2); use_here(p.f3);
     if (a.which & 1) {
-        double sacc = (double)p.e0 + (double)p.e1;     // lane partial in index order, as potts_hamiltonian_from_parts
+        const int lane = threadIdx.x & 63;
+        // lane partial in index order, as potts_hamiltonian_from_parts
+        double sacc = (double)(lane < a.g.Lp ? p.e0 : 0.f) + (double)(lane + 64 < a.g.Lp ? p.e1 : 0.f);
         if (a.g.Lp > 128) {
             const float* ep = a.epart + ((size_t)slot * a.n + b) * a.g.Lp;
             for (int i = (threadIdx.x & 63) + 128; i < a.g.Lp; i += 64) sacc += (double)ep[i];
@@ -492,7 +635,7 @@ struct AcceptPrefetch {
     int flat_v;      // thread t < mu_max: move t of the path
     float lpf_v;     //                    and its forward log-probability
 };
-__device__ __forceinline__ AcceptPrefetch accept_prefetch(const PasArgs& a, const RowLds& lds, int b0) {
+__device__ __forceinline__ AcceptPrefetch accept_prefetch(const PasArgs& a, const RowLds& lds, int b0, int it) {
     AcceptPrefetch q;
     q.px.e0 = q.px.e1 = q.px.f0 = q.px.f1 = q.px.f2 = q.px.f3 = 0.f;
     q.cur_e = q.cur_f = q.u = q.lpf_v = 0.f;
@@ -507,11 +650,14 @@ __device__ __forceinline__ AcceptPrefetch accept_prefetch(const PasArgs& a, cons
     if (!a.reuse) q.px = prefetch_energy(a, 0, b);
     q.best_e = rc->best_e;
     if (a.rng_mode == 0) q.u = a.u_in[b];
-    else q.u = unif_from_bits(philox4x32_10(U4{a.key.chain_lo + (uint32_t)b0, (uint32_t)iteration_of(a), 1u, 0u}, a.key.k0, a.key.k1).x);
-    if ((int)threadIdx.x < a.mu_max) {
-        q.flat_v = rec_flat(rc)[threadIdx.x];
-        q.lpf_v = rec_logp(rc, a.mu_max)[threadIdx.x];
+    {                                                // clamped + selected, as in prefetch_energy
+        const int t = min((int)threadIdx.x, a.mu_max - 1);   // raw; only threads < mu_max park theirs in LDS
+        q.flat_v = rec_flat(rc)[t];
+        q.lpf_v = rec_logp(rc, a.mu_max)[t];
     }
+    // last: the accept uniform needs the iteration index (the first load the kernel issued)
+    if (a.rng_mode != 0)
+        q.u = unif_from_bits(philox4x32_10(U4{a.key.chain_lo + (uint32_t)b0, (uint32_t)it, 1u, 0u}, a.key.k0, a.key.k1).x);
     return q;
 }
 // second half: park the path in LDS (forward log-probabilities sit next to the moves); call before row_commit()
@@ -528,9 +674,7 @@ template <int GPT>
 __device__ __forceinline__ AcceptOut accept_body(const PasArgs& a, const RowLds& lds, RowRegs<GPT>& R, int b, int it,
                                                  const AcceptPrefetch& pf, bool stamp) {
     const Geom g = a.g;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const float* G = (const float*)lds.G;
-    const float* lpf = (const float*)(lds.mv + 128);
+    const int tid = threadIdx.x;
     const int Ub = __builtin_amdgcn_readfirstlane(pf.Ub);
     constexpr int sloty = 1;
     const EnergyPrefetch& py = pf.py;
@@ -541,38 +685,13 @@ __device__ __forceinline__ AcceptOut accept_body(const PasArgs& a, const RowLds&
     const int d_cur = pf.dist_cur, d_prop = pf.dist_prop, d_fb = pf.dist_fb;
     PPDE_STAMP(a.dbg, 25, stamp);
     float log_ratio = 0.f;
-    for (int s = 0; s < Ub; ++s) {
-        const int win = lds.mv[s];
-        const int ls = win / 20, ks = win - 20 * ls;
-        float4 z[GPT];
-#pragma unroll
-        for (int r = 0; r < GPT; ++r) {
-            if (R.l[r] == ls) R.cur[r] = ks;        // state after sub-step s
-            const float gc = G[R.l[r] * 20 + R.cur[r]];
-            const float4 gv = R.gv[r];
-            z[r] = make_float4((gv.x - gc) * 0.5f, (gv.y - gc) * 0.5f, (gv.z - gc) * 0.5f, (gv.w - gc) * 0.5f);
-        }
-        float m, S1;
-        row_max_sumexp<GPT>(lds, z, R.valid, m, S1);
-        const float lse = logf(S1) + m;
-        const float mp = m - lse;
-        const float inv = 1.0f / S1;
-        float s3 = 0.f;
-#pragma unroll
-        for (int r = 0; r < GPT; ++r) {
-            if (!R.valid[r]) continue;
-            s3 += clampp(expf((z[r].x - lse) - mp) * inv); s3 += clampp(expf((z[r].y - lse) - mp) * inv);
-            s3 += clampp(expf((z[r].z - lse) - mp) * inv); s3 += clampp(expf((z[r].w - lse) - mp) * inv);
-        }
-        const float s3w = wave_sum(s3);
-        if (lane == 0) lds.xb[8 * (tid >> 6)] = s3w;
-        // probability of the recorded move under the reverse proposal: its residue now holds letter ks, so the
-        // logit is (g[win] - g[win]) / 2 = 0 exactly
-        const float pwin = clampp(expf((0.f - lse) - mp) * inv);
-        __syncthreads();
-        const float S3 = row8_sum(lane < PPDE_NW ? lds.xb[8 * (lane & (PPDE_NW - 1))] : 0.f);
-        const float logp_rev = logf(clampp(pwin / S3));
-        log_ratio += logp_rev - lpf[s];
+    // The reverse rows of a path are independent of each other (gradient at y, states along the recorded path), so
+    // up to PAS_SB of them are evaluated per pass: two barriers per pass instead of two per sub-step.
+    for (int s0 = 0; s0 < Ub; s0 += PAS_SB) {
+        const int nrows = Ub - s0;
+        if (nrows >= 3) reverse_rows<GPT, 3>(lds, R, s0, log_ratio);
+        else if (nrows == 2) reverse_rows<GPT, 2>(lds, R, s0, log_ratio);
+        else reverse_rows<GPT, 1>(lds, R, s0, log_ratio);
     }
 
     PPDE_STAMP(a.dbg, 26, stamp);
@@ -659,21 +778,23 @@ __device__ __forceinline__ void commit_current_row(const PasArgs& a, const RowLd
 
 template <int GPT>
 __global__ __launch_bounds__(PPDE_BLOCK) void k_accept(PasArgs a) {
+    args_up_front(a);
     extern __shared__ unsigned char smem_raw[];
     const RowLds lds = carve_lds(smem_raw, a.g);
     const int b = a.b_off + blockIdx.x;
     const bool stamp = blockIdx.x == 0;
     PPDE_STAMP(a.dbg, 24, stamp);
+    const int it = iteration_of(a);
     RowRegs<GPT> R;
-    const RowLetters rl = row_issue<GPT>(a.g, slot_row(a, 1, b), a.cur + (size_t)b * a.g.Ls, a.wt, R);
+    const RowLetters<GPT> rl = row_issue<GPT>(a.g, slot_row(a, 1, b), a.cur + (size_t)b * a.g.Ls, a.wt, R);
     PPDE_STAMP(a.dbg, 30, stamp);
-    const AcceptPrefetch pf = accept_prefetch(a, lds, b);
+    const AcceptPrefetch pf = accept_prefetch(a, lds, b, it);
     PPDE_STAMP(a.dbg, 31, stamp);
     accept_stage_path(a, lds, pf);
     PPDE_STAMP(a.dbg, 32, stamp);
     row_commit<GPT>(lds, a.g, rl, R);
     PPDE_STAMP(a.dbg, 33, stamp);
-    const AcceptOut o = accept_body<GPT>(a, lds, R, b, iteration_of(a), pf, stamp);
+    const AcceptOut o = accept_body<GPT>(a, lds, R, b, it, pf, stamp);
     if (a.reuse) commit_current_row<GPT>(a, lds, R, b, o, false);
 }
 
@@ -682,6 +803,7 @@ __global__ __launch_bounds__(PPDE_BLOCK) void k_accept(PasArgs a) {
 // back to. Saves a launch boundary and a row staging per iteration.
 template <int GPT>
 __global__ __launch_bounds__(PPDE_BLOCK) void k_accept_propose(PasArgs a) {
+    args_up_front(a);
     extern __shared__ unsigned char smem_raw[];
     const Geom g = a.g;
     const RowLds lds = carve_lds(smem_raw, g);
@@ -690,8 +812,8 @@ __global__ __launch_bounds__(PPDE_BLOCK) void k_accept_propose(PasArgs a) {
     const int it = iteration_of(a);
     PPDE_STAMP(a.dbg, 24, stamp);
     RowRegs<GPT> R;
-    const RowLetters rl = row_issue<GPT>(g, slot_row(a, 1, b), a.cur + (size_t)b * g.Ls, a.wt, R);
-    const AcceptPrefetch pf = accept_prefetch(a, lds, b);
+    const RowLetters<GPT> rl = row_issue<GPT>(g, slot_row(a, 1, b), a.cur + (size_t)b * g.Ls, a.wt, R);
+    const AcceptPrefetch pf = accept_prefetch(a, lds, b, it);
     const ProposePrefetch<GPT> pp = propose_prefetch<GPT>(a, b, it + 1);
     accept_stage_path(a, lds, pf);
     row_commit<GPT>(lds, g, rl, R);

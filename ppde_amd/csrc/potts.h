@@ -91,6 +91,7 @@ __host__ __device__ inline size_t potts_lds_bytes(int NC, int NG, int Ls) {
 
 template <int NG>   // NG groups of 64 chains per workgroup
 __global__ __launch_bounds__(256) void potts_energy_grad_kernel(PottsArgs a) {
+    warm_kernargs<sizeof(PottsArgs)>();
     extern __shared__ float4 smem[];
     const Geom g = a.g;
     const int NC = g.NC;
