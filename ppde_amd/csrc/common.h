@@ -67,9 +67,10 @@ struct Geom {
 };
 
 // ---- wavefront reductions on DPP (no LDS round trips): two quad permutes, row_half_mirror, row_mirror
-// leave every 16-lane row holding its row total; the four row totals are then read with v_readlane and
-// combined as (r0 + r1) + (r2 + r3). Each step combines a lane with its mirror image, so both partners
-// compute the same (commutative) result and every lane ends with the same bits.
+// leave every 16-lane row holding its row total T_r (each step combines a lane with its mirror image, so both
+// partners compute the same commutative result); row_bcast:15 on rows 1 and 3 and row_bcast:31 on rows 2 and 3
+// then leave (T3 + T2) + (T1 + T0) in lane 63, which one v_readlane hands to every lane. The tree is fixed, so
+// the bits do not depend on the launch.
 template <int CTRL>
 __device__ __forceinline__ float dpp_f(float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
@@ -78,10 +79,21 @@ template <int CTRL>
 __device__ __forceinline__ int dpp_i(int v) {
     return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true);
 }
+// lanes of the rows in ROWS get lane CTRL's broadcast, the others `idle`
+template <int CTRL, int ROWS>
+__device__ __forceinline__ int dpp_rows_i(int idle, int v) {
+    return __builtin_amdgcn_update_dpp(idle, v, CTRL, ROWS, 0xF, false);
+}
+template <int CTRL, int ROWS>
+__device__ __forceinline__ float dpp_rows_f(float idle, float v) {
+    return __builtin_bit_cast(float, dpp_rows_i<CTRL, ROWS>(__builtin_bit_cast(int, idle), __builtin_bit_cast(int, v)));
+}
 #define DPP_XOR1 0xB1        // quad_perm [1,0,3,2]
 #define DPP_XOR2 0x4E        // quad_perm [2,3,0,1]
 #define DPP_HALF_MIRROR 0x141
 #define DPP_MIRROR 0x140
+#define DPP_BCAST15 0x142    // lane 15 of each row -> the next row
+#define DPP_BCAST31 0x143    // lane 31 -> rows 2 and 3
 __device__ __forceinline__ float lane_f(float v, int lane) {
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
 }
@@ -91,12 +103,20 @@ __device__ __forceinline__ float wave_sum(float v) {
     v += dpp_f<DPP_XOR2>(v);
     v += dpp_f<DPP_HALF_MIRROR>(v);
     v += dpp_f<DPP_MIRROR>(v);
-    return (lane_f(v, 0) + lane_f(v, 16)) + (lane_f(v, 32) + lane_f(v, 48));
+    v += dpp_rows_f<DPP_BCAST15, 0xA>(0.f, v);
+    v += dpp_rows_f<DPP_BCAST31, 0xC>(0.f, v);
+    return lane_f(v, 63);
 }
 template <int CTRL>
 __device__ __forceinline__ double dpp_d(double v) {
     const long long b = __builtin_bit_cast(long long, v);
     const int lo = dpp_i<CTRL>((int)(b & 0xffffffffll)), hi = dpp_i<CTRL>((int)(b >> 32));
+    return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
+}
+template <int CTRL, int ROWS>
+__device__ __forceinline__ double dpp_rows_d(double v) {     // idle lanes get 0.0
+    const long long b = __builtin_bit_cast(long long, v);
+    const int lo = dpp_rows_i<CTRL, ROWS>(0, (int)(b & 0xffffffffll)), hi = dpp_rows_i<CTRL, ROWS>(0, (int)(b >> 32));
     return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
 }
 __device__ __forceinline__ double lane_d(double v, int lane) {
@@ -109,7 +129,9 @@ __device__ __forceinline__ double wave_sum_d(double v) {
     v += dpp_d<DPP_XOR2>(v);
     v += dpp_d<DPP_HALF_MIRROR>(v);
     v += dpp_d<DPP_MIRROR>(v);
-    return (lane_d(v, 0) + lane_d(v, 16)) + (lane_d(v, 32) + lane_d(v, 48));
+    v += dpp_rows_d<DPP_BCAST15, 0xA>(v);
+    v += dpp_rows_d<DPP_BCAST31, 0xC>(v);
+    return lane_d(v, 63);
 }
 // wave-wide maximum of a 64-bit key (used as (race value bits << 32) | ~index: larger value wins, then the
 // smaller index)
@@ -118,27 +140,31 @@ __device__ __forceinline__ unsigned long long dpp_u64(unsigned long long v) {
     const int lo = dpp_i<CTRL>((int)(v & 0xffffffffull)), hi = dpp_i<CTRL>((int)(v >> 32));
     return ((unsigned long long)(unsigned int)hi << 32) | (unsigned int)lo;
 }
+template <int CTRL, int ROWS>
+__device__ __forceinline__ unsigned long long dpp_rows_u64(unsigned long long v) {   // idle lanes get 0
+    const int lo = dpp_rows_i<CTRL, ROWS>(0, (int)(v & 0xffffffffull)), hi = dpp_rows_i<CTRL, ROWS>(0, (int)(v >> 32));
+    return ((unsigned long long)(unsigned int)hi << 32) | (unsigned int)lo;
+}
 __device__ __forceinline__ unsigned long long umax64(unsigned long long a, unsigned long long b) { return a > b ? a : b; }
 __device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v) {
     v = umax64(v, dpp_u64<DPP_XOR1>(v));
     v = umax64(v, dpp_u64<DPP_XOR2>(v));
     v = umax64(v, dpp_u64<DPP_HALF_MIRROR>(v));
     v = umax64(v, dpp_u64<DPP_MIRROR>(v));
-    unsigned long long r = 0;
-#pragma unroll
-    for (int l = 0; l < 64; l += 16) {
-        const unsigned int lo = (unsigned int)__builtin_amdgcn_readlane((int)(v & 0xffffffffull), l);
-        const unsigned int hi = (unsigned int)__builtin_amdgcn_readlane((int)(v >> 32), l);
-        r = umax64(r, ((unsigned long long)hi << 32) | lo);
-    }
-    return r;
+    v = umax64(v, dpp_rows_u64<DPP_BCAST15, 0xA>(v));
+    v = umax64(v, dpp_rows_u64<DPP_BCAST31, 0xC>(v));
+    const unsigned int lo = (unsigned int)__builtin_amdgcn_readlane((int)(v & 0xffffffffull), 63);
+    const unsigned int hi = (unsigned int)__builtin_amdgcn_readlane((int)(v >> 32), 63);
+    return ((unsigned long long)hi << 32) | lo;
 }
 __device__ __forceinline__ float wave_max(float v) {
     v = fmaxf(v, dpp_f<DPP_XOR1>(v));
     v = fmaxf(v, dpp_f<DPP_XOR2>(v));
     v = fmaxf(v, dpp_f<DPP_HALF_MIRROR>(v));
     v = fmaxf(v, dpp_f<DPP_MIRROR>(v));
-    return fmaxf(fmaxf(lane_f(v, 0), lane_f(v, 16)), fmaxf(lane_f(v, 32), lane_f(v, 48)));
+    v = fmaxf(v, dpp_rows_f<DPP_BCAST15, 0xA>(-INFINITY, v));
+    v = fmaxf(v, dpp_rows_f<DPP_BCAST31, 0xC>(-INFINITY, v));
+    return lane_f(v, 63);
 }
 
 // reductions over lanes 0..PPDE_NW-1 only (the cross-wave merges: one entry per wave, PPDE_NW in {4, 8, 16});

@@ -438,6 +438,7 @@ __device__ __forceinline__ void propose_body(const PasArgs& a, const RowLds& lds
 #pragma unroll
     for (int r = 0; r < GPT; ++r) q[r] = pp.q0[r];
 
+    int pend_l = 0, pend_k = 0;                      // the last move, not yet applied to lds.St
     for (int s = 0; s < Ub; ++s) {
         const bool capped = dist >= a.thr;
         // ---- logits z = (g - g[current letter]) / 2 with the forward masks (ppde.py:98-104)
@@ -447,6 +448,7 @@ __device__ __forceinline__ void propose_body(const PasArgs& a, const RowLds& lds
         PPDE_STAMP(a.dbg, 10 + 4 * min(s, 1), stamp);
         float m, S1;
         row_max_sumexp<GPT>(lds, z, R.valid, m, S1);
+        if (tid == 0 && s > 0) lds.St[pend_l] = (uint8_t)pend_k;   // every wave has left the previous sub-step
         PPDE_STAMP(a.dbg, 11 + 4 * min(s, 1), stamp);
         if (m == -INFINITY) {                       // no admissible move: the reference raises ValueError here
             if (tid == 0) atomicOr(a.err_flag, 1);
@@ -492,21 +494,14 @@ __device__ __forceinline__ void propose_body(const PasArgs& a, const RowLds& lds
         PPDE_STAMP(a.dbg, 12 + 4 * min(s, 1), stamp);
         const int win = min((int)(0xffffffffu - (unsigned int)key), g.N - 1);
         const int ls = win / 20, ks = win - 20 * ls;
-        // letter being replaced: the start state's, unless an earlier move of this path touched the residue
-        int old = lds.St[ls];
-        for (int t = 0; t < s; ++t)
-            if (lds.mv[2 * t] == ls) old = lds.mv[2 * t + 1];
+        // letter being replaced (lds.St follows the path: the previous move was applied behind this sub-step's
+        // first barrier)
+        const int old = lds.St[ls];
         const int wl = lds.Wt[ls];
-        // probability of the winner, recomputed by everyone exactly as its owner computed it
-        float pwin;
-        {
-            const int kbw = ks & ~3;
-            const float4 gw = lds.G[win >> 2];
-            const float4 zw = forward_logits(a, G, gw, ls, kbw, old, wl, capped);
-            const int d = ks & 3;
-            const float zz = d == 0 ? zw.x : d == 1 ? zw.y : d == 2 ? zw.z : zw.w;
-            pwin = clampp(expf((zz - lse) - mp) * inv);
-        }
+        // probability of the winner, recomputed by everyone exactly as its owner computed it (a drawn move is
+        // admissible, so its logit carries no mask)
+        const float zz = (G[win] - G[ls * 20 + old]) * 0.5f;
+        const float pwin = clampp(expf((zz - lse) - mp) * inv);
         const float logp = logf(clampp(pwin / s3));   // Categorical.log_prob = log(clamp(p_hat))
 
         // ---- apply the substitution (l*, k*) to the register copies and log it for later sub-steps
@@ -514,8 +509,8 @@ __device__ __forceinline__ void propose_body(const PasArgs& a, const RowLds& lds
         for (int r = 0; r < GPT; ++r)
             if (R.l[r] == ls) R.cur[r] = ks;
         dist += (int)(ks != wl) - (int)(old != wl);
+        pend_l = ls; pend_k = ks;
         if (tid == 0) {
-            lds.mv[2 * s] = ls; lds.mv[2 * s + 1] = ks;      // read one barrier later at the earliest
             ChainRec* rc = rec_of(a, b);
             rec_flat(rc)[s] = win;
             rec_logp(rc, a.mu_max)[s] = logp;
