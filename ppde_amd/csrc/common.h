@@ -251,9 +251,17 @@ __host__ __device__ __forceinline__ U4 philox4x32_10(U4 c, uint32_t k0, uint32_t
 }
 
 // uniform in (0,1) on a 2^-23 lattice offset by 2^-24 (exactly representable), then Exp(1) = -log(u)
+// Exp(1) variate -log(u), u on the 2^-23 lattice in (0, 1). u is never denormal or special, so this is logf()
+// without its range handling: v_log_f32 (base 2) times ln 2 in two pieces, the same operations and constants as
+// the library's fast path (bit-identical results, 5 instead of 14 instructions).
 __device__ __forceinline__ float exp1_from_bits(uint32_t r) {
-    float u = ((float)(r >> 9) + 0.5f) * 1.1920928955078125e-07f;
-    return -logf(u);
+    const float u = ((float)(r >> 9) + 0.5f) * 1.1920928955078125e-07f;
+    const float t = __builtin_amdgcn_logf(u);
+    const float ln2_hi = 0x1.62e42ep-1f, ln2_lo = 0x1.efa39ep-25f;
+    const float hi = t * ln2_hi;
+    float lo = __builtin_fmaf(t, ln2_hi, -hi);
+    lo = __builtin_fmaf(t, ln2_lo, lo);
+    return -(hi + lo);
 }
 // uniform in [0,1) with 24 bits, like torch.rand for fp32
 __host__ __device__ __forceinline__ float unif_from_bits(uint32_t r) {
