@@ -53,7 +53,8 @@ __host__ __device__ inline size_t cnn_lds_bytes(int T, int CP, int FP, int J, in
     const size_t r0 = rows * (AS > OS ? AS : OS) * 4;      // h1, later second route accumulator, later O
     const size_t r1 = rows * AS * 4;                        // routed gradient
     const size_t bits = rows * ((CP + 31) / 32) * 4;        // ReLU gate of h1
-    return r0 + r1 + bits + (size_t)FP * 8 + 64 + ((L + CNN_MAX_K + 15) & ~15);
+    const size_t route = (rows + 4 + (size_t)FP) * 4;       // row offsets and the row-sorted list of routed features
+    return r0 + r1 + bits + route + (size_t)FP * 8 + 64 + ((L + CNN_MAX_K + 15) & ~15);
 }
 
 // One wave: C[rows x 16] (+)= A[rows x CP] (LDS, stride AS) * B[CP x 16] (global, leading dimension ldb, first
@@ -108,7 +109,12 @@ __global__ __launch_bounds__(256, 2) void k_cnn(CnnArgs a) {
     float* sH = (float*)smem_raw;                                   // [rows][AS] h1 | route accumulator 2 | O [rows][J]
     float* sD = sH + (size_t)rows * (AS > OS ? AS : OS);            // [rows][AS] routed gradient
     uint32_t* sG = (uint32_t*)(sD + (size_t)rows * AS);             // [rows][BW] bit o of word: h1[t][o] > 0
-    float* sM = (float*)(sG + (size_t)rows * BW);                   // [FP] max values
+    const int BWF = (FP + 31) / 32;                                 // route words per row
+    uint32_t* sB = (uint32_t*)sD;                                   // [rows][BWF] bit f of row t: feature f routes into row t
+                                                                    // (in sD's storage: dead before sD is written)
+    int* sStart = (int*)(sG + (size_t)rows * BW);                   // [rows + 1] first list entry of each row (+ 3 pad)
+    int* sList = sStart + rows + 4;                                 // [FP] routed features sorted by (row, feature)
+    float* sM = (float*)(sList + FP);                               // [FP] max values
     int* sTs = (int*)(sM + FP);                                     // [FP] arg-max rows
     float* red = (float*)(sTs + FP);                                // 16 floats
     uint8_t* sSt = (uint8_t*)(red + 16);                            // [L] letters
@@ -125,9 +131,8 @@ __global__ __launch_bounds__(256, 2) void k_cnn(CnnArgs a) {
     //      channels, row): 16-byte table loads (a quarter of the load instructions of a dword gather), two rows per
     //      round = 2*KT independent L2 loads in flight, addresses clamped and values masked (no branches). The ReLU
     //      gate bits are OR-ed into sG with LDS atomics.
-    const int oc = tid & 127, th = tid >> 7;                        // (channel mod 128, row phase) of the elementwise passes
     for (int w = tid; w < rows * BW; w += 256) sG[w] = 0u;
-    for (int e = tid; e < rows * 2; e += 256) { sH[(e >> 1) * AS + CP + (e & 1)] = 0.f; sD[(e >> 1) * AS + CP + (e & 1)] = 0.f; }
+    for (int e = tid; e < rows * 2; e += 256) sH[(e >> 1) * AS + CP + (e & 1)] = 0.f;   // (the contractions stop at CP: never read)
     __syncthreads();
     {
         const int G4 = CP / 4;                                       // float4 groups per row
@@ -157,9 +162,6 @@ __global__ __launch_bounds__(256, 2) void k_cnn(CnnArgs a) {
                     float* hp = sH + t * AS + 4 * g4;                 // AS = 2 mod 4: rows are only 8-byte aligned
                     *(float2*)hp = make_float2(x.x, x.y);
                     *(float2*)(hp + 2) = make_float2(x.z, x.w);
-                    float* dp = sD + t * AS + 4 * g4;
-                    *(float2*)dp = make_float2(0.f, 0.f);
-                    *(float2*)(dp + 2) = make_float2(0.f, 0.f);
                     const uint32_t nib = (x.x > 0.f ? 1u : 0u) | (x.y > 0.f ? 2u : 0u) | (x.z > 0.f ? 4u : 0u) | (x.w > 0.f ? 8u : 0u);
                     if (nib) atomicOr(&sG[t * BW + (g4 >> 3)], nib << (4 * (g4 & 7)));
                 }
@@ -211,6 +213,8 @@ __global__ __launch_bounds__(256, 2) void k_cnn(CnnArgs a) {
             s += wdf * mf;
             if (k < 2) cf[k] = (f < F && mf > 0.f) ? a.scale * wdf : 0.f;
         }
+        if (a.want_grad)
+            for (int w = tid; w < rows * BWF; w += 256) sB[w] = 0u;  // route bitmap (filled behind the barrier below)
         const float tot = block_sum<4>(s, red, phase);             // (its barrier also orders the sM rewrite below)
         if (tid == 0) a.fitC[((size_t)slot * a.n_nets + ni) * a.n + b] = tot + net.bd;
         k = 0;
@@ -220,58 +224,97 @@ __global__ __launch_bounds__(256, 2) void k_cnn(CnnArgs a) {
     PPDE_STAMP(a.dbg, 44, stamp);
     if (!a.want_grad) return;
 
-    // ---- clear the second route accumulator (h1's storage: its ReLU gate is already in sG)
-    float* sD2 = sH;
-    for (int o = oc; o < AS; o += 128) {
-#pragma unroll 8
-        for (int t = th; t < rows; t += 2) sD2[t * AS + o] = 0.f;
+    // ---- route + gate: d pre1[t][o] = [h1[t][o] > 0] * sum_{f: t*_f = t} coef_f * We[f][o], features in increasing
+    //      order (deterministic), written to sD by ONE writer per element (no read-modify-write chains in LDS):
+    //      (1) a bitmap per row of the features that land in it (LDS atomicOr: independent of arrival order) gives
+    //          row counts, row offsets and each feature's rank in its row: a list of routed features sorted by
+    //          (row, feature);
+    //      (2) work item = (row, 4 channels) sums coef * We[f][4c..] over its row's consecutive list entries, the
+    //          pieces coming straight from L2 with a dozen loads in flight per thread, and applies the gate.
+    {
+        int k = 0;
+        for (int f = tid; f < FP; f += 256, ++k)
+            if (k < 2 && sM[f] != 0.f) atomicOr(&sB[sTs[f] * BWF + (f >> 5)], 1u << (f & 31));   // (own sM writes)
+    }
+    __syncthreads();
+    int my_cnt = 0;
+    if (tid < rows) {
+        for (int w = 0; w < BWF; ++w) my_cnt += __builtin_popcount(sB[tid * BWF + w]);
+        sStart[tid + 1] = my_cnt;                                    // counts first; offsets after the barrier
+    }
+    __syncthreads();
+    int my_start = 0;
+    if (tid < rows)
+        for (int t = 0; t < tid; ++t) my_start += sStart[t + 1];
+    __syncthreads();
+    if (tid < rows) {
+        sStart[tid] = my_start;
+        if (tid == rows - 1) sStart[rows] = my_start + my_cnt;
+    }
+    __syncthreads();
+    {
+        int k = 0;
+        for (int f = tid; f < FP; f += 256, ++k) {
+            if (k >= 2 || sM[f] == 0.f) continue;
+            const int t = sTs[f], w = f >> 5;
+            int r = __builtin_popcount(sB[t * BWF + w] & ((1u << (f & 31)) - 1u));
+            for (int w2 = 0; w2 < w; ++w2) r += __builtin_popcount(sB[t * BWF + w2]);
+            sList[sStart[t] + r] = f;
+        }
     }
     __syncthreads();
     PPDE_STAMP(a.dbg, 45, stamp);
-    // ---- route: dH1[t*_f][o] += coef_f * We[f][o]. Thread = (channel, half of the features); each half accumulates
-    //      in feature order into its own array (deterministic); the next batch of We rows is in flight while the
-    //      current one is added. (LDS float atomics instead of the read-modify-write were measured 4.5x SLOWER.)
-    for (int wi = tid; wi < 2 * CP; wi += 256) {
-        const int half = wi >= CP ? 1 : 0, o = wi - half * CP;
-        float* dst = half ? sD2 : sD;
-        const int f_lo = half ? FP / 2 : 0, f_hi = half ? FP : FP / 2;    // FP is a multiple of 16: whole batches of 8
-        float wn[8];
+    {
+        // work item = (row, 4 channels); three items per round, the first four list entries of each fetched
+        // unconditionally (clamped index, zero coefficient past the row's end): 12 independent L2 loads in flight
+        const int G4 = CP / 4, items = rows * G4;
+        const int last = max(sStart[rows] - 1, 0);
+        const float4* We4 = (const float4*)net.We;                   // [FP][G4]
+        for (int item0 = tid; item0 < items; item0 += 256 * 3) {
+            int t[3], c4[3], rs[3], kk[3];
+            float4 v[3][4];
+            float c[3][4];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) wn[j] = net.We[(size_t)(f_lo + j) * CP + o];   // We has FP rows (zero padded)
-        for (int f0 = f_lo; f0 < f_hi; f0 += 8) {
-            float w[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) w[j] = wn[j];
-            if (f0 + 8 < f_hi) {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) wn[j] = net.We[(size_t)(f0 + 8 + j) * CP + o];
+            for (int j = 0; j < 3; ++j) {
+                const int ic = min(item0 + 256 * j, items - 1);
+                t[j] = ic / G4; c4[j] = ic - t[j] * G4;
+                rs[j] = sStart[t[j]];
+                kk[j] = sStart[t[j] + 1] - rs[j];
             }
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const float c = sM[f0 + j];
-                if (c != 0.f) dst[sTs[f0 + j] * AS + o] += c * w[j];
+            for (int j = 0; j < 3; ++j) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int f = min((unsigned)sList[min(rs[j] + q, last)], (unsigned)(FP - 1));
+                    v[j][q] = We4[(size_t)f * G4 + c4[j]];
+                    c[j][q] = q < kk[j] ? sM[f] : 0.f;
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    acc.x += c[j][q] * v[j][q].x; acc.y += c[j][q] * v[j][q].y;
+                    acc.z += c[j][q] * v[j][q].z; acc.w += c[j][q] * v[j][q].w;
+                }
+                for (int q = 4; q < kk[j]; ++q) {                    // rows with more than four routed features
+                    const int f = sList[rs[j] + q];
+                    const float cq = sM[f];
+                    const float4 w = We4[(size_t)f * G4 + c4[j]];
+                    acc.x += cq * w.x; acc.y += cq * w.y; acc.z += cq * w.z; acc.w += cq * w.w;
+                }
+                const uint32_t nib = (sG[t[j] * BW + (c4[j] >> 3)] >> (4 * (c4[j] & 7))) & 0xFu;   // gate by relu'(pre1)
+                acc.x = (nib & 1u) ? acc.x : 0.f; acc.y = (nib & 2u) ? acc.y : 0.f;
+                acc.z = (nib & 4u) ? acc.z : 0.f; acc.w = (nib & 8u) ? acc.w : 0.f;
+                if (item0 + 256 * j < items) {
+                    float* dp = sD + t[j] * AS + 4 * c4[j];          // AS = 2 mod 4: rows are only 8-byte aligned
+                    *(float2*)dp = make_float2(acc.x, acc.y);
+                    *(float2*)(dp + 2) = make_float2(acc.z, acc.w);
+                }
             }
         }
     }
-    __syncthreads();
-    PPDE_STAMP(a.dbg, 46, stamp);
-    // ---- d pre1 = gate * (half 0 + half 1)
-    for (int o = oc; o < AS; o += 128)
-        for (int t0 = th; t0 < rows; t0 += 8) {                // four rows per round: all LDS reads, then all writes
-            float x[4], y[4];
-            uint32_t gb[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int e = (t0 + 2 * u) * AS + o;
-                x[u] = sD[e]; y[u] = sD2[e];
-                gb[u] = sG[(t0 + 2 * u) * BW + (min(o, CP - 1) >> 5)];
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const bool on = o < CP && ((gb[u] >> (o & 31)) & 1u);
-                sD[(t0 + 2 * u) * AS + o] = on ? x[u] + y[u] : 0.f;
-            }
-        }
     __syncthreads();
     PPDE_STAMP(a.dbg, 47, stamp);
     // ---- O[t][kappa*20 + c] = sum_o dpre1[t][o] Wc[o][c][kappa] on the matrix cores (O takes h1's storage)

@@ -35,7 +35,7 @@ NAMES = {0: "potts entry", 1: "potts DMAs issued", 2: "potts states landed+barri
          24: "accept entry", 25: "accept row staged", 26: "accept loop done", 27: "accept decision", 28: "accept count done",
          29: "accept end", 30: "accept row loads issued", 31: "accept prefetch issued", 32: "accept path staged",
          33: "accept row committed", 40: "cnn entry", 41: "cnn letters staged", 42: "cnn h1 built", 43: "cnn forward contraction + max",
-         44: "cnn output written", 45: "cnn gate bits + clear", 46: "cnn routed", 47: "cnn gated", 48: "cnn backward contraction",
+         44: "cnn output written", 45: "cnn route bitmap built", 47: "cnn routed + gated", 48: "cnn backward contraction",
          49: "cnn end"}
 acc = {}
 for rep in range(20):
