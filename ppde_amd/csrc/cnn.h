@@ -237,20 +237,25 @@ __global__ __launch_bounds__(256, 2) void k_cnn(CnnArgs a) {
             if (k < 2 && sM[f] != 0.f) atomicOr(&sB[sTs[f] * BWF + (f >> 5)], 1u << (f & 31));   // (own sM writes)
     }
     __syncthreads();
-    int my_cnt = 0;
-    if (tid < rows) {
-        for (int w = 0; w < BWF; ++w) my_cnt += __builtin_popcount(sB[tid * BWF + w]);
-        sStart[tid + 1] = my_cnt;                                    // counts first; offsets after the barrier
+    // row counts and offsets: an exclusive scan inside each group of 64 rows (waves 0 and 1), then the second
+    // group is shifted by the first group's total
+    int* sTot = (int*)(red + 12);
+    if (tid < 128) {
+        int my_cnt = 0;
+        if (tid < rows)
+            for (int w = 0; w < BWF; ++w) my_cnt += __builtin_popcount(sB[tid * BWF + w]);
+        int incl = my_cnt;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int up = __shfl_up(incl, o);
+            if (lane >= o) incl += up;
+        }
+        if (tid < rows) sStart[tid] = incl - my_cnt;
+        if (tid == rows - 1) sStart[rows] = (rows == 64) ? 0 : incl;   // (row index `rows` belongs to the next group iff rows == 64)
+        if (lane == 63) sTot[wave] = incl;
     }
     __syncthreads();
-    int my_start = 0;
-    if (tid < rows)
-        for (int t = 0; t < tid; ++t) my_start += sStart[t + 1];
-    __syncthreads();
-    if (tid < rows) {
-        sStart[tid] = my_start;
-        if (tid == rows - 1) sStart[rows] = my_start + my_cnt;
-    }
+    if (tid >= 64 && tid <= rows) sStart[tid] += sTot[0];
     __syncthreads();
     {
         int k = 0;
