@@ -342,19 +342,29 @@ __global__ __launch_bounds__(256, 2) void k_cnn(CnnArgs a) {
     PPDE_STAMP(a.dbg, 48, stamp);
     // ---- transposed convolution: dx[p][c] = sum_kappa O[p - kappa][kappa*20 + c]
     float* out = a.gradC + (((size_t)slot * a.n_nets + ni) * a.n + b) * g.N;
-    for (int e = tid; e < g.N; e += 256) {
-        const int p = e / 20, c = e - 20 * p;
-        float ov[KT];
+    for (int e0 = tid; e0 < g.N; e0 += 512) {                       // two elements per round: 2*KT LDS reads in flight
+        float x[2][KT];
+        int pp[2];
 #pragma unroll
-        for (int kp = 0; kp < KT; ++kp) {
-            const int t = min(max(p - kp, 0), T - 1);               // clamped address, masked value: no branch
-            const float x = sO[t * OS + kp * 20 + c];
-            ov[kp] = (p - kp >= 0 && p - kp < T) ? x : 0.f;
+        for (int u = 0; u < 2; ++u) {
+            const int e = min(e0 + 256 * u, g.N - 1);
+            const int p = e / 20, c = e - 20 * p;
+            pp[u] = p;
+#pragma unroll
+            for (int kp = 0; kp < KT; ++kp) x[u][kp] = sO[min(max(p - kp, 0), T - 1) * OS + kp * 20 + c];   // clamped address
         }
-        float v = 0.f;
 #pragma unroll
-        for (int kp = 0; kp < KT; ++kp) v += ov[kp];
-        out[e] = v;
+        for (int u = 0; u < 2; ++u) {
+#pragma unroll
+            for (int kp = 0; kp < KT; ++kp) use_here(x[u][kp]);      // (keeps the reads unconditional: hipcc would branch around them)
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            float v = 0.f;
+#pragma unroll
+            for (int kp = 0; kp < KT; ++kp) v += (pp[u] - kp >= 0 && pp[u] - kp < T) ? x[u][kp] : 0.f;   // masked value
+            if (e0 + 256 * u < g.N) out[e0 + 256 * u] = v;
+        }
     }
     PPDE_STAMP(a.dbg, 49, stamp);
 }
