@@ -123,6 +123,9 @@ __global__ __launch_bounds__(256, 2) void k_cnn(CnnArgs a) {
 
     [[maybe_unused]] const bool stamp = blockIdx.x == 0 && blockIdx.y == 0;
     PPDE_STAMP(a.dbg, 40, stamp);
+    float wdf[2];                                                   // decoder weights of this thread's features (used after the
+#pragma unroll                                                      // forward contraction: no L2 round trip there)
+    for (int k = 0; k < 2; ++k) wdf[k] = net.wd[min(tid + 256 * k, FP - 1)];
     for (int l = tid; l < g.L + CNN_MAX_K; l += 256) sSt[l] = l < g.L ? min((int)a.idx[(size_t)b * g.Ls + g.sh + l], 19) : 0;
     __syncthreads();
     PPDE_STAMP(a.dbg, 41, stamp);
@@ -176,9 +179,9 @@ __global__ __launch_bounds__(256, 2) void k_cnn(CnnArgs a) {
         f32x4 acc[RT];
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) acc[rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        mfma_strip<RT>(acc, sH, AS, net.WeT, FP, ct * 16, KSP);
         const int f = ct * 16 + (lane & 15);
-        const float bias = net.be[f];
+        const float bias = net.be[f];                               // (in flight under the strip)
+        mfma_strip<RT>(acc, sH, AS, net.WeT, FP, ct * 16, KSP);
         float m = -INFINITY;
         int ts = 0;
 #pragma unroll
@@ -208,10 +211,13 @@ __global__ __launch_bounds__(256, 2) void k_cnn(CnnArgs a) {
         float s = 0.f;
         float cf[2] = {0.f, 0.f};
         int k = 0;
-        for (int f = tid; f < FP; f += 256, ++k) {
-            const float wdf = f < F ? net.wd[f] : 0.f, mf = sM[f];
-            s += wdf * mf;
-            if (k < 2) cf[k] = (f < F && mf > 0.f) ? a.scale * wdf : 0.f;
+#pragma unroll
+        for (k = 0; k < 2; ++k) {                                    // FP <= 512
+            const int f = tid + 256 * k;
+            if (f >= FP) break;
+            const float wv = f < F ? wdf[k] : 0.f, mf = sM[f];
+            s += wv * mf;
+            cf[k] = (f < F && mf > 0.f) ? a.scale * wv : 0.f;
         }
         if (a.want_grad)
             for (int w = tid; w < rows * BWF; w += 256) sB[w] = 0u;  // route bitmap (filled behind the barrier below)
