@@ -121,14 +121,19 @@ __global__ __launch_bounds__(256, 2) void k_cnn(CnnArgs a) {
     int phase = 0;
     const int slot = a.slot;
 
-    [[maybe_unused]] const bool stamp = blockIdx.x == 0 && blockIdx.y == 0;
-    PPDE_STAMP(a.dbg, 40, stamp);
+    // diagnostic build: the first workgroup stamps slots 40.., the last one slots 50..
+    [[maybe_unused]] const bool first_wg = blockIdx.x == 0 && blockIdx.y == 0;
+    [[maybe_unused]] const bool stamp = first_wg || (blockIdx.x == gridDim.x - 1 && blockIdx.y == gridDim.y - 1);
+    [[maybe_unused]] const int sb = first_wg ? 40 : 50;
+    [[maybe_unused]] const int wg_lin = blockIdx.x + gridDim.x * blockIdx.y;
+    PPDE_STAMP(a.dbg, sb, stamp);
+    PPDE_WG_STAMP(a.dbg, wg_lin, 0);
     float wdf[2];                                                   // decoder weights of this thread's features (used after the
 #pragma unroll                                                      // forward contraction: no L2 round trip there)
     for (int k = 0; k < 2; ++k) wdf[k] = net.wd[min(tid + 256 * k, FP - 1)];
     for (int l = tid; l < g.L + CNN_MAX_K; l += 256) sSt[l] = l < g.L ? min((int)a.idx[(size_t)b * g.Ls + g.sh + l], 19) : 0;
     __syncthreads();
-    PPDE_STAMP(a.dbg, 41, stamp);
+    PPDE_STAMP(a.dbg, sb + 1, stamp);
 
     // ---- h1 = relu(conv): KT table rows per (t, channel); padded rows/channels are zero. Thread = (4 consecutive
     //      channels, row): 16-byte table loads (a quarter of the load instructions of a dword gather), two rows per
@@ -172,7 +177,7 @@ __global__ __launch_bounds__(256, 2) void k_cnn(CnnArgs a) {
         }
     }
     __syncthreads();
-    PPDE_STAMP(a.dbg, 42, stamp);
+    PPDE_STAMP(a.dbg, sb + 2, stamp);
     // ---- pre2 = h1 We^T + be on the matrix cores; relu and the running max over t straight from the accumulators
     //      (strict >, rows ascending: the first index wins, like torch.max)
     for (int ct = wave; ct < FP / 16; ct += 4) {
@@ -204,7 +209,7 @@ __global__ __launch_bounds__(256, 2) void k_cnn(CnnArgs a) {
     }
     __syncthreads();
 
-    PPDE_STAMP(a.dbg, 43, stamp);
+    PPDE_STAMP(a.dbg, sb + 3, stamp);
     // ---- out = bd + wd . m  (fixed tree); the routing coefficients scale * wd_f (0 for features whose max is not
     //      positive) replace m in LDS so that the route loop touches LDS only
     {
@@ -227,7 +232,7 @@ __global__ __launch_bounds__(256, 2) void k_cnn(CnnArgs a) {
         for (int f = tid; f < FP; f += 256, ++k)
             if (k < 2) sM[f] = cf[k];
     }
-    PPDE_STAMP(a.dbg, 44, stamp);
+    PPDE_STAMP(a.dbg, sb + 4, stamp);
     if (!a.want_grad) return;
 
     // ---- route + gate: d pre1[t][o] = [h1[t][o] > 0] * sum_{f: t*_f = t} coef_f * We[f][o], features in increasing
@@ -274,7 +279,8 @@ __global__ __launch_bounds__(256, 2) void k_cnn(CnnArgs a) {
         }
     }
     __syncthreads();
-    PPDE_STAMP(a.dbg, 45, stamp);
+    PPDE_STAMP(a.dbg, sb + 5, stamp);
+    PPDE_WG_STAMP(a.dbg, wg_lin, 1);
     {
         // work item = (row, 4 channels); three items per round, the first four list entries of each fetched
         // unconditionally (clamped index, zero coefficient past the row's end): 12 independent L2 loads in flight
@@ -327,7 +333,8 @@ __global__ __launch_bounds__(256, 2) void k_cnn(CnnArgs a) {
         }
     }
     __syncthreads();
-    PPDE_STAMP(a.dbg, 47, stamp);
+    PPDE_STAMP(a.dbg, sb + 7, stamp);
+    PPDE_WG_STAMP(a.dbg, wg_lin, 2);
     // ---- O[t][kappa*20 + c] = sum_o dpre1[t][o] Wc[o][c][kappa] on the matrix cores (O takes h1's storage)
     float* sO = sH;
     for (int ct = wave; ct < JP / 16; ct += 4) {
@@ -345,7 +352,7 @@ __global__ __launch_bounds__(256, 2) void k_cnn(CnnArgs a) {
         }
     }
     __syncthreads();
-    PPDE_STAMP(a.dbg, 48, stamp);
+    PPDE_STAMP(a.dbg, sb + 8, stamp);
     // ---- transposed convolution: dx[p][c] = sum_kappa O[p - kappa][kappa*20 + c]
     float* out = a.gradC + (((size_t)slot * a.n_nets + ni) * a.n + b) * g.N;
     for (int e0 = tid; e0 < g.N; e0 += 512) {                       // two elements per round: 2*KT LDS reads in flight
@@ -372,7 +379,8 @@ __global__ __launch_bounds__(256, 2) void k_cnn(CnnArgs a) {
             if (e0 + 256 * u < g.N) out[e0 + 256 * u] = v;
         }
     }
-    PPDE_STAMP(a.dbg, 49, stamp);
+    PPDE_STAMP(a.dbg, sb + 9, stamp);
+    PPDE_WG_STAMP(a.dbg, wg_lin, 3);
 }
 
 // =====================================================================================================

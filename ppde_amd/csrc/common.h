@@ -13,6 +13,7 @@
 
 // Diagnostic build only (-DPPDE_STAMPS, scripts/stamp_kernels.py): wave 0 of the first workgroup of a launch
 // stores s_memtime at named points into a buffer nothing else reads. The shipped library executes no stamp.
+#define PPDE_DBG_WORDS (128 + 4 * 2048)   // stamp slots + per-workgroup records of the diagnostic build
 #ifdef PPDE_STAMPS
 #define PPDE_STAMP(buf, slot, cond)                                                          \
     do {                                                                                     \
@@ -21,8 +22,13 @@
             (buf)[2 * (slot) + 1] = __builtin_amdgcn_s_memrealtime();                        \
         }                                                                                    \
     } while (0)
+#define PPDE_WG_STAMP(buf, wg, k)                                                             \
+    do {                                                                                     \
+        if ((buf) && threadIdx.x == 0 && (wg) < 2048) (buf)[128 + 4 * (wg) + (k)] = __builtin_amdgcn_s_memrealtime(); \
+    } while (0)
 #else
 #define PPDE_STAMP(buf, slot, cond) do { } while (0)
+#define PPDE_WG_STAMP(buf, wg, k) do { } while (0)
 #endif
 
 // A zero the compiler cannot see through. Indexing per-chain scalars with (b + opaque_zero()) makes their loads

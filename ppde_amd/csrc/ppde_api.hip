@@ -639,7 +639,7 @@ int ppde_chains_create(ppde_chains** out, ppde_model* m, const ppde_chain_config
     A(&c->fb_e, cfg->paper_results ? n : 1, true); A(&c->fb_f, cfg->paper_results ? n : 1, true);
     A(&c->e_hist, T1 * n, true); A(&c->f_hist, T1 * n, true);
     A(&c->tmp_be, n, true); A(&c->tmp_bf, n, true); A(&c->tmp_bt, n, true);
-    A(&c->err_flag, 1, true); A(&c->d_it, 1, true); A(&c->dbg, 128, true);
+    A(&c->err_flag, 1, true); A(&c->d_it, 1, true); A(&c->dbg, PPDE_DBG_WORDS, true);
     if (cfg->trace) {
         A(&c->tr_flat, (size_t)c->T * c->mu_max * n, true); A(&c->tr_acc, (size_t)c->T * n, true);
         A(&c->tr_logacc, (size_t)c->T * n, true); A(&c->tr_U, (size_t)c->T * n, true);
@@ -878,6 +878,12 @@ int ppde_chains_philox_dump(ppde_chains* c, int it, int s, float* q_dev, float* 
 int ppde_debug_read_stamps(ppde_chains* c, unsigned long long* out128) {
     HIPCHK(hipStreamSynchronize(c->stream));
     HIPCHK(hipMemcpy(out128, c->dbg, 128 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    return PPDE_OK;
+}
+// per-workgroup records of the last k_cnn launch: [wg][4] = 100 MHz ticks at entry, route start, route end, exit
+int ppde_debug_read_wg_stamps(ppde_chains* c, unsigned long long* out, int words) {
+    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipMemcpy(out, c->dbg + 128, (size_t)std::min(words, PPDE_DBG_WORDS - 128) * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     return PPDE_OK;
 }
 #endif

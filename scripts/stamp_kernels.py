@@ -43,7 +43,7 @@ for rep in range(20):
     out = np.zeros(128, dtype=np.uint64)
     _hip.check(lib.ppde_debug_read_stamps(ch.handle, out.ctypes.data))
     st = out.reshape(64, 2)
-    for grp in ((0, 1, 2, 3, 4, 5), (8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19), (24, 30, 31, 32, 33, 25, 26, 27, 28, 29), (40, 41, 42, 43, 44, 45, 46, 47, 48, 49)):
+    for grp in ((0, 1, 2, 3, 4, 5), (8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19), (24, 30, 31, 32, 33, 25, 26, 27, 28, 29), (40, 41, 42, 43, 44, 45, 46, 47, 48, 49), (50, 51, 52, 53, 54, 55, 56, 57, 58, 59)):
         prev = None
         for k in grp:
             if st[k, 0] == 0:
@@ -54,9 +54,24 @@ for rep in range(20):
         ks = [k for k in grp if st[k, 0]]
         if len(ks) >= 2:
             acc.setdefault(("total", grp[0]), []).append((int(st[ks[-1], 0] - st[ks[0], 0]), int(st[ks[-1], 1] - st[ks[0], 1])))
+if cnn and hasattr(lib, "ppde_debug_read_wg_stamps"):
+    nwg = 3 * n
+    wg = np.zeros(4 * nwg, dtype=np.uint64)
+    lib.ppde_debug_read_wg_stamps.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+    _hip.check(lib.ppde_debug_read_wg_stamps(ch.handle, wg.ctypes.data, 4 * nwg))
+    w = wg.reshape(nwg, 4).astype(np.int64)
+    t0 = w[:, 0].min()
+    tot = (w[:, 3] - w[:, 0]) / 100.0; route = (w[:, 2] - w[:, 1]) / 100.0; start = (w[:, 0] - t0) / 100.0; end = (w[:, 3] - t0) / 100.0
+    print(f"cnn per-workgroup (us): start max {start.max():.2f}; duration min/median/max {tot.min():.1f}/{np.median(tot):.1f}/{tot.max():.1f}; "
+          f"route min/median/max {route.min():.1f}/{np.median(route):.1f}/{route.max():.1f}; last end {end.max():.1f}")
+    for lo in range(0, nwg, 64):
+        print(f"   wg {lo:3d}..{lo + 63:3d}: duration {np.median(tot[lo:lo + 64]):.1f}  route {np.median(route[lo:lo + 64]):.1f}  end {np.median(end[lo:lo + 64]):.1f}")
+if st[40, 1] and st[59, 1]:
+    print(f"cnn: last workgroup starts {(int(st[50, 1]) - int(st[40, 1])) / 100:.2f} us after the first, runs "
+          f"{(int(st[59, 1]) - int(st[50, 1])) / 100:.2f} us; first start -> last end {(int(st[59, 1]) - int(st[40, 1])) / 100:.2f} us")
 for (a, b), v in acc.items():
     cyc = np.median([x[0] for x in v]); rt = np.median([x[1] for x in v])
     if a == "total":
         print(f"TOTAL group {b}: {cyc:.0f} cycles = {rt / 100:.2f} us  (clock {cyc / max(rt, 1) * 100:.0f} MHz)")
     else:
-        print(f"  {NAMES[a]:34s} -> {NAMES[b]:34s}: {cyc:7.0f} cycles  {rt / 100:6.2f} us")
+        print(f"  {NAMES.get(a, NAMES.get(a - 10, '?') + ' (last wg)'):34s} -> {NAMES.get(b, NAMES.get(b - 10, '?') + ' (last wg)'):34s}: {cyc:7.0f} cycles  {rt / 100:6.2f} us")
