@@ -92,12 +92,12 @@ __device__ __forceinline__ void mfma_strip(f32x4 (&acc)[RT], const float* A, int
 
 // KT = convolution taps the tables are laid out for (the real kernel size, or zero-padded to CNN_MAX_K): a
 // compile-time trip count keeps the table loads branch-free, so they issue back to back.
+// Body of one workgroup = (chain bx of the launch, network ni); shared by k_cnn and the fused experts launch.
 template <int RT, int KT>
-__global__ __launch_bounds__(256, 2) void k_cnn(CnnArgs a) {
-    warm_kernargs<sizeof(CnnArgs)>();
-    extern __shared__ unsigned char smem_raw[];
+__device__ __forceinline__ void cnn_body(const CnnArgs& a, const int bx, const int ni, const int n_bx, const int n_ni,
+                                         unsigned char* smem_raw) {
     const Geom g = a.g;
-    const int b = a.b_off + blockIdx.x, ni = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
+    const int b = a.b_off + bx, tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const CnnNet net = a.net[ni];
     const int T = a.T, CP = a.CP, F = a.F, FP = a.FP, J = a.J, JP = a.JP;
@@ -122,10 +122,10 @@ __global__ __launch_bounds__(256, 2) void k_cnn(CnnArgs a) {
     const int slot = a.slot;
 
     // diagnostic build: the first workgroup stamps slots 40.., the last one slots 50..
-    [[maybe_unused]] const bool first_wg = blockIdx.x == 0 && blockIdx.y == 0;
-    [[maybe_unused]] const bool stamp = first_wg || (blockIdx.x == gridDim.x - 1 && blockIdx.y == gridDim.y - 1);
+    [[maybe_unused]] const bool first_wg = bx == 0 && ni == 0;
+    [[maybe_unused]] const bool stamp = first_wg || (bx == n_bx - 1 && ni == n_ni - 1);
     [[maybe_unused]] const int sb = first_wg ? 40 : 50;
-    [[maybe_unused]] const int wg_lin = blockIdx.x + gridDim.x * blockIdx.y;
+    [[maybe_unused]] const int wg_lin = bx + n_bx * ni;
     PPDE_STAMP(a.dbg, sb, stamp);
     PPDE_WG_STAMP(a.dbg, wg_lin, 0);
     float wdf[2];                                                   // decoder weights of this thread's features (used after the
@@ -381,6 +381,13 @@ __global__ __launch_bounds__(256, 2) void k_cnn(CnnArgs a) {
     }
     PPDE_STAMP(a.dbg, sb + 9, stamp);
     PPDE_WG_STAMP(a.dbg, wg_lin, 3);
+}
+
+template <int RT, int KT>
+__global__ __launch_bounds__(256, 2) void k_cnn(CnnArgs a) {
+    warm_kernargs<sizeof(CnnArgs)>();
+    extern __shared__ unsigned char smem_raw[];
+    cnn_body<RT, KT>(a, blockIdx.x, blockIdx.y, gridDim.x, gridDim.y, smem_raw);
 }
 
 // =====================================================================================================

@@ -89,19 +89,18 @@ __host__ __device__ inline size_t potts_lds_bytes(int NC, int NG, int Ls) {
     return ((size_t)4 * NC * 80 + (size_t)4 * NG * 64) * 16 + (((size_t)NG * 64 * Ls + 1023) & ~(size_t)1023) + 1024;
 }
 
+// Body of one workgroup: `tile` = 4 output columns, `by` = block of NG*64 chains. A __device__ function so that
+// the kernel below and the fused experts launch (ppde_api.hip: k_experts) share it.
 template <int NG>   // NG groups of 64 chains per workgroup
-__global__ __launch_bounds__(256) void potts_energy_grad_kernel(PottsArgs a) {
-    warm_kernargs<sizeof(PottsArgs)>();
-    extern __shared__ float4 smem[];
+__device__ __forceinline__ void potts_body(const PottsArgs& a, const int tile, const int by, float4* smem) {
     const Geom g = a.g;
     const int NC = g.NC;
     constexpr int CPB = NG * 64;
     const int tid = threadIdx.x, lane = tid & 63;
     const int part = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: every address derived from it stays in SGPRs
-    const int tile = blockIdx.x;
-    const int b0 = a.b_off + blockIdx.y * CPB;
+    const int b0 = a.b_off + by * CPB;
     const int b_end = a.b_off + a.n_sub;
-    [[maybe_unused]] const bool stamp = blockIdx.x == 0 && blockIdx.y == 0;
+    [[maybe_unused]] const bool stamp = tile == 0 && by == 0;
     PPDE_STAMP(a.dbg, 0, stamp);
     float4* sT = smem + (size_t)part * NC * 80;                 // this wave's rows of the slab
     float4* sR = smem + (size_t)4 * NC * 80;                    // [4][CPB]
@@ -182,6 +181,13 @@ __global__ __launch_bounds__(256) void potts_energy_grad_kernel(PottsArgs a) {
         }
     }
     PPDE_STAMP(a.dbg, 5, stamp);
+}
+
+template <int NG>
+__global__ __launch_bounds__(256) void potts_energy_grad_kernel(PottsArgs a) {
+    warm_kernargs<sizeof(PottsArgs)>();
+    extern __shared__ float4 smem[];
+    potts_body<NG>(a, blockIdx.x, blockIdx.y, smem);
 }
 
 // H = sum_i epart[i] in a fixed tree with fp64 partials (one wave); returns the same value in all lanes.

@@ -209,8 +209,84 @@ static int launch_cnn(const ppde_model* m, const uint8_t* states, int n, const E
     return PPDE_OK;
 }
 
+// Both experts in ONE launch. The CNN grid (chains x networks workgroups, two per CU by LDS) comes first in block
+// order; once it exceeds the CU count, every further workgroup shares a CU with an earlier one and the CUs beyond
+// (grid - CUs) hold a single one with half of their LDS and wave slots idle for the whole launch (measured: 32 us
+// alone vs 37 / 45 us for a pair). The Potts tiles come last in block order, so they are placed into exactly those
+// free slots and finish long before the paired CNN workgroups: the Potts evaluation costs no time of its own and
+// one launch boundary disappears. (Running the two kernels on two streams of a captured graph was measured 24 us
+// per iteration SLOWER: fork/join inside a hipGraph is expensive.)
+struct ExpertsArgs {
+    CnnArgs c;
+    PottsArgs p;
+    int cnn_bx, cnn_ni;        // CNN workgroups = cnn_bx (chains) x cnn_ni (networks), first in block order
+    int potts_tiles;           // then potts_tiles x (chain blocks) Potts workgroups
+};
+template <int RT, int NG>
+__global__ __launch_bounds__(256, 2) void k_experts(ExpertsArgs a) {
+    warm_kernargs<sizeof(ExpertsArgs)>();
+    extern __shared__ float4 smem_experts[];
+    const int w = blockIdx.x, n_cnn = a.cnn_bx * a.cnn_ni;
+    if (w < n_cnn) {
+        const int ni = w / a.cnn_bx;
+        cnn_body<RT, 5>(a.c, w - ni * a.cnn_bx, ni, a.cnn_bx, a.cnn_ni, (unsigned char*)smem_experts);
+    } else {
+        const int q = w - n_cnn, by = q / a.potts_tiles;
+        potts_body<NG>(a.p, q - by * a.potts_tiles, by, smem_experts);
+    }
+}
+
+static int launch_experts_fused(const ppde_model* m, const uint8_t* states, int n, const EvalTargets& t, float scale,
+                                hipStream_t s, int b_off, int n_sub, bool* done) {
+    *done = false;
+    static const bool enabled = []() { const char* e = getenv("PPDE_FUSE_EXPERTS"); return !e || atoi(e) != 0; }();
+    const int NG = potts_ng_for(n_sub);
+    if (!enabled || !cnn_single_launch(m) || m->KT != 5 || NG > 2 || g_potts_events) return PPDE_OK;
+    const size_t lds_c = cnn_lds_bytes(m->T, m->CP, m->FP, m->J, m->L), lds_p = potts_lds_bytes(m->g.NC, NG, m->g.Ls);
+    if (lds_p > lds_c || ((m->g.NC * 1280 + 1023) >> 10) > 32) return PPDE_OK;
+    ExpertsArgs a{};
+    CnnArgs& c = a.c;
+    c.b_off = b_off; c.dbg = t.dbg;
+    for (int k = 0; k < m->n_nets; ++k) c.net[k] = m->nets[k];
+    c.n_nets = m->n_nets; c.C = m->C; c.CP = m->CP; c.K = m->K; c.KT = m->KT; c.F = m->F; c.FP = m->FP; c.T = m->T; c.J = m->J; c.JP = m->JP;
+    c.idx = states; c.gradC = t.gradC; c.fitC = t.fitC;
+    c.slot = t.slot; c.n = n; c.want_grad = 1; c.scale = scale;
+    c.g = m->g;
+    PottsArgs& p = a.p;
+    p.b_off = b_off; p.n_sub = n_sub; p.dbg = t.dbg;
+    p.Jt = m->d_Jt; p.h = m->d_h; p.idx = states; p.grad = t.grad; p.epart = t.epart;
+    p.slot = t.slot; p.n = n;
+    p.g = m->g;
+    a.cnn_bx = n_sub; a.cnn_ni = m->n_nets;
+    a.potts_tiles = m->g.Lp * 5;
+    const int CPB = NG * 64;
+    const dim3 grid(a.cnn_bx * a.cnn_ni + a.potts_tiles * ((n_sub + CPB - 1) / CPB));
+#define PPDE_EX(RTV)                                                                              \
+    if (NG == 1) hipLaunchKernelGGL((k_experts<RTV, 1>), grid, dim3(256), lds_c, s, a);            \
+    else hipLaunchKernelGGL((k_experts<RTV, 2>), grid, dim3(256), lds_c, s, a);
+    switch (cnn_rows(m->T) / 16) {
+        case 1: PPDE_EX(1) break;
+        case 2: PPDE_EX(2) break;
+        case 3: PPDE_EX(3) break;
+        case 4: PPDE_EX(4) break;
+        case 5: PPDE_EX(5) break;
+        case 6: PPDE_EX(6) break;
+        case 7: PPDE_EX(7) break;
+        default: PPDE_EX(8) break;
+    }
+#undef PPDE_EX
+    HIPCHK(hipGetLastError());
+    *done = true;
+    return PPDE_OK;
+}
+
 static int eval_experts(const ppde_model* m, int which, const uint8_t* states, int n, const EvalTargets& t,
                         int want_grad, hipStream_t s, int b_off = 0, int n_sub = -1) {
+    if ((which & 3) == 3 && want_grad && m->has_potts && m->has_cnn) {
+        bool done = false;
+        int rc = launch_experts_fused(m, states, n, t, m->lamda / (float)m->n_nets, s, b_off, n_sub < 0 ? n : n_sub, &done);
+        if (rc || done) return rc;
+    }
     if (which & 1) {
         ARGCHK(m->has_potts, "the energy uses the Potts expert but ppde_model_set_potts was not called");
         int rc = launch_potts(m, states, n, t, s, b_off, n_sub);
