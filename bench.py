@@ -35,6 +35,8 @@ def parse():
     p.add_argument("--chains", type=int, default=128, help="chains per GPU")
     p.add_argument("--workload", default="potts", choices=["potts", "potts+cnn"],
                    help="potts = BASELINE configs[1] (Potts-only PoE); potts+cnn = configs[2] (lamda=5)")
+    p.add_argument("--protein", default="PABP", choices=["PABP", "UBE4B", "GFP"],
+                   help="PABP = the configuration BASELINE.json's metric is quoted on; the others are auxiliary measurements")
     p.add_argument("--reuse-grad", type=int, default=0,
                    help="0 (default): evaluate energy+gradient twice per step exactly as the reference does; "
                         "1: carry the current state's gradient over (bit-identical results, half the expert calls)")
@@ -47,11 +49,12 @@ def parse():
     return p.parse_args()
 
 
-def build_model(workload, device):
+def build_model(workload, device, protein="PABP"):
     from ppde_amd import synthetic
     from ppde_amd.encoding import seqs_to_idx
     from ppde_amd.energy import HipModel
-    _, seq, (i0, Lp) = synthetic.PROTEINS["PABP_YEAST_Fields2013"]
+    name = [k for k in synthetic.PROTEINS if k.startswith(protein)][0]
+    _, seq, (i0, Lp) = synthetic.PROTEINS[name]
     wt = seqs_to_idx([seq])[0]
     J, h = synthetic.make_potts(Lp, seed=1234)
     m = HipModel(wt, device)
@@ -115,7 +118,7 @@ def main():
     torch.cuda.set_device(local)
 
     from ppde_amd.sampler import Chains
-    m, wt, J, h, i0, Lp, cnn = build_model(args.workload, device)
+    m, wt, J, h, i0, Lp, cnn = build_model(args.workload, device, args.protein)
     n, L = args.chains, wt.shape[0]
     which = 3 if args.workload == "potts+cnn" else 1
     IN_SITU = 200
@@ -170,7 +173,7 @@ def main():
 
     if rank == 0:
         out = {
-            "metric": "MCMC steps/sec (128 chains, PABP Potts PoE)",
+            "metric": "MCMC steps/sec (128 chains, PABP Potts PoE)" if args.protein == "PABP" else f"MCMC steps/sec ({n} chains, {args.protein} Potts PoE)",
             "value": world * args.steps / dt,
             "unit": "steps/s",
             "n_gpus": world,
@@ -182,8 +185,9 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": "PABP_YEAST Potts product of experts" + (" + supervised CNN (lamda=5)" if cnn else "")
-                                   + f", L=96, L'=80, A=20, {n} chains/GPU, pas_length={args.pas}, nmut_threshold={args.nmut}, "
+            "config": {"workload": {"PABP": "PABP_YEAST", "UBE4B": "UBE4B_MOUSE", "GFP": "GFP_AEQVI"}[args.protein]
+                                   + " Potts product of experts" + (" + supervised CNN (lamda=5)" if cnn else "")
+                                   + f", L={L}, L'={Lp}, A=20, {n} chains/GPU, pas_length={args.pas}, nmut_threshold={args.nmut}, "
                                      "device Philox RNG, all chains start at WT",
                        "chains_per_gpu": n, "total_chains": n * world, "parallelism": f"chains sharded x{world}, no per-step collective",
                        "energy_evaluations_per_step": 1 if args.reuse_grad else 2, "hip_streams": args.streams},

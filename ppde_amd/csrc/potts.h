@@ -88,11 +88,20 @@ __device__ __forceinline__ uint32_t lds_offset_of(const void* p) {
 __host__ __device__ inline size_t potts_lds_bytes(int NC, int NG, int Ls) {
     return ((size_t)4 * NC * 80 + (size_t)4 * NG * 64) * 16 + (((size_t)NG * 64 * Ls + 1023) & ~(size_t)1023) + 1024;
 }
+// Long windows (NC > POTTS_RING_CHUNKS): each wave streams its slab rows through a ring of 8 chunks = 10 pieces
+// (10 KiB) instead of holding them all, which keeps two workgroups per CU (GFP, L' = 237: 113 KB -> 73 KB) and the
+// DMA queue fed while the wave gathers. The part sums are exchanged through the (then free) rings.
+#define POTTS_RING_CHUNKS 8
+#define POTTS_RING_PIECES 10
+__host__ __device__ inline size_t potts_ring_lds_bytes(int NG, int Ls) {
+    return (size_t)4 * POTTS_RING_CHUNKS * 80 * 16 + (((size_t)NG * 64 * Ls + 1023) & ~(size_t)1023) + 1024;
+}
 
 // Body of one workgroup: `tile` = 4 output columns, `by` = block of NG*64 chains. A __device__ function so that
 // the kernel below and the fused experts launch (ppde_api.hip: k_experts) share it.
-template <int NG>   // NG groups of 64 chains per workgroup
+template <int NG, bool RING = false>   // NG groups of 64 chains per workgroup
 __device__ __forceinline__ void potts_body(const PottsArgs& a, const int tile, const int by, float4* smem) {
+    static_assert(!RING || NG <= 2, "the part sums of a ring workgroup live in one wave's 10 KiB ring");
     const Geom g = a.g;
     const int NC = g.NC;
     constexpr int CPB = NG * 64;
@@ -102,9 +111,11 @@ __device__ __forceinline__ void potts_body(const PottsArgs& a, const int tile, c
     const int b_end = a.b_off + a.n_sub;
     [[maybe_unused]] const bool stamp = tile == 0 && by == 0;
     PPDE_STAMP(a.dbg, 0, stamp);
-    float4* sT = smem + (size_t)part * NC * 80;                 // this wave's rows of the slab
-    float4* sR = smem + (size_t)4 * NC * 80;                    // [4][CPB]
-    uint8_t* sS = (uint8_t*)(sR + 4 * CPB);                     // raw state rows of this chain block [CPB][Ls]
+    const int slab_rows = RING ? POTTS_RING_CHUNKS * 80 : NC * 80;   // float4 rows of LDS per wave
+    float4* sT = smem + (size_t)part * slab_rows;               // this wave's rows of the slab (or its ring)
+    float4* sR = RING ? smem : smem + (size_t)4 * slab_rows;    // [4][CPB] part sums (ring: wave p's sums in wave p's ring)
+    const int sr_stride = RING ? slab_rows : CPB;
+    uint8_t* sS = (uint8_t*)(RING ? smem + (size_t)4 * slab_rows : sR + 4 * CPB);   // raw state rows of this chain block [CPB][Ls]
 
     // ---- LDS-DMA, 1 KiB a piece: first the chain block's state rows (one contiguous, coalesced range shared by
     //      the four waves), then this wave's own slab rows. Ls/4 is odd, so the strided letter reads below are
@@ -119,12 +130,14 @@ __device__ __forceinline__ void potts_body(const PottsArgs& a, const int tile, c
         const int off = p * 1024 + lane * 16;
         if (off < state_bytes) glds16_asm(ssrc + off, lds_offset_of(sS + p * 1024));
     }
-    for (int p = 0; p < npieces; ++p) {
-        const int off = p * 1024 + lane * 16;
-        if (off < region_bytes) glds16_asm(src + off, lds_offset_of(sT + p * 64));
+    int issued = 0;                                              // slab pieces requested so far
+    const int first = RING ? min(npieces, POTTS_RING_PIECES) : npieces;
+    for (; issued < first; ++issued) {
+        const int off = issued * 1024 + lane * 16;
+        if (off < region_bytes) glds16_asm(src + off, lds_offset_of(sT + issued * 64));
     }
     PPDE_STAMP(a.dbg, 1, stamp);
-    wait_vmcnt(npieces);                                        // my state pieces have landed (issued first) ...
+    wait_vmcnt(issued);                                         // my state pieces have landed (issued first) ...
     asm volatile("" ::: "memory");
     __builtin_amdgcn_s_barrier();                               // ... and so have the other waves'
     PPDE_STAMP(a.dbg, 2, stamp);
@@ -136,9 +149,9 @@ __device__ __forceinline__ void potts_body(const PottsArgs& a, const int tile, c
     for (int gi = 0; gi < NG; ++gi) acc[gi] = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int ck = 0; ck < NC; ++ck) {
         const int need = min(((ck + 1) * 1280 + 1023) >> 10, npieces);
-        wait_vmcnt(npieces - need);
+        wait_vmcnt(issued - need);
         asm volatile("" ::: "memory");
-        const float4* rows = sT + ck * 80;
+        const float4* rows = sT + (RING ? ck % POTTS_RING_CHUNKS : ck) * 80;
 #pragma unroll
         for (int gi = 0; gi < NG; ++gi) {
             const uint32_t w = *(const uint32_t*)(myrow + (size_t)gi * 64 * g.Ls + 4 * ck);
@@ -149,10 +162,18 @@ __device__ __forceinline__ void potts_body(const PottsArgs& a, const int tile, c
                 acc[gi].x += r.x; acc[gi].y += r.y; acc[gi].z += r.z; acc[gi].w += r.w;
             }
         }
+        if (RING && (ck & 3) == 3 && issued < npieces) {        // chunks 4h .. 4h+3 = pieces 5h .. 5h+4 are consumed: refill them
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (their LDS reads have returned)
+            const int upto = min(issued + POTTS_RING_PIECES / 2, npieces);
+            for (; issued < upto; ++issued) {
+                const int off = issued * 1024 + lane * 16;
+                if (off < region_bytes) glds16_asm(src + off, lds_offset_of(sT + (issued % POTTS_RING_PIECES) * 64));
+            }
+        }
     }
     PPDE_STAMP(a.dbg, 3, stamp);
 #pragma unroll
-    for (int gi = 0; gi < NG; ++gi) sR[part * CPB + gi * 64 + lane] = acc[gi];
+    for (int gi = 0; gi < NG; ++gi) sR[part * sr_stride + gi * 64 + lane] = acc[gi];
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
@@ -163,7 +184,7 @@ __device__ __forceinline__ void potts_body(const PottsArgs& a, const int tile, c
     for (int cl = tid; cl < CPB; cl += 256) {
         const int b = b0 + cl;
         if (b >= b_end) continue;
-        const float4 s0 = sR[cl], s1 = sR[CPB + cl], s2 = sR[2 * CPB + cl], s3 = sR[3 * CPB + cl];
+        const float4 s0 = sR[cl], s1 = sR[sr_stride + cl], s2 = sR[2 * sr_stride + cl], s3 = sR[3 * sr_stride + cl];
         float4 S;
         S.x = (s0.x + s1.x) + (s2.x + s3.x);
         S.y = (s0.y + s1.y) + (s2.y + s3.y);
@@ -183,11 +204,11 @@ __device__ __forceinline__ void potts_body(const PottsArgs& a, const int tile, c
     PPDE_STAMP(a.dbg, 5, stamp);
 }
 
-template <int NG>
+template <int NG, bool RING = false>
 __global__ __launch_bounds__(256) void potts_energy_grad_kernel(PottsArgs a) {
     warm_kernargs<sizeof(PottsArgs)>();
     extern __shared__ float4 smem[];
-    potts_body<NG>(a, blockIdx.x, blockIdx.y, smem);
+    potts_body<NG, RING>(a, blockIdx.x, blockIdx.y, smem);
 }
 
 // H = sum_i epart[i] in a fixed tree with fp64 partials (one wave); returns the same value in all lanes.

@@ -130,19 +130,29 @@ static int launch_potts(const ppde_model* m, const uint8_t* states, int n, const
     int NG = potts_ng_for(n_sub);
     static const int ng_override = []() { const char* e = getenv("PPDE_POTTS_NG"); return e ? atoi(e) : 0; }();   // tuning knob
     if (ng_override == 1 || ng_override == 2 || ng_override == 4 || ng_override == 8) NG = ng_override;
-    size_t lds = potts_lds_bytes(m->g.NC, NG, m->g.Ls);
-    while (lds > 150 * 1024 && NG > 1) { NG >>= 1; lds = potts_lds_bytes(m->g.NC, NG, m->g.Ls); }
-    ARGCHK(((m->g.NC * 1280 + 1023) >> 10) <= 32, "Potts window too long for the LDS-DMA pipeline");
-    ARGCHK(lds <= 160 * 1024, "Potts window too long for one LDS slab");
-    dim3 grid(m->g.Lp * 5, (n_sub + NG * 64 - 1) / (NG * 64));
     ARGCHK(m->g.Ls <= 512, "state rows longer than 512 bytes are not supported by the Potts kernel staging");
-    switch (NG) {
-        case 1: hipLaunchKernelGGL(potts_energy_grad_kernel<1>, grid, dim3(256), lds, s, a); break;
-        case 2: hipLaunchKernelGGL(potts_energy_grad_kernel<2>, grid, dim3(256), lds, s, a); break;
-        case 4: hipLaunchKernelGGL(potts_energy_grad_kernel<4>, grid, dim3(256), lds, s, a); break;
-        default: hipLaunchKernelGGL(potts_energy_grad_kernel<8>, grid, dim3(256), lds, s, a); break;
+    static const int ring_override = []() { const char* e = getenv("PPDE_POTTS_RING"); return e ? atoi(e) : -1; }();   // tuning knob
+    const bool ring = ring_override >= 0 ? ring_override != 0 : m->g.NC > POTTS_RING_CHUNKS;   // long windows stream through a ring
+    if (ring) {
+        NG = std::min(NG, 2);
+        const size_t lds = potts_ring_lds_bytes(NG, m->g.Ls);
+        ARGCHK(lds <= 160 * 1024, "state rows too long for the Potts kernel staging");
+        dim3 grid(m->g.Lp * 5, (n_sub + NG * 64 - 1) / (NG * 64));
+        if (NG == 1) hipLaunchKernelGGL((potts_energy_grad_kernel<1, true>), grid, dim3(256), lds, s, a);
+        else hipLaunchKernelGGL((potts_energy_grad_kernel<2, true>), grid, dim3(256), lds, s, a);
+    } else {
+        size_t lds = potts_lds_bytes(m->g.NC, NG, m->g.Ls);
+        while (lds > 150 * 1024 && NG > 1) { NG >>= 1; lds = potts_lds_bytes(m->g.NC, NG, m->g.Ls); }
+        ARGCHK(((m->g.NC * 1280 + 1023) >> 10) <= 32, "Potts window too long for the LDS-DMA pipeline");
+        ARGCHK(lds <= 160 * 1024, "Potts window too long for one LDS slab");
+        dim3 grid(m->g.Lp * 5, (n_sub + NG * 64 - 1) / (NG * 64));
+        switch (NG) {
+            case 1: hipLaunchKernelGGL(potts_energy_grad_kernel<1>, grid, dim3(256), lds, s, a); break;
+            case 2: hipLaunchKernelGGL(potts_energy_grad_kernel<2>, grid, dim3(256), lds, s, a); break;
+            case 4: hipLaunchKernelGGL(potts_energy_grad_kernel<4>, grid, dim3(256), lds, s, a); break;
+            default: hipLaunchKernelGGL(potts_energy_grad_kernel<8>, grid, dim3(256), lds, s, a); break;
+        }
     }
-
     HIPCHK(hipGetLastError());
     if (ep) HIPCHK(hipEventRecord(ep->ev[ep->used++], s));
     return PPDE_OK;
