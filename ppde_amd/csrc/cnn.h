@@ -93,7 +93,9 @@ __device__ __forceinline__ void mfma_strip(f32x4 (&acc)[RT], const float* A, int
 // KT = convolution taps the tables are laid out for (the real kernel size, or zero-padded to CNN_MAX_K): a
 // compile-time trip count keeps the table loads branch-free, so they issue back to back.
 // Body of one workgroup = (chain bx of the launch, network ni); shared by k_cnn and the fused experts launch.
-template <int RT, int KT>
+// NT = threads per workgroup: 256 where two workgroups fit a CU's LDS, 512 (8 waves) where only one does, so that
+// the CU's four SIMDs still hold two waves each.
+template <int RT, int KT, int NT = 256>
 __device__ __forceinline__ void cnn_body(const CnnArgs& a, const int bx, const int ni, const int n_bx, const int n_ni,
                                          unsigned char* smem_raw) {
     const Geom g = a.g;
@@ -130,8 +132,8 @@ __device__ __forceinline__ void cnn_body(const CnnArgs& a, const int bx, const i
     PPDE_WG_STAMP(a.dbg, wg_lin, 0);
     float wdf[2];                                                   // decoder weights of this thread's features (used after the
 #pragma unroll                                                      // forward contraction: no L2 round trip there)
-    for (int k = 0; k < 2; ++k) wdf[k] = net.wd[min(tid + 256 * k, FP - 1)];
-    for (int l = tid; l < g.L + CNN_MAX_K; l += 256) sSt[l] = l < g.L ? min((int)a.idx[(size_t)b * g.Ls + g.sh + l], 19) : 0;
+    for (int k = 0; k < 2; ++k) wdf[k] = net.wd[min(tid + NT * k, FP - 1)];
+    for (int l = tid; l < g.L + CNN_MAX_K; l += NT) sSt[l] = l < g.L ? min((int)a.idx[(size_t)b * g.Ls + g.sh + l], 19) : 0;
     __syncthreads();
     PPDE_STAMP(a.dbg, sb + 1, stamp);
 
@@ -139,12 +141,12 @@ __device__ __forceinline__ void cnn_body(const CnnArgs& a, const int bx, const i
     //      channels, row): 16-byte table loads (a quarter of the load instructions of a dword gather), two rows per
     //      round = 2*KT independent L2 loads in flight, addresses clamped and values masked (no branches). The ReLU
     //      gate bits are OR-ed into sG with LDS atomics.
-    for (int w = tid; w < rows * BW; w += 256) sG[w] = 0u;
-    for (int e = tid; e < rows * 2; e += 256) sH[(e >> 1) * AS + CP + (e & 1)] = 0.f;   // (the contractions stop at CP: never read)
+    for (int w = tid; w < rows * BW; w += NT) sG[w] = 0u;
+    for (int e = tid; e < rows * 2; e += NT) sH[(e >> 1) * AS + CP + (e & 1)] = 0.f;   // (the contractions stop at CP: never read)
     __syncthreads();
     {
         const int G4 = CP / 4;                                       // float4 groups per row
-        const int RPR = 256 / G4;                                    // rows per round (threads beyond RPR*G4 idle)
+        const int RPR = NT / G4;                                     // rows per round (threads beyond RPR*G4 idle)
         const int g4 = tid % G4, tr = tid / G4;
         if (tr < RPR) {
             const float4 bias4 = *(const float4*)(net.bc + 4 * g4);
@@ -180,7 +182,7 @@ __device__ __forceinline__ void cnn_body(const CnnArgs& a, const int bx, const i
     PPDE_STAMP(a.dbg, sb + 2, stamp);
     // ---- pre2 = h1 We^T + be on the matrix cores; relu and the running max over t straight from the accumulators
     //      (strict >, rows ascending: the first index wins, like torch.max)
-    for (int ct = wave; ct < FP / 16; ct += 4) {
+    for (int ct = wave; ct < FP / 16; ct += NT / 64) {
         f32x4 acc[RT];
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) acc[rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -218,18 +220,18 @@ __device__ __forceinline__ void cnn_body(const CnnArgs& a, const int bx, const i
         int k = 0;
 #pragma unroll
         for (k = 0; k < 2; ++k) {                                    // FP <= 512
-            const int f = tid + 256 * k;
+            const int f = tid + NT * k;
             if (f >= FP) break;
             const float wv = f < F ? wdf[k] : 0.f, mf = sM[f];
             s += wv * mf;
             cf[k] = (f < F && mf > 0.f) ? a.scale * wv : 0.f;
         }
         if (a.want_grad)
-            for (int w = tid; w < rows * BWF; w += 256) sB[w] = 0u;  // route bitmap (filled behind the barrier below)
-        const float tot = block_sum<4>(s, red, phase);             // (its barrier also orders the sM rewrite below)
+            for (int w = tid; w < rows * BWF; w += NT) sB[w] = 0u;  // route bitmap (filled behind the barrier below)
+        const float tot = block_sum<NT / 64>(s, red, phase);             // (its barrier also orders the sM rewrite below)
         if (tid == 0) a.fitC[((size_t)slot * a.n_nets + ni) * a.n + b] = tot + net.bd;
         k = 0;
-        for (int f = tid; f < FP; f += 256, ++k)
+        for (int f = tid; f < FP; f += NT, ++k)
             if (k < 2) sM[f] = cf[k];
     }
     PPDE_STAMP(a.dbg, sb + 4, stamp);
@@ -244,7 +246,7 @@ __device__ __forceinline__ void cnn_body(const CnnArgs& a, const int bx, const i
     //          pieces coming straight from L2 with a dozen loads in flight per thread, and applies the gate.
     {
         int k = 0;
-        for (int f = tid; f < FP; f += 256, ++k)
+        for (int f = tid; f < FP; f += NT, ++k)
             if (k < 2 && sM[f] != 0.f) atomicOr(&sB[sTs[f] * BWF + (f >> 5)], 1u << (f & 31));   // (own sM writes)
     }
     __syncthreads();
@@ -270,7 +272,7 @@ __device__ __forceinline__ void cnn_body(const CnnArgs& a, const int bx, const i
     __syncthreads();
     {
         int k = 0;
-        for (int f = tid; f < FP; f += 256, ++k) {
+        for (int f = tid; f < FP; f += NT, ++k) {
             if (k >= 2 || sM[f] == 0.f) continue;
             const int t = sTs[f], w = f >> 5;
             int r = __builtin_popcount(sB[t * BWF + w] & ((1u << (f & 31)) - 1u));
@@ -287,13 +289,13 @@ __device__ __forceinline__ void cnn_body(const CnnArgs& a, const int bx, const i
         const int G4 = CP / 4, items = rows * G4;
         const int last = max(sStart[rows] - 1, 0);
         const float4* We4 = (const float4*)net.We;                   // [FP][G4]
-        for (int item0 = tid; item0 < items; item0 += 256 * 3) {
+        for (int item0 = tid; item0 < items; item0 += NT * 3) {
             int t[3], c4[3], rs[3], kk[3];
             float4 v[3][4];
             float c[3][4];
 #pragma unroll
             for (int j = 0; j < 3; ++j) {
-                const int ic = min(item0 + 256 * j, items - 1);
+                const int ic = min(item0 + NT * j, items - 1);
                 t[j] = ic / G4; c4[j] = ic - t[j] * G4;
                 rs[j] = sStart[t[j]];
                 kk[j] = sStart[t[j] + 1] - rs[j];
@@ -324,7 +326,7 @@ __device__ __forceinline__ void cnn_body(const CnnArgs& a, const int bx, const i
                 const uint32_t nib = (sG[t[j] * BW + (c4[j] >> 3)] >> (4 * (c4[j] & 7))) & 0xFu;   // gate by relu'(pre1)
                 acc.x = (nib & 1u) ? acc.x : 0.f; acc.y = (nib & 2u) ? acc.y : 0.f;
                 acc.z = (nib & 4u) ? acc.z : 0.f; acc.w = (nib & 8u) ? acc.w : 0.f;
-                if (item0 + 256 * j < items) {
+                if (item0 + NT * j < items) {
                     float* dp = sD + t[j] * AS + 4 * c4[j];          // AS = 2 mod 4: rows are only 8-byte aligned
                     *(float2*)dp = make_float2(acc.x, acc.y);
                     *(float2*)(dp + 2) = make_float2(acc.z, acc.w);
@@ -337,7 +339,7 @@ __device__ __forceinline__ void cnn_body(const CnnArgs& a, const int bx, const i
     PPDE_WG_STAMP(a.dbg, wg_lin, 2);
     // ---- O[t][kappa*20 + c] = sum_o dpre1[t][o] Wc[o][c][kappa] on the matrix cores (O takes h1's storage)
     float* sO = sH;
-    for (int ct = wave; ct < JP / 16; ct += 4) {
+    for (int ct = wave; ct < JP / 16; ct += NT / 64) {
         f32x4 acc[RT];
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) acc[rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -355,12 +357,12 @@ __device__ __forceinline__ void cnn_body(const CnnArgs& a, const int bx, const i
     PPDE_STAMP(a.dbg, sb + 8, stamp);
     // ---- transposed convolution: dx[p][c] = sum_kappa O[p - kappa][kappa*20 + c]
     float* out = a.gradC + (((size_t)slot * a.n_nets + ni) * a.n + b) * g.N;
-    for (int e0 = tid; e0 < g.N; e0 += 512) {                       // two elements per round: 2*KT LDS reads in flight
+    for (int e0 = tid; e0 < g.N; e0 += 2 * NT) {                       // two elements per round: 2*KT LDS reads in flight
         float x[2][KT];
         int pp[2];
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
-            const int e = min(e0 + 256 * u, g.N - 1);
+            const int e = min(e0 + NT * u, g.N - 1);
             const int p = e / 20, c = e - 20 * p;
             pp[u] = p;
 #pragma unroll
@@ -376,7 +378,7 @@ __device__ __forceinline__ void cnn_body(const CnnArgs& a, const int bx, const i
             float v = 0.f;
 #pragma unroll
             for (int kp = 0; kp < KT; ++kp) v += (pp[u] - kp >= 0 && pp[u] - kp < T) ? x[u][kp] : 0.f;   // masked value
-            if (e0 + 256 * u < g.N) out[e0 + 256 * u] = v;
+            if (e0 + NT * u < g.N) out[e0 + NT * u] = v;
         }
     }
     PPDE_STAMP(a.dbg, sb + 9, stamp);
@@ -387,7 +389,13 @@ template <int RT, int KT>
 __global__ __launch_bounds__(256, 2) void k_cnn(CnnArgs a) {
     warm_kernargs<sizeof(CnnArgs)>();
     extern __shared__ unsigned char smem_raw[];
-    cnn_body<RT, KT>(a, blockIdx.x, blockIdx.y, gridDim.x, gridDim.y, smem_raw);
+    cnn_body<RT, KT, 256>(a, blockIdx.x, blockIdx.y, gridDim.x, gridDim.y, smem_raw);
+}
+template <int RT, int KT>
+__global__ __launch_bounds__(512, 2) void k_cnn_wide(CnnArgs a) {
+    warm_kernargs<sizeof(CnnArgs)>();
+    extern __shared__ unsigned char smem_raw[];
+    cnn_body<RT, KT, 512>(a, blockIdx.x, blockIdx.y, gridDim.x, gridDim.y, smem_raw);
 }
 
 // =====================================================================================================

@@ -201,6 +201,18 @@ static int launch_cnn(const ppde_model* m, const uint8_t* states, int n, const E
     }
     size_t lds = cnn_lds_bytes(m->T, m->CP, m->FP, m->J, m->L);
     const dim3 grid(n_sub, m->n_nets);
+    static const int wide_override = []() { const char* e = getenv("PPDE_CNN_WIDE"); return e ? atoi(e) : -1; }();   // tuning knob
+    const int rt = cnn_rows(m->T) / 16;
+    if ((wide_override >= 0 ? wide_override != 0 : 2 * lds > 160 * 1024) && rt >= 7) {
+        // only one workgroup fits a CU's LDS: eight waves per workgroup keep two waves on every SIMD
+#define PPDE_CNNW(RTV)                                                                          \
+        if (m->KT == 5) hipLaunchKernelGGL((k_cnn_wide<RTV, 5>), grid, dim3(512), lds, s, a);     \
+        else hipLaunchKernelGGL((k_cnn_wide<RTV, CNN_MAX_K>), grid, dim3(512), lds, s, a);
+        if (rt == 7) { PPDE_CNNW(7) } else { PPDE_CNNW(8) }
+#undef PPDE_CNNW
+        HIPCHK(hipGetLastError());
+        return PPDE_OK;
+    }
 #define PPDE_CNN(RTV)                                                                           \
     if (m->KT == 5) hipLaunchKernelGGL((k_cnn<RTV, 5>), grid, dim3(256), lds, s, a);              \
     else hipLaunchKernelGGL((k_cnn<RTV, CNN_MAX_K>), grid, dim3(256), lds, s, a);
@@ -253,7 +265,7 @@ static int launch_experts_fused(const ppde_model* m, const uint8_t* states, int 
     const int NG = potts_ng_for(n_sub);
     if (!enabled || !cnn_single_launch(m) || m->KT != 5 || NG > 2 || g_potts_events) return PPDE_OK;
     const size_t lds_c = cnn_lds_bytes(m->T, m->CP, m->FP, m->J, m->L), lds_p = potts_lds_bytes(m->g.NC, NG, m->g.Ls);
-    if (lds_p > lds_c || ((m->g.NC * 1280 + 1023) >> 10) > 32) return PPDE_OK;
+    if (lds_p > lds_c || 2 * lds_c > 160 * 1024 || m->g.NC > POTTS_RING_CHUNKS) return PPDE_OK;   // (needs the free second slot)
     ExpertsArgs a{};
     CnnArgs& c = a.c;
     c.b_off = b_off; c.dbg = t.dbg;
