@@ -93,3 +93,26 @@ def test_sampler_vs_oracle_shapes(L, Lp, i0, n, with_cnn):
     ch2.run(45)
     r2 = ch2.collect()
     assert np.isfinite(r2["energy_history"]).all() and np.array_equal(r2["best_energy"], r2["energy_history"].max(0))
+
+
+@pytest.mark.parametrize("L,Lp,i0,with_cnn,n", [(237, 237, 0, False, 300),    # ring Potts kernel, 2 chain groups, 3 chain blocks
+                                                 (96, 80, 8, True, 100),       # both experts in one launch (2 chain groups)
+                                                 (96, 80, 8, True, 300),       # 4 chain groups: separate launches
+                                                 (104, 76, 23, True, 70),      # 8-wave CNN workgroups
+                                                 (237, 237, 0, True, 70)])     # chunked CNN + ring Potts
+def test_batch_composition_does_not_change_a_bit(L, Lp, i0, with_cnn, n):
+    """Every chain's energy, fitness and gradient are bit-identical whether it is evaluated in a large batch (other
+    chain-group counts, other launch shapes, other kernels) or in batches of 20: results cannot depend on sharding."""
+    lam = 3.0 if with_cnn else 0.0
+    m, wt, J, h, cnn = _model(L, Lp, i0, with_cnn, lam)
+    rng = np.random.default_rng(n)
+    idx = np.tile(wt, (n, 1))
+    for b in range(n):
+        pos = rng.choice(L, size=min(L, b % 17), replace=False)
+        idx[b, pos] = rng.integers(0, 20, len(pos))
+    which = 3 if with_cnn else 1
+    x = torch.as_tensor(idx).cuda()
+    e, f, g = m.energy_grad(x, which)
+    for lo in range(0, n, 20):
+        e2, f2, g2 = m.energy_grad(x[lo:lo + 20], which)
+        assert torch.equal(e[lo:lo + 20], e2) and torch.equal(f[lo:lo + 20], f2) and torch.equal(g[lo:lo + 20], g2), lo
