@@ -401,20 +401,24 @@ __global__ __launch_bounds__(512, 2) void k_cnn_wide(CnnArgs a) {
 // =====================================================================================================
 // Long sequences (the [T x C] activations of one chain do not fit LDS next to the routed gradient, e.g. GFP,
 // L = 237): the same arithmetic cut along the length axis into two launches.
-//   k_cnn_fwd_chunk  grid (chain, network, NCH): rows [c*96, c*96+96): conv gather, forward contraction, the
+//   k_cnn_fwd_chunk  grid (chain, network, NCH): rows [c*R, c*R+R): conv gather, forward contraction, the
 //                    chunk's max / arg-max per feature -> global scratch
 //   k_cnn_bwd_chunk  grid (chain, network, NCB): merges the chunk maxima (first index on ties), chunk 0 writes
 //                    the network output; then routes / gates / contracts the rows its OUTPUT positions
-//                    [c*PO, c*PO+PO) depend on, PO = 96 - (KT-1): the KT-1 halo rows are recomputed instead
+//                    [c*PO, c*PO+PO) depend on, PO = R' - (KT-1): the KT-1 halo rows are recomputed instead
 //                    of exchanged, so every output element has exactly one writer.
 // =====================================================================================================
-#define CNN_CH_RT 6                                   // 96 rows per chunk
-__host__ __device__ inline int cnn_fwd_chunks(int T) { return (T + CNN_CH_RT * 16 - 1) / (CNN_CH_RT * 16); }
-__host__ __device__ inline int cnn_bwd_out_per_chunk(int KT) { return CNN_CH_RT * 16 - (KT - 1); }
+// Rows per chunk are chosen so that TWO workgroups fit a CU's LDS at GFP's width (256 padded channels): the
+// forward chunk holds [rows x channels] (64 rows: 66 KB), the backward chunk additionally [rows x 5*20] (48 rows:
+// 69 KB). With 96-row chunks a CU held one 4-wave workgroup at a time (fwd 341 us, bwd 300 us per launch at GFP).
+#define CNN_FCH_RT 4                                  // forward: 64 rows per chunk
+#define CNN_BCH_RT 3                                  // backward: 48-row windows
+__host__ __device__ inline int cnn_fwd_chunks(int T) { return (T + CNN_FCH_RT * 16 - 1) / (CNN_FCH_RT * 16); }
+__host__ __device__ inline int cnn_bwd_out_per_chunk(int KT) { return CNN_BCH_RT * 16 - (KT - 1); }
 __host__ __device__ inline int cnn_bwd_chunks(int L, int KT) { return (L + cnn_bwd_out_per_chunk(KT) - 1) / cnn_bwd_out_per_chunk(KT); }
-__host__ __device__ inline size_t cnn_fwd_chunk_lds(int CP) { return (size_t)CNN_CH_RT * 16 * cnn_astride(CP) * 4 + 256; }
+__host__ __device__ inline size_t cnn_fwd_chunk_lds(int CP) { return (size_t)CNN_FCH_RT * 16 * cnn_astride(CP) * 4 + 256; }
 __host__ __device__ inline size_t cnn_bwd_chunk_lds(int CP, int FP, int J) {
-    const size_t rows = CNN_CH_RT * 16;
+    const size_t rows = CNN_BCH_RT * 16;
     return rows * cnn_astride(CP) * 4 + rows * J * 4 + rows * ((CP + 31) / 32) * 4 + (size_t)FP * 12 + 512;
 }
 
@@ -468,12 +472,12 @@ __device__ __forceinline__ void cnn_build_rows(const CnnNet& net, const uint8_t*
 }
 
 template <int KT>
-__global__ __launch_bounds__(256) void k_cnn_fwd_chunk(CnnChunkArgs ca) {
+__global__ __launch_bounds__(256, 2) void k_cnn_fwd_chunk(CnnChunkArgs ca) {
     warm_kernargs<sizeof(CnnChunkArgs)>();
     extern __shared__ unsigned char smem_raw[];
     const CnnArgs& a = ca.a;
     const Geom g = a.g;
-    constexpr int RT = CNN_CH_RT, rows = RT * 16;
+    constexpr int RT = CNN_FCH_RT, rows = RT * 16;
     const int b = a.b_off + blockIdx.x, ni = blockIdx.y, c = blockIdx.z, tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const CnnNet net = a.net[ni];
@@ -523,12 +527,12 @@ __global__ __launch_bounds__(256) void k_cnn_fwd_chunk(CnnChunkArgs ca) {
 }
 
 template <int KT>
-__global__ __launch_bounds__(256) void k_cnn_bwd_chunk(CnnChunkArgs ca) {
+__global__ __launch_bounds__(256, 2) void k_cnn_bwd_chunk(CnnChunkArgs ca) {
     warm_kernargs<sizeof(CnnChunkArgs)>();
     extern __shared__ unsigned char smem_raw[];
     const CnnArgs& a = ca.a;
     const Geom g = a.g;
-    constexpr int RT = CNN_CH_RT, rows = RT * 16;
+    constexpr int RT = CNN_BCH_RT, rows = RT * 16;
     const int b = a.b_off + blockIdx.x, ni = blockIdx.y, c = blockIdx.z, tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const CnnNet net = a.net[ni];
