@@ -416,7 +416,7 @@ __global__ __launch_bounds__(512, 2) void k_cnn_wide(CnnArgs a) {
 __host__ __device__ inline int cnn_fwd_chunks(int T) { return (T + CNN_FCH_RT * 16 - 1) / (CNN_FCH_RT * 16); }
 __host__ __device__ inline int cnn_bwd_out_per_chunk(int KT) { return CNN_BCH_RT * 16 - (KT - 1); }
 __host__ __device__ inline int cnn_bwd_chunks(int L, int KT) { return (L + cnn_bwd_out_per_chunk(KT) - 1) / cnn_bwd_out_per_chunk(KT); }
-__host__ __device__ inline size_t cnn_fwd_chunk_lds(int CP) { return (size_t)CNN_FCH_RT * 16 * cnn_astride(CP) * 4 + 256; }
+__host__ __device__ inline size_t cnn_fwd_chunk_lds(int CP) { return (size_t)CNN_FCH_RT * 16 * (cnn_astride(CP) + (CP + 31) / 32) * 4 + 256; }
 __host__ __device__ inline size_t cnn_bwd_chunk_lds(int CP, int FP, int J) {
     const size_t rows = CNN_BCH_RT * 16;
     return rows * cnn_astride(CP) * 4 + rows * J * 4 + rows * ((CP + 31) / 32) * 4 + (size_t)FP * 12 + 512;
@@ -426,11 +426,12 @@ struct CnnChunkArgs {
     CnnArgs a;
     float* cmax;        // [nets][n][NCH][FP] chunk maxima of relu(pre2)
     int* carg;          // [nets][n][NCH][FP] their rows
+    uint32_t* cgate;    // [nets][n][NCH * rows][BW] ReLU gate bits of h1 (bit o of word o/32: h1[t][o] > 0)
     int NCH;
 };
 
-// h1 rows [t0, t0 + rows) of one chain into LDS (optionally only their ReLU gate bits)
-template <int KT, bool BITS_ONLY>
+// h1 rows [t0, t0 + rows) of one chain into LDS and / or their ReLU gate bits
+template <int KT, bool WANT_H, bool WANT_BITS>
 __device__ __forceinline__ void cnn_build_rows(const CnnNet& net, const uint8_t* sSt, int t0, int rows, int T, int CP, int AS,
                                                float* sH, uint32_t* sG, int BW) {
     const int tid = threadIdx.x;
@@ -458,11 +459,12 @@ __device__ __forceinline__ void cnn_build_rows(const CnnNet& net, const uint8_t*
                 const bool live = t >= 0 && t < T;
                 x.x = live ? fmaxf(x.x, 0.f) : 0.f; x.y = live ? fmaxf(x.y, 0.f) : 0.f;
                 x.z = live ? fmaxf(x.z, 0.f) : 0.f; x.w = live ? fmaxf(x.w, 0.f) : 0.f;
-                if constexpr (!BITS_ONLY) {
+                if constexpr (WANT_H) {
                     float* hp = sH + r * AS + 4 * g4;
                     *(float2*)hp = make_float2(x.x, x.y);
                     *(float2*)(hp + 2) = make_float2(x.z, x.w);
-                } else {
+                }
+                if constexpr (WANT_BITS) {
                     const uint32_t nib = (x.x > 0.f ? 1u : 0u) | (x.y > 0.f ? 2u : 0u) | (x.z > 0.f ? 4u : 0u) | (x.w > 0.f ? 8u : 0u);
                     if (nib) atomicOr(&sG[r * BW + (g4 >> 3)], nib << (4 * (g4 & 7)));
                 }
@@ -482,9 +484,12 @@ __global__ __launch_bounds__(256, 2) void k_cnn_fwd_chunk(CnnChunkArgs ca) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const CnnNet net = a.net[ni];
     const int T = a.T, CP = a.CP, FP = a.FP, AS = cnn_astride(CP), KSP = CP / 4;
+    const int BW = (CP + 31) / 32;
     float* sH = (float*)smem_raw;
-    uint8_t* sSt = (uint8_t*)(sH + (size_t)rows * AS);               // letters t0 .. t0 + rows + KT (relative index)
+    uint32_t* sG = (uint32_t*)(sH + (size_t)rows * AS);              // [rows][BW] gate bits of this chunk's rows
+    uint8_t* sSt = (uint8_t*)(sG + (size_t)rows * BW);               // letters t0 .. t0 + rows + KT (relative index)
     const int t0 = c * rows;
+    for (int w = tid; w < rows * BW; w += 256) sG[w] = 0u;
     for (int l = tid; l < rows + CNN_MAX_K; l += 256) {
         const int res = t0 + l;
         sSt[l] = res < g.L ? min((int)a.idx[(size_t)b * g.Ls + g.sh + res], 19) : 0;
@@ -492,8 +497,12 @@ __global__ __launch_bounds__(256, 2) void k_cnn_fwd_chunk(CnnChunkArgs ca) {
     for (int e = tid; e < rows * 2; e += 256) sH[(e >> 1) * AS + CP + (e & 1)] = 0.f;
     __syncthreads();
     // sSt is relative to t0 here: shift the pointer so that cnn_build_rows can index by absolute residue
-    cnn_build_rows<KT, false>(net, sSt - t0, t0, rows, T, CP, AS, sH, nullptr, 0);
+    cnn_build_rows<KT, true, true>(net, sSt - t0, t0, rows, T, CP, AS, sH, sG, BW);
     __syncthreads();
+    if (a.want_grad) {                                               // the backward windows read the gate instead of recomputing it
+        uint32_t* gout = ca.cgate + ((((size_t)ni * a.n + b) * ca.NCH) + c) * rows * BW;
+        for (int w = tid; w < rows * BW; w += 256) gout[w] = sG[w];
+    }
     for (int ct = wave; ct < FP / 16; ct += 4) {
         f32x4 acc[RT];
 #pragma unroll
@@ -579,8 +588,14 @@ __global__ __launch_bounds__(256, 2) void k_cnn_bwd_chunk(CnnChunkArgs ca) {
     for (int e = tid; e < rows * AS; e += 256) sD[e] = 0.f;
     if (tid == 0) *sCnt = 0;
     __syncthreads();
-    // ---- ReLU gate bits of the window's rows (h1 itself is not needed again)
-    cnn_build_rows<KT, true>(net, sSt - r0, r0, rows, T, CP, AS, nullptr, sG, BW);
+    // ---- ReLU gate bits of the window's rows, as the forward chunks left them (rows outside [0, T): zero)
+    {
+        const uint32_t* gin = ca.cgate + ((size_t)ni * a.n + b) * ca.NCH * (CNN_FCH_RT * 16) * BW;
+        for (int w = tid; w < rows * BW; w += 256) {
+            const int t = r0 + w / BW;
+            sG[w] = (t >= 0 && t < T) ? gin[(size_t)t * BW + (w % BW)] : 0u;
+        }
+    }
     // ---- features whose arg-max row lies in the window, compacted in feature order (one wave, ballot + prefix)
     if (wave == 0) {
         int cnt = 0;

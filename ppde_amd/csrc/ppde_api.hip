@@ -65,6 +65,7 @@ struct ppde_model {
     // chunk maxima of the long-sequence CNN path, sized for `cnn_scratch_n` chains
     float* cnn_cmax = nullptr;
     int* cnn_carg = nullptr;
+    uint32_t* cnn_cgate = nullptr;   // ReLU gate bits of h1, written by the forward chunks for the backward chunks
     int cnn_scratch_n = 0;
 };
 
@@ -164,10 +165,11 @@ static bool cnn_single_launch(const ppde_model* m) {
 
 static int ensure_cnn_scratch(ppde_model* m, int n) {
     if (cnn_single_launch(m) || n <= m->cnn_scratch_n) return PPDE_OK;
-    hipFree(m->cnn_cmax); hipFree(m->cnn_carg);
+    hipFree(m->cnn_cmax); hipFree(m->cnn_carg); hipFree(m->cnn_cgate);
     const size_t cnt = (size_t)m->n_nets * n * cnn_fwd_chunks(m->T) * m->FP;
     HIPCHK(dalloc(&m->cnn_cmax, cnt));
     HIPCHK(dalloc(&m->cnn_carg, cnt));
+    HIPCHK(dalloc(&m->cnn_cgate, (size_t)m->n_nets * n * cnn_fwd_chunks(m->T) * CNN_FCH_RT * 16 * ((m->CP + 31) / 32)));
     m->cnn_scratch_n = n;
     return PPDE_OK;
 }
@@ -187,7 +189,7 @@ static int launch_cnn(const ppde_model* m, const uint8_t* states, int n, const E
         ARGCHK(m->cnn_scratch_n >= n, "CNN chunk scratch not allocated for this batch size");
         ARGCHK(cnn_fwd_chunk_lds(m->CP) <= 160 * 1024 && cnn_bwd_chunk_lds(m->CP, m->FP, m->J) <= 160 * 1024,
                "sequence too long for the chunked CNN kernels");
-        CnnChunkArgs ca{a, m->cnn_cmax, m->cnn_carg, cnn_fwd_chunks(m->T)};
+        CnnChunkArgs ca{a, m->cnn_cmax, m->cnn_carg, m->cnn_cgate, cnn_fwd_chunks(m->T)};
         const dim3 gf(n_sub, m->n_nets, ca.NCH), gb(n_sub, m->n_nets, want_grad ? cnn_bwd_chunks(m->L, m->KT) : 1);
         if (m->KT == 5) {
             hipLaunchKernelGGL(k_cnn_fwd_chunk<5>, gf, dim3(256), cnn_fwd_chunk_lds(m->CP), s, ca);
@@ -363,7 +365,7 @@ int ppde_model_destroy(ppde_model* m) {
     hipSetDevice(m->device);
     free_scratch(m);
     hipFree(m->s_flag);
-    hipFree(m->d_wt); hipFree(m->d_Jt); hipFree(m->d_h); hipFree(m->cnn_cmax); hipFree(m->cnn_carg);
+    hipFree(m->d_wt); hipFree(m->d_Jt); hipFree(m->d_h); hipFree(m->cnn_cmax); hipFree(m->cnn_carg); hipFree(m->cnn_cgate);
     for (void* p : m->cnn_allocs) hipFree(p);
     delete m;
     return PPDE_OK;
@@ -480,8 +482,8 @@ int ppde_model_set_cnn(ppde_model* m, int n_nets, int C, int K, int F, const flo
         nt.bd = dec_b[k][0];
     }
     free_scratch(m);
-    hipFree(m->cnn_cmax); hipFree(m->cnn_carg);
-    m->cnn_cmax = nullptr; m->cnn_carg = nullptr; m->cnn_scratch_n = 0;
+    hipFree(m->cnn_cmax); hipFree(m->cnn_carg); hipFree(m->cnn_cgate);
+    m->cnn_cmax = nullptr; m->cnn_carg = nullptr; m->cnn_cgate = nullptr; m->cnn_scratch_n = 0;
     m->has_cnn = true;
     return PPDE_OK;
 }
