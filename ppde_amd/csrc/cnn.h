@@ -92,6 +92,114 @@ __device__ __forceinline__ void mfma_strip(f32x4 (&acc)[RT], const float* A, int
 
 // KT = convolution taps the tables are laid out for (the real kernel size, or zero-padded to CNN_MAX_K): a
 // compile-time trip count keeps the table loads branch-free, so they issue back to back.
+// Routed gradient of a window of rows [r0, r0 + rows) with the ReLU gate of h1 applied:
+//   sD[t - r0][o] = [h1[t][o] > 0] * sum_{f: t*_f = t} coef_f * We[f][o],   features in increasing order (deterministic),
+// written by ONE writer per element (no read-modify-write chains through LDS):
+//   (1) a bitmap per row of the features that land in it (LDS atomicOr: independent of arrival order) gives row
+//       counts, row offsets and each feature's rank in its row, i.e. the list of routed features sorted by
+//       (row, feature);
+//   (2) work item = (row, 4 channels) sums coef * We[f][4c..] over its row's consecutive list entries, the pieces
+//       coming straight from L2 with a dozen loads in flight per thread, and applies the gate.
+// sM[f] = coefficient (0: not routed), sTs[f] = absolute arg-max row. sB (rows x ceil(FP/32) words) must be ZERO on
+// entry and may alias sD (it is dead before sD is written); rows <= 128. Ends with a barrier.
+template <int NT>
+__device__ __forceinline__ void cnn_route_rows(const CnnNet& net, const int rows, const int r0, const int CP, const int AS,
+                                               const int FP, const int BW, float* sD, uint32_t* sB, const uint32_t* sG,
+                                               const float* sM, const int* sTs, int* sStart, int* sList, int* sTot) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int BWF = (FP + 31) / 32;
+    {
+        int k = 0;
+        for (int f = tid; f < FP; f += NT, ++k) {
+            const int t = sTs[f] - r0;
+            if (k < 2 && sM[f] != 0.f && t >= 0 && t < rows) atomicOr(&sB[t * BWF + (f >> 5)], 1u << (f & 31));
+        }
+    }
+    __syncthreads();
+    // row counts and offsets: an exclusive scan inside each group of 64 rows (waves 0 and 1), then the second
+    // group is shifted by the first group's total
+    if (tid < 128) {
+        int my_cnt = 0;
+        if (tid < rows)
+            for (int w = 0; w < BWF; ++w) my_cnt += __builtin_popcount(sB[tid * BWF + w]);
+        int incl = my_cnt;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int up = __shfl_up(incl, o);
+            if (lane >= o) incl += up;
+        }
+        if (tid < rows) sStart[tid] = incl - my_cnt;
+        if (tid == rows - 1) sStart[rows] = (rows == 64) ? 0 : incl;   // (row index `rows` belongs to the next group iff rows == 64)
+        if (lane == 63) sTot[wave] = incl;
+    }
+    __syncthreads();
+    if (tid >= 64 && tid <= rows) sStart[tid] += sTot[0];
+    __syncthreads();
+    {
+        int k = 0;
+        for (int f = tid; f < FP; f += NT, ++k) {
+            const int t = sTs[f] - r0, w = f >> 5;
+            if (k >= 2 || sM[f] == 0.f || t < 0 || t >= rows) continue;
+            int r = __builtin_popcount(sB[t * BWF + w] & ((1u << (f & 31)) - 1u));
+            for (int w2 = 0; w2 < w; ++w2) r += __builtin_popcount(sB[t * BWF + w2]);
+            sList[sStart[t] + r] = f;
+        }
+    }
+    __syncthreads();
+    {
+        // work item = (row, 4 channels); three items per round, the first four list entries of each fetched
+        // unconditionally (clamped index, zero coefficient past the row's end): 12 independent L2 loads in flight
+        const int G4 = CP / 4, items = rows * G4;
+        const int last = max(sStart[rows] - 1, 0);
+        const float4* We4 = (const float4*)net.We;                   // [FP][G4]
+        for (int item0 = tid; item0 < items; item0 += NT * 3) {
+            int t[3], c4[3], rs[3], kk[3];
+            float4 v[3][4];
+            float c[3][4];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const int ic = min(item0 + NT * j, items - 1);
+                t[j] = ic / G4; c4[j] = ic - t[j] * G4;
+                rs[j] = sStart[t[j]];
+                kk[j] = sStart[t[j] + 1] - rs[j];
+            }
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int f = min((unsigned)sList[min(rs[j] + q, last)], (unsigned)(FP - 1));
+                    v[j][q] = We4[(size_t)f * G4 + c4[j]];
+                    c[j][q] = q < kk[j] ? sM[f] : 0.f;
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    acc.x += c[j][q] * v[j][q].x; acc.y += c[j][q] * v[j][q].y;
+                    acc.z += c[j][q] * v[j][q].z; acc.w += c[j][q] * v[j][q].w;
+                }
+                for (int q = 4; q < kk[j]; ++q) {                    // rows with more than four routed features
+                    const int f = sList[rs[j] + q];
+                    const float cq = sM[f];
+                    const float4 w = We4[(size_t)f * G4 + c4[j]];
+                    acc.x += cq * w.x; acc.y += cq * w.y; acc.z += cq * w.z; acc.w += cq * w.w;
+                }
+                const uint32_t nib = (sG[t[j] * BW + (c4[j] >> 3)] >> (4 * (c4[j] & 7))) & 0xFu;   // gate by relu'(pre1)
+                acc.x = (nib & 1u) ? acc.x : 0.f; acc.y = (nib & 2u) ? acc.y : 0.f;
+                acc.z = (nib & 4u) ? acc.z : 0.f; acc.w = (nib & 8u) ? acc.w : 0.f;
+                if (item0 + NT * j < items) {
+                    float* dp = sD + t[j] * AS + 4 * c4[j];          // AS = 2 mod 4: rows are only 8-byte aligned
+                    *(float2*)dp = make_float2(acc.x, acc.y);
+                    *(float2*)(dp + 2) = make_float2(acc.z, acc.w);
+                }
+            }
+        }
+    }
+    __syncthreads();
+}
+
 // Body of one workgroup = (chain bx of the launch, network ni); shared by k_cnn and the fused experts launch.
 // NT = threads per workgroup: 256 where two workgroups fit a CU's LDS, 512 (8 waves) where only one does, so that
 // the CU's four SIMDs still hold two waves each.
@@ -237,103 +345,9 @@ __device__ __forceinline__ void cnn_body(const CnnArgs& a, const int bx, const i
     PPDE_STAMP(a.dbg, sb + 4, stamp);
     if (!a.want_grad) return;
 
-    // ---- route + gate: d pre1[t][o] = [h1[t][o] > 0] * sum_{f: t*_f = t} coef_f * We[f][o], features in increasing
-    //      order (deterministic), written to sD by ONE writer per element (no read-modify-write chains in LDS):
-    //      (1) a bitmap per row of the features that land in it (LDS atomicOr: independent of arrival order) gives
-    //          row counts, row offsets and each feature's rank in its row: a list of routed features sorted by
-    //          (row, feature);
-    //      (2) work item = (row, 4 channels) sums coef * We[f][4c..] over its row's consecutive list entries, the
-    //          pieces coming straight from L2 with a dozen loads in flight per thread, and applies the gate.
-    {
-        int k = 0;
-        for (int f = tid; f < FP; f += NT, ++k)
-            if (k < 2 && sM[f] != 0.f) atomicOr(&sB[sTs[f] * BWF + (f >> 5)], 1u << (f & 31));   // (own sM writes)
-    }
-    __syncthreads();
-    // row counts and offsets: an exclusive scan inside each group of 64 rows (waves 0 and 1), then the second
-    // group is shifted by the first group's total
-    int* sTot = (int*)(red + 12);
-    if (tid < 128) {
-        int my_cnt = 0;
-        if (tid < rows)
-            for (int w = 0; w < BWF; ++w) my_cnt += __builtin_popcount(sB[tid * BWF + w]);
-        int incl = my_cnt;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const int up = __shfl_up(incl, o);
-            if (lane >= o) incl += up;
-        }
-        if (tid < rows) sStart[tid] = incl - my_cnt;
-        if (tid == rows - 1) sStart[rows] = (rows == 64) ? 0 : incl;   // (row index `rows` belongs to the next group iff rows == 64)
-        if (lane == 63) sTot[wave] = incl;
-    }
-    __syncthreads();
-    if (tid >= 64 && tid <= rows) sStart[tid] += sTot[0];
-    __syncthreads();
-    {
-        int k = 0;
-        for (int f = tid; f < FP; f += NT, ++k) {
-            if (k >= 2 || sM[f] == 0.f) continue;
-            const int t = sTs[f], w = f >> 5;
-            int r = __builtin_popcount(sB[t * BWF + w] & ((1u << (f & 31)) - 1u));
-            for (int w2 = 0; w2 < w; ++w2) r += __builtin_popcount(sB[t * BWF + w2]);
-            sList[sStart[t] + r] = f;
-        }
-    }
-    __syncthreads();
+    // ---- route + gate (cnn_route_rows): d pre1 = relu'(pre1) * (features routed into their arg-max rows) -> sD
+    cnn_route_rows<NT>(net, rows, 0, CP, AS, FP, BW, sD, sB, sG, sM, sTs, sStart, sList, (int*)(red + 12));
     PPDE_STAMP(a.dbg, sb + 5, stamp);
-    PPDE_WG_STAMP(a.dbg, wg_lin, 1);
-    {
-        // work item = (row, 4 channels); three items per round, the first four list entries of each fetched
-        // unconditionally (clamped index, zero coefficient past the row's end): 12 independent L2 loads in flight
-        const int G4 = CP / 4, items = rows * G4;
-        const int last = max(sStart[rows] - 1, 0);
-        const float4* We4 = (const float4*)net.We;                   // [FP][G4]
-        for (int item0 = tid; item0 < items; item0 += NT * 3) {
-            int t[3], c4[3], rs[3], kk[3];
-            float4 v[3][4];
-            float c[3][4];
-#pragma unroll
-            for (int j = 0; j < 3; ++j) {
-                const int ic = min(item0 + NT * j, items - 1);
-                t[j] = ic / G4; c4[j] = ic - t[j] * G4;
-                rs[j] = sStart[t[j]];
-                kk[j] = sStart[t[j] + 1] - rs[j];
-            }
-#pragma unroll
-            for (int j = 0; j < 3; ++j) {
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int f = min((unsigned)sList[min(rs[j] + q, last)], (unsigned)(FP - 1));
-                    v[j][q] = We4[(size_t)f * G4 + c4[j]];
-                    c[j][q] = q < kk[j] ? sM[f] : 0.f;
-                }
-            }
-#pragma unroll
-            for (int j = 0; j < 3; ++j) {
-                float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    acc.x += c[j][q] * v[j][q].x; acc.y += c[j][q] * v[j][q].y;
-                    acc.z += c[j][q] * v[j][q].z; acc.w += c[j][q] * v[j][q].w;
-                }
-                for (int q = 4; q < kk[j]; ++q) {                    // rows with more than four routed features
-                    const int f = sList[rs[j] + q];
-                    const float cq = sM[f];
-                    const float4 w = We4[(size_t)f * G4 + c4[j]];
-                    acc.x += cq * w.x; acc.y += cq * w.y; acc.z += cq * w.z; acc.w += cq * w.w;
-                }
-                const uint32_t nib = (sG[t[j] * BW + (c4[j] >> 3)] >> (4 * (c4[j] & 7))) & 0xFu;   // gate by relu'(pre1)
-                acc.x = (nib & 1u) ? acc.x : 0.f; acc.y = (nib & 2u) ? acc.y : 0.f;
-                acc.z = (nib & 4u) ? acc.z : 0.f; acc.w = (nib & 8u) ? acc.w : 0.f;
-                if (item0 + NT * j < items) {
-                    float* dp = sD + t[j] * AS + 4 * c4[j];          // AS = 2 mod 4: rows are only 8-byte aligned
-                    *(float2*)dp = make_float2(acc.x, acc.y);
-                    *(float2*)(dp + 2) = make_float2(acc.z, acc.w);
-                }
-            }
-        }
-    }
     __syncthreads();
     PPDE_STAMP(a.dbg, sb + 7, stamp);
     PPDE_WG_STAMP(a.dbg, wg_lin, 2);
@@ -419,7 +433,7 @@ __host__ __device__ inline int cnn_bwd_chunks(int L, int KT) { return (L + cnn_b
 __host__ __device__ inline size_t cnn_fwd_chunk_lds(int CP) { return (size_t)CNN_FCH_RT * 16 * (cnn_astride(CP) + (CP + 31) / 32) * 4 + 256; }
 __host__ __device__ inline size_t cnn_bwd_chunk_lds(int CP, int FP, int J) {
     const size_t rows = CNN_BCH_RT * 16;
-    return rows * cnn_astride(CP) * 4 + rows * J * 4 + rows * ((CP + 31) / 32) * 4 + (size_t)FP * 12 + 512;
+    return rows * cnn_astride(CP) * 4 + rows * J * 4 + rows * ((CP + 31) / 32) * 4 + (size_t)FP * 12 + 512;   // (+ offsets, sums)
 }
 
 struct CnnChunkArgs {
@@ -555,7 +569,7 @@ __global__ __launch_bounds__(256, 2) void k_cnn_bwd_chunk(CnnChunkArgs ca) {
     int* sList = sTs + FP;                                            // [FP] features routed into this window, in order
     float* red = (float*)(sList + FP);                                // 16 floats + 1 int
     int* sCnt = (int*)(red + 16);
-    uint8_t* sSt = (uint8_t*)(sCnt + 4);                              // letters (relative to r0 - 0)
+    int* sStart = sCnt + 4;                                           // [rows + 1] list offsets of the window's rows (+ 3 pad)
     int phase = 0;
     const int PO = cnn_bwd_out_per_chunk(KT);
     const int p0 = c * PO, r0 = p0 - (KT - 1);                        // window rows r0 .. r0 + rows
@@ -580,14 +594,7 @@ __global__ __launch_bounds__(256, 2) void k_cnn_bwd_chunk(CnnChunkArgs ca) {
     if (c == 0 && tid == 0) a.fitC[((size_t)slot * a.n_nets + ni) * a.n + b] = tot + net.bd;
     if (!a.want_grad) return;
 
-    for (int l = tid; l < rows + CNN_MAX_K; l += 256) {
-        const int res = r0 + l;
-        sSt[l] = (res >= 0 && res < g.L) ? min((int)a.idx[(size_t)b * g.Ls + g.sh + res], 19) : 0;
-    }
-    for (int w = tid; w < rows * BW; w += 256) sG[w] = 0u;
-    for (int e = tid; e < rows * AS; e += 256) sD[e] = 0.f;
-    if (tid == 0) *sCnt = 0;
-    __syncthreads();
+    for (int w = tid; w < rows * ((FP + 31) / 32); w += 256) ((uint32_t*)sD)[w] = 0u;   // route bitmap (in sD's storage)
     // ---- ReLU gate bits of the window's rows, as the forward chunks left them (rows outside [0, T): zero)
     {
         const uint32_t* gin = ca.cgate + ((size_t)ni * a.n + b) * ca.NCH * (CNN_FCH_RT * 16) * BW;
@@ -596,45 +603,9 @@ __global__ __launch_bounds__(256, 2) void k_cnn_bwd_chunk(CnnChunkArgs ca) {
             sG[w] = (t >= 0 && t < T) ? gin[(size_t)t * BW + (w % BW)] : 0u;
         }
     }
-    // ---- features whose arg-max row lies in the window, compacted in feature order (one wave, ballot + prefix)
-    if (wave == 0) {
-        int cnt = 0;
-        for (int f0 = 0; f0 < FP; f0 += 64) {
-            const int f = f0 + lane;
-            const bool in = f < F && sM[f] != 0.f && sTs[f] >= r0 && sTs[f] < r0 + rows;
-            const unsigned long long bal = __ballot(in);
-            if (in) sList[cnt + __popcll(bal & ((1ull << lane) - 1ull))] = f;
-            cnt += __popcll(bal);
-        }
-        if (lane == 0) *sCnt = cnt;
-    }
     __syncthreads();
-    const int nlist = *sCnt;
-    // ---- route (thread = channel, features in order), batches of 8 rows of We in flight
-    for (int o = tid; o < CP; o += 256) {
-        for (int k0 = 0; k0 < nlist; k0 += 8) {
-            float w[8], cf[8];
-            int rr[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int f = sList[min(k0 + j, nlist - 1)];
-                w[j] = net.We[(size_t)f * CP + o];
-                cf[j] = k0 + j < nlist ? sM[f] : 0.f;
-                rr[j] = sTs[f] - r0;
-            }
-#pragma unroll
-            for (int j = 0; j < 8; ++j)
-                if (cf[j] != 0.f) sD[rr[j] * AS + o] += cf[j] * w[j];
-        }
-    }
-    __syncthreads();
-    // ---- gate
-    for (int o = tid & 127; o < AS; o += 128)
-        for (int r = tid >> 7; r < rows; r += 2) {
-            const bool on = o < CP && ((sG[r * BW + (min(o, CP - 1) >> 5)] >> (o & 31)) & 1u);
-            if (!on) sD[r * AS + o] = 0.f;
-        }
-    __syncthreads();
+    // ---- route the features whose arg-max row lies in the window, gate (cnn_route_rows)
+    cnn_route_rows<256>(net, rows, r0, CP, AS, FP, BW, sD, (uint32_t*)sD, sG, sM, sTs, sStart, sList, sCnt);
     // ---- O = dpre1 x Wf on the matrix cores
     for (int ct = wave; ct < JP / 16; ct += 4) {
         f32x4 acc[RT];
