@@ -201,8 +201,7 @@ __device__ __forceinline__ void cnn_route_rows(const CnnNet& net, const int rows
 }
 
 // Body of one workgroup = (chain bx of the launch, network ni); shared by k_cnn and the fused experts launch.
-// NT = threads per workgroup: 256 where two workgroups fit a CU's LDS, 512 (8 waves) where only one does, so that
-// the CU's four SIMDs still hold two waves each.
+// NT = threads per workgroup (256 in every shipped instantiation; the body does not depend on it).
 template <int RT, int KT, int NT = 256>
 __device__ __forceinline__ void cnn_body(const CnnArgs& a, const int bx, const int ni, const int n_bx, const int n_ni,
                                          unsigned char* smem_raw) {
@@ -405,13 +404,6 @@ __global__ __launch_bounds__(256, 2) void k_cnn(CnnArgs a) {
     extern __shared__ unsigned char smem_raw[];
     cnn_body<RT, KT, 256>(a, blockIdx.x, blockIdx.y, gridDim.x, gridDim.y, smem_raw);
 }
-template <int RT, int KT>
-__global__ __launch_bounds__(512, 2) void k_cnn_wide(CnnArgs a) {
-    warm_kernargs<sizeof(CnnArgs)>();
-    extern __shared__ unsigned char smem_raw[];
-    cnn_body<RT, KT, 512>(a, blockIdx.x, blockIdx.y, gridDim.x, gridDim.y, smem_raw);
-}
-
 // =====================================================================================================
 // Long sequences (the [T x C] activations of one chain do not fit LDS next to the routed gradient, e.g. GFP,
 // L = 237): the same arithmetic cut along the length axis into two launches.

@@ -160,7 +160,14 @@ static int launch_potts(const ppde_model* m, const uint8_t* states, int n, const
 }
 
 static bool cnn_single_launch(const ppde_model* m) {
-    return cnn_rows(m->T) <= 16 * CNN_MAX_RT && cnn_lds_bytes(m->T, m->CP, m->FP, m->J, m->L) <= 160 * 1024;
+    static const int chunked_override = []() { const char* e = getenv("PPDE_CNN_CHUNKED"); return e ? atoi(e) : -1; }();   // tuning knob
+    if (chunked_override == 1) return false;
+    const size_t lds = cnn_lds_bytes(m->T, m->CP, m->FP, m->J, m->L);
+    if (cnn_rows(m->T) > 16 * CNN_MAX_RT || lds > 160 * 1024) return false;
+    // Where only ONE workgroup of the single-launch kernel fits a CU (L >= 100), the chunked path (two to four
+    // workgroups per CU, balanced grids) is faster: UBE4B, L = 104: 166 us/step against 214 (180 with an 8-wave
+    // variant of the single-launch kernel that was built and dropped again). PABP (two per CU): 108 vs 136.
+    return 2 * lds <= 160 * 1024 || chunked_override == 0;
 }
 
 static int ensure_cnn_scratch(ppde_model* m, int n) {
@@ -203,18 +210,6 @@ static int launch_cnn(const ppde_model* m, const uint8_t* states, int n, const E
     }
     size_t lds = cnn_lds_bytes(m->T, m->CP, m->FP, m->J, m->L);
     const dim3 grid(n_sub, m->n_nets);
-    static const int wide_override = []() { const char* e = getenv("PPDE_CNN_WIDE"); return e ? atoi(e) : -1; }();   // tuning knob
-    const int rt = cnn_rows(m->T) / 16;
-    if ((wide_override >= 0 ? wide_override != 0 : 2 * lds > 160 * 1024) && rt >= 7) {
-        // only one workgroup fits a CU's LDS: eight waves per workgroup keep two waves on every SIMD
-#define PPDE_CNNW(RTV)                                                                          \
-        if (m->KT == 5) hipLaunchKernelGGL((k_cnn_wide<RTV, 5>), grid, dim3(512), lds, s, a);     \
-        else hipLaunchKernelGGL((k_cnn_wide<RTV, CNN_MAX_K>), grid, dim3(512), lds, s, a);
-        if (rt == 7) { PPDE_CNNW(7) } else { PPDE_CNNW(8) }
-#undef PPDE_CNNW
-        HIPCHK(hipGetLastError());
-        return PPDE_OK;
-    }
 #define PPDE_CNN(RTV)                                                                           \
     if (m->KT == 5) hipLaunchKernelGGL((k_cnn<RTV, 5>), grid, dim3(256), lds, s, a);              \
     else hipLaunchKernelGGL((k_cnn<RTV, CNN_MAX_K>), grid, dim3(256), lds, s, a);

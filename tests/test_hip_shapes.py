@@ -98,7 +98,7 @@ def test_sampler_vs_oracle_shapes(L, Lp, i0, n, with_cnn):
 @pytest.mark.parametrize("L,Lp,i0,with_cnn,n", [(237, 237, 0, False, 300),    # ring Potts kernel, 2 chain groups, 3 chain blocks
                                                  (96, 80, 8, True, 100),       # both experts in one launch (2 chain groups)
                                                  (96, 80, 8, True, 300),       # 4 chain groups: separate launches
-                                                 (104, 76, 23, True, 70),      # 8-wave CNN workgroups
+                                                 (104, 76, 23, True, 70),      # one single-launch CNN workgroup per CU would fit: chunked CNN instead
                                                  (237, 237, 0, True, 70)])     # chunked CNN + ring Potts
 def test_batch_composition_does_not_change_a_bit(L, Lp, i0, with_cnn, n):
     """Every chain's energy, fitness and gradient are bit-identical whether it is evaluated in a large batch (other
