@@ -107,7 +107,9 @@ struct EvalTargets {
     unsigned long long* dbg = nullptr;
 };
 
-static int potts_ng_for(int n) { return n <= 64 ? 1 : n <= 128 ? 2 : n <= 256 ? 4 : 8; }
+// chain groups (of 64) per Potts workgroup. Measured at 256 / 512 / 1024 chains: 4 groups 7.1 / 11.3 / 18.7 us,
+// 2 groups 8.4 / 11.4 / 17.7, 8 groups (one workgroup per CU by LDS) 7.1 / 14.4 / 25.7.
+static int potts_ng_for(int n) { return n <= 64 ? 1 : n <= 128 ? 2 : 4; }
 
 
 // When set, every Potts launch is bracketed by a pair of events taken from this pool (in-situ timing).
@@ -130,7 +132,7 @@ static int launch_potts(const ppde_model* m, const uint8_t* states, int n, const
     a.g = m->g;
     int NG = potts_ng_for(n_sub);
     static const int ng_override = []() { const char* e = getenv("PPDE_POTTS_NG"); return e ? atoi(e) : 0; }();   // tuning knob
-    if (ng_override == 1 || ng_override == 2 || ng_override == 4 || ng_override == 8) NG = ng_override;
+    if (ng_override == 1 || ng_override == 2 || ng_override == 4) NG = ng_override;
     ARGCHK(m->g.Ls <= 512, "state rows longer than 512 bytes are not supported by the Potts kernel staging");
     static const int ring_override = []() { const char* e = getenv("PPDE_POTTS_RING"); return e ? atoi(e) : -1; }();   // tuning knob
     const bool ring = ring_override >= 0 ? ring_override != 0 : m->g.NC > POTTS_RING_CHUNKS;   // long windows stream through a ring
@@ -150,8 +152,7 @@ static int launch_potts(const ppde_model* m, const uint8_t* states, int n, const
         switch (NG) {
             case 1: hipLaunchKernelGGL(potts_energy_grad_kernel<1>, grid, dim3(256), lds, s, a); break;
             case 2: hipLaunchKernelGGL(potts_energy_grad_kernel<2>, grid, dim3(256), lds, s, a); break;
-            case 4: hipLaunchKernelGGL(potts_energy_grad_kernel<4>, grid, dim3(256), lds, s, a); break;
-            default: hipLaunchKernelGGL(potts_energy_grad_kernel<8>, grid, dim3(256), lds, s, a); break;
+            default: hipLaunchKernelGGL(potts_energy_grad_kernel<4>, grid, dim3(256), lds, s, a); break;
         }
     }
     HIPCHK(hipGetLastError());
