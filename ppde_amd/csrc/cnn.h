@@ -50,7 +50,7 @@ __host__ __device__ inline int cnn_rows(int T) { return ((T + 15) / 16) * 16; }
 __host__ __device__ inline int cnn_astride(int CP) { return CP + 2; }   // = 2 mod 4 dwords
 __host__ __device__ inline size_t cnn_lds_bytes(int T, int CP, int FP, int J, int L) {
     const size_t rows = cnn_rows(T), AS = cnn_astride(CP), OS = J;
-    const size_t r0 = rows * (AS > OS ? AS : OS) * 4;      // h1, later second route accumulator, later O
+    const size_t r0 = rows * (AS > OS ? AS : OS) * 4;      // h1, later O
     const size_t r1 = rows * AS * 4;                        // routed gradient
     const size_t bits = rows * ((CP + 31) / 32) * 4;        // ReLU gate of h1
     const size_t route = (rows + 4 + (size_t)FP) * 4;       // row offsets and the row-sorted list of routed features
@@ -215,7 +215,7 @@ __device__ __forceinline__ void cnn_body(const CnnArgs& a, const int bx, const i
     const int KSP = CP / 4;                                         // CP is padded to a multiple of 4*CNN_KB
     const int OS = J;
     const int BW = (CP + 31) / 32;                                  // gate words per row
-    float* sH = (float*)smem_raw;                                   // [rows][AS] h1 | route accumulator 2 | O [rows][J]
+    float* sH = (float*)smem_raw;                                   // [rows][AS] h1, later O [rows][J]
     float* sD = sH + (size_t)rows * (AS > OS ? AS : OS);            // [rows][AS] routed gradient
     uint32_t* sG = (uint32_t*)(sD + (size_t)rows * AS);             // [rows][BW] bit o of word: h1[t][o] > 0
     const int BWF = (FP + 31) / 32;                                 // route words per row
