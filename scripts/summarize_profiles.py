@@ -21,7 +21,7 @@ OUT = os.path.join(REPO, "profiles")
 
 
 def counters(d):
-    f = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)[0]
+    f = max(glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True), key=os.path.getmtime)   # newest run
     df = pd.read_csv(f)
     df["kernel"] = df["Kernel_Name"].str.replace(r"\(.*", "", regex=True).str.replace("void ", "")
     return df.groupby(["kernel", "Counter_Name"])["Counter_Value"].agg(["mean", "count"]).reset_index()
@@ -37,7 +37,7 @@ def main():
     a = ap.parse_args()
     os.makedirs(OUT, exist_ok=True)
     if a.stats:
-        f = glob.glob(os.path.join(a.stats, "**", "*kernel_stats.csv"), recursive=True)[0]
+        f = max(glob.glob(os.path.join(a.stats, "**", "*kernel_stats.csv"), recursive=True), key=os.path.getmtime)   # newest run
         shutil.copy(f, os.path.join(OUT, f"{a.tag}_kernel_stats.csv"))
     lines = [f"# rocprofv3 PMC summary ({a.tag})", ""]
     vals = {}
