@@ -266,6 +266,11 @@ def test_full_size_properties():
     same = (eh[1:] == eh[:-1]) | (eh[1:] == e_wt)
     assert same[~acc].all()
     assert 0.02 < acc.mean() < 0.98
+    # 100-iteration graph replays + the eager remainder == every iteration launched eagerly
+    _, tr2, res2 = _philox_run(m, n, T, 2, 10, False, i0, Lp, wt_idx, use_graph=False)
+    for k in ("energy_history", "fitness_history", "best_idx", "best_step"):
+        assert np.array_equal(res[k], res2[k]), k
+    assert np.array_equal(tr["flat"], tr2["flat"]) and np.array_equal(tr["accepted"], tr2["accepted"])
 
 
 def test_error_paths():
