@@ -108,12 +108,9 @@ __device__ __forceinline__ void cnn_route_rows(const CnnNet& net, const int rows
                                                const float* sM, const int* sTs, int* sStart, int* sList, int* sTot) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int BWF = (FP + 31) / 32;
-    {
-        int k = 0;
-        for (int f = tid; f < FP; f += NT, ++k) {
-            const int t = sTs[f] - r0;
-            if (k < 2 && sM[f] != 0.f && t >= 0 && t < rows) atomicOr(&sB[t * BWF + (f >> 5)], 1u << (f & 31));
-        }
+    for (int f = tid; f < FP; f += NT) {
+        const int t = sTs[f] - r0;
+        if (sM[f] != 0.f && t >= 0 && t < rows) atomicOr(&sB[t * BWF + (f >> 5)], 1u << (f & 31));
     }
     __syncthreads();
     // row counts and offsets: an exclusive scan inside each group of 64 rows (waves 0 and 1), then the second
@@ -135,15 +132,12 @@ __device__ __forceinline__ void cnn_route_rows(const CnnNet& net, const int rows
     __syncthreads();
     if (tid >= 64 && tid <= rows) sStart[tid] += sTot[0];
     __syncthreads();
-    {
-        int k = 0;
-        for (int f = tid; f < FP; f += NT, ++k) {
-            const int t = sTs[f] - r0, w = f >> 5;
-            if (k >= 2 || sM[f] == 0.f || t < 0 || t >= rows) continue;
-            int r = __builtin_popcount(sB[t * BWF + w] & ((1u << (f & 31)) - 1u));
-            for (int w2 = 0; w2 < w; ++w2) r += __builtin_popcount(sB[t * BWF + w2]);
-            sList[sStart[t] + r] = f;
-        }
+    for (int f = tid; f < FP; f += NT) {
+        const int t = sTs[f] - r0, w = f >> 5;
+        if (sM[f] == 0.f || t < 0 || t >= rows) continue;
+        int r = __builtin_popcount(sB[t * BWF + w] & ((1u << (f & 31)) - 1u));
+        for (int w2 = 0; w2 < w; ++w2) r += __builtin_popcount(sB[t * BWF + w2]);
+        sList[sStart[t] + r] = f;
     }
     __syncthreads();
     {

@@ -164,7 +164,7 @@ static bool cnn_single_launch(const ppde_model* m) {
     static const int chunked_override = []() { const char* e = getenv("PPDE_CNN_CHUNKED"); return e ? atoi(e) : -1; }();   // tuning knob
     if (chunked_override == 1) return false;
     const size_t lds = cnn_lds_bytes(m->T, m->CP, m->FP, m->J, m->L);
-    if (cnn_rows(m->T) > 16 * CNN_MAX_RT || lds > 160 * 1024) return false;
+    if (cnn_rows(m->T) > 16 * CNN_MAX_RT || lds > 160 * 1024 || m->FP > 512) return false;   // (cnn_body keeps two features per thread)
     // Where only ONE workgroup of the single-launch kernel fits a CU (L >= 100), the chunked path (two to four
     // workgroups per CU, balanced grids) is faster: UBE4B, L = 104: 166 us/step against 214 (180 with an 8-wave
     // variant of the single-launch kernel that was built and dropped again). PABP (two per CU): 108 vs 136.
