@@ -32,7 +32,8 @@ def _model(L, Lp, i0, with_cnn, lam, seed=5, K=5):
                                                (150, 60, 20, True), (133, 133, 0, True),
                                                (237, 237, 0, False),      # GFP: window = whole protein
                                                (104, 76, 23, True),       # UBE4B: odd window start
-                                               (237, 100, 77, False), (40, 7, 31, True), (24, 16, 4, True)])
+                                               (237, 100, 77, False), (40, 7, 31, True), (24, 16, 4, True),
+                                               (300, 120, 50, True)])     # more than 512 CNN features, ring Potts not needed
 def test_energy_grad_shapes(L, Lp, i0, with_cnn):
     lam = 3.0 if with_cnn else 0.0
     m, wt, J, h, cnn = _model(L, Lp, i0, with_cnn, lam)
