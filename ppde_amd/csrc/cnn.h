@@ -68,24 +68,35 @@ __device__ __forceinline__ void mfma_strip(f32x4 (&acc)[RT], const float* A, int
     const int lane = threadIdx.x & 63, r = lane & 15, kq = lane >> 4;
     const float* bp = B + (size_t)kq * ldb + n0 + r;
     const float* ap = A + r * AS + kq;
-    float bn[CNN_KB];
+    // Three B buffers in rotation: while one burst multiplies, the next two are in flight (one burst = RT * CNN_KB
+    // MFMAs does not cover an L2 round trip under load). Each buffer is refilled right after its use, so no register
+    // copies (which would wait for the younger loads) are needed.
+    float bx[CNN_KB], by[CNN_KB], bz[CNN_KB];
+    auto fill = [&](float (&b)[CNN_KB], int kb) {
 #pragma unroll
-    for (int u = 0; u < CNN_KB; ++u) bn[u] = bp[(size_t)u * 4 * ldb];
-    for (int kb = 0; kb < KSP; kb += CNN_KB) {
-        float bv[CNN_KB];
-#pragma unroll
-        for (int u = 0; u < CNN_KB; ++u) bv[u] = bn[u];
-        if (kb + CNN_KB < KSP) {                                // next burst is in flight while this one multiplies
-#pragma unroll
-            for (int u = 0; u < CNN_KB; ++u) bn[u] = bp[(size_t)(kb + CNN_KB + u) * 4 * ldb];
-        }
+        for (int u = 0; u < CNN_KB; ++u) b[u] = bp[(size_t)min(kb + u, KSP - 1) * 4 * ldb];   // (clamped past the end)
+    };
+    auto mult = [&](const float (&b)[CNN_KB], int kb) {
 #pragma unroll
         for (int u = 0; u < CNN_KB; ++u) {
 #pragma unroll
             for (int rt = 0; rt < RT; ++rt) {
                 const float av = ap[rt * 16 * AS + (kb + u) * 4];
-                acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv[u], acc[rt], 0, 0, 0);
+                acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b[u], acc[rt], 0, 0, 0);
             }
+        }
+    };
+    fill(bx, 0); fill(by, CNN_KB); fill(bz, 2 * CNN_KB);
+    for (int kb = 0; kb < KSP; kb += 3 * CNN_KB) {
+        mult(bx, kb);
+        if (kb + 3 * CNN_KB < KSP) fill(bx, kb + 3 * CNN_KB);
+        if (kb + CNN_KB < KSP) {
+            mult(by, kb + CNN_KB);
+            if (kb + 4 * CNN_KB < KSP) fill(by, kb + 4 * CNN_KB);
+        }
+        if (kb + 2 * CNN_KB < KSP) {
+            mult(bz, kb + 2 * CNN_KB);
+            if (kb + 5 * CNN_KB < KSP) fill(bz, kb + 5 * CNN_KB);
         }
     }
 }
@@ -489,6 +500,8 @@ __global__ __launch_bounds__(256, 2) void k_cnn_fwd_chunk(CnnChunkArgs ca) {
     uint32_t* sG = (uint32_t*)(sH + (size_t)rows * AS);              // [rows][BW] gate bits of this chunk's rows
     uint8_t* sSt = (uint8_t*)(sG + (size_t)rows * BW);               // letters t0 .. t0 + rows + KT (relative index)
     const int t0 = c * rows;
+    [[maybe_unused]] const bool stamp = blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 1;
+    PPDE_STAMP(a.dbg, 50, stamp);
     for (int w = tid; w < rows * BW; w += 256) sG[w] = 0u;
     for (int l = tid; l < rows + CNN_MAX_K; l += 256) {
         const int res = t0 + l;
@@ -497,8 +510,10 @@ __global__ __launch_bounds__(256, 2) void k_cnn_fwd_chunk(CnnChunkArgs ca) {
     for (int e = tid; e < rows * 2; e += 256) sH[(e >> 1) * AS + CP + (e & 1)] = 0.f;
     __syncthreads();
     // sSt is relative to t0 here: shift the pointer so that cnn_build_rows can index by absolute residue
+    PPDE_STAMP(a.dbg, 51, stamp);
     cnn_build_rows<KT, true, true>(net, sSt - t0, t0, rows, T, CP, AS, sH, sG, BW);
     __syncthreads();
+    PPDE_STAMP(a.dbg, 52, stamp);
     if (a.want_grad) {                                               // the backward windows read the gate instead of recomputing it
         uint32_t* gout = ca.cgate + ((((size_t)ni * a.n + b) * ca.NCH) + c) * rows * BW;
         for (int w = tid; w < rows * BW; w += 256) gout[w] = sG[w];
@@ -533,6 +548,7 @@ __global__ __launch_bounds__(256, 2) void k_cnn_fwd_chunk(CnnChunkArgs ca) {
             ca.carg[at] = ts;
         }
     }
+    PPDE_STAMP(a.dbg, 53, stamp);
 }
 
 template <int KT>
@@ -561,6 +577,8 @@ __global__ __launch_bounds__(256, 2) void k_cnn_bwd_chunk(CnnChunkArgs ca) {
     const int p0 = c * PO, r0 = p0 - (KT - 1);                        // window rows r0 .. r0 + rows
     const int slot = a.slot;
 
+    [[maybe_unused]] const bool stamp = blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 1;
+    PPDE_STAMP(a.dbg, 40, stamp);
     // ---- merge the forward chunks: first index on ties (chunks ascending, strict >)
     float part = 0.f;
     for (int f = tid; f < FP; f += 256) {
@@ -581,6 +599,7 @@ __global__ __launch_bounds__(256, 2) void k_cnn_bwd_chunk(CnnChunkArgs ca) {
     if (!a.want_grad) return;
 
     for (int w = tid; w < rows * ((FP + 31) / 32); w += 256) ((uint32_t*)sD)[w] = 0u;   // route bitmap (in sD's storage)
+    PPDE_STAMP(a.dbg, 41, stamp);
     // ---- ReLU gate bits of the window's rows, as the forward chunks left them (rows outside [0, T): zero)
     {
         const uint32_t* gin = ca.cgate + ((size_t)ni * a.n + b) * ca.NCH * (CNN_FCH_RT * 16) * BW;
@@ -590,8 +609,10 @@ __global__ __launch_bounds__(256, 2) void k_cnn_bwd_chunk(CnnChunkArgs ca) {
         }
     }
     __syncthreads();
+    PPDE_STAMP(a.dbg, 42, stamp);
     // ---- route the features whose arg-max row lies in the window, gate (cnn_route_rows)
     cnn_route_rows<256>(net, rows, r0, CP, AS, FP, BW, sD, (uint32_t*)sD, sG, sM, sTs, sStart, sList, sCnt);
+    PPDE_STAMP(a.dbg, 43, stamp);
     // ---- O = dpre1 x Wf on the matrix cores
     for (int ct = wave; ct < JP / 16; ct += 4) {
         f32x4 acc[RT];
@@ -608,6 +629,7 @@ __global__ __launch_bounds__(256, 2) void k_cnn_bwd_chunk(CnnChunkArgs ca) {
         }
     }
     __syncthreads();
+    PPDE_STAMP(a.dbg, 44, stamp);
     // ---- transposed convolution for this chunk's own output positions
     float* out = a.gradC + (((size_t)slot * a.n_nets + ni) * a.n + b) * g.N;
     const int p1 = min(p0 + PO, g.L);
@@ -625,4 +647,5 @@ __global__ __launch_bounds__(256, 2) void k_cnn_bwd_chunk(CnnChunkArgs ca) {
         for (int kp = 0; kp < KT; ++kp) v += ov[kp];
         out[e] = v;
     }
+    PPDE_STAMP(a.dbg, 45, stamp);
 }

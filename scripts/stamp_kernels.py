@@ -19,7 +19,8 @@ from bench import build_model
 from ppde_amd.sampler import Chains
 
 WORK = "potts+cnn" if "--cnn" in sys.argv else "potts"
-m, wt, J, h, i0, Lp, cnn = build_model(WORK, "cuda:0")
+PROT = [a.split("=")[1] for a in sys.argv if a.startswith("--protein=")]
+m, wt, J, h, i0, Lp, cnn = build_model(WORK, "cuda:0", PROT[0] if PROT else "PABP")
 n = 128
 pas = 2
 ch = Chains(m, n, 64, pas, 0, False, i0, i0 + Lp - 1, 3 if cnn else 1, 1, reuse_grad=False, use_graph=False, seed=1)
