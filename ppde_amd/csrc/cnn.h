@@ -455,7 +455,9 @@ __device__ __forceinline__ void cnn_build_rows(const CnnNet& net, const uint8_t*
             float4 wv[2][KT];
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
-                const int tt = min(max(t0 + r0 + u * RPR, 0), T - 1);      // sSt is indexed by absolute residue
+                // sSt is indexed by absolute residue and holds the letters of rows t0 .. t0 + rows - 1 (+ KT - 1): a row
+                // index past the chunk (its value is dropped below) must not read letters that were never staged
+                const int tt = min(max(t0 + min(r0 + u * RPR, rows - 1), 0), T - 1);
 #pragma unroll
                 for (int kp = 0; kp < KT; ++kp)
                     wv[u][kp] = *(const float4*)(net.WcT + ((size_t)kp * 20 + sSt[tt + kp]) * CP + 4 * g4);

@@ -1,0 +1,38 @@
+"""Random geometries (sequence length, window, kernel size, experts, batch size) through ppde_energy_grad against the
+oracle. Run on the GPU box: python scripts/fuzz_energy_grad.py [seed]. Exits non-zero on a mismatch."""
+import sys, os, numpy as np, torch
+sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "oracle")); sys.path.insert(0, os.path.join(os.getcwd(), "tests"))
+import ppde_oracle as orc
+from helpers import oracle_energy
+from ppde_amd import synthetic
+from ppde_amd.energy import HipModel
+rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
+bad = 0
+for trial in range(40):
+    L = int(rng.integers(12, 280))
+    Lp = int(rng.integers(4, L + 1)); i0 = int(rng.integers(0, L - Lp + 1))
+    K = int(rng.choice([3, 5, 5, 5, 7])); K = min(K, L - 2)
+    with_cnn = bool(rng.integers(0, 2)); lam = float(rng.choice([0.5, 3.0, 15.0])) if with_cnn else 0.0
+    n = int(rng.choice([1, 7, 64, 65, 130, 200]))
+    wt = rng.integers(0, 20, L).astype(np.uint8)
+    J, h = synthetic.make_potts(Lp, seed=trial, symmetric=bool(rng.integers(0, 2)))
+    cnn = [synthetic.make_cnn_state(L, s, kernel_size=K) for s in range(3)] if with_cnn else None
+    m = HipModel(wt, "cuda:0"); m.set_potts(J, h, i0)
+    if cnn: m.set_cnn(cnn)
+    m.set_lamda(lam)
+    en = oracle_energy(J, h, i0, wt, cnn, lam)
+    idx = np.tile(wt, (n, 1))
+    for b in range(n):
+        pos = rng.choice(L, size=min(L, b % 23), replace=False); idx[b, pos] = rng.integers(0, 20, len(pos))
+    which = 3 if with_cnn else 1
+    print(f"trial {trial}: L={L} Lp={Lp} i0={i0} K={K} cnn={with_cnn} lam={lam} n={n}", flush=True)   # before the launch: a fault names its configuration
+    e, f, g = m.energy_grad(torch.as_tensor(idx).cuda(), which)
+    eo, fo, go = en.energy_grad(torch.as_tensor(idx.astype(np.int64)))
+    scale = abs(float(en.potts.wt_H)) + 1.0
+    de = np.abs(e.cpu().numpy() - eo.numpy()).max(); df = np.abs(f.cpu().numpy() - fo.numpy()).max(); dg = np.abs(g.cpu().numpy() - go.numpy()).max()
+    ok = de <= 2e-6 * 8 * (scale + np.abs(eo.numpy()).max()) + 1e-5 * lam and df <= 5e-6 and dg <= 2e-5 * max(1.0, lam)
+    bad += not ok
+    print(f"L={L} Lp={Lp} i0={i0} K={K} cnn={with_cnn} lam={lam} n={n}: de={de:.2e} df={df:.2e} dg={dg:.2e} {'ok' if ok else 'FAIL'}", flush=True)
+    m.close()
+print("failures:", bad)
+sys.exit(1 if bad else 0)

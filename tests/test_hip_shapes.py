@@ -52,11 +52,13 @@ def test_energy_grad_shapes(L, Lp, i0, with_cnn):
     assert np.abs(g.cpu().numpy() - go.numpy()).max() <= 2e-5 * max(1.0, lam)
 
 
-def test_cnn_other_kernel_size():
-    """kernel size 3 goes through the zero-padded 8-tap instantiation"""
-    m, wt, J, h, cnn = _model(50, 30, 10, True, 2.0, K=3)
+@pytest.mark.parametrize("L,K", [(50, 3), (150, 3), (278, 3), (120, 7)])
+def test_cnn_other_kernel_size(L, K):
+    """kernel sizes other than 5 go through the zero-padded 8-tap instantiation, single-launch and chunked
+    (278 x 3: found by scripts/fuzz_energy_grad.py, the forward chunk read letters of rows it had not staged)"""
+    m, wt, J, h, cnn = _model(L, 30, 10, True, 2.0, K=K)
     en = oracle_energy(J, h, 10, wt, cnn, 2.0)
-    idx = np.random.default_rng(0).integers(0, 20, (6, 50)).astype(np.uint8)
+    idx = np.random.default_rng(0).integers(0, 20, (6, L)).astype(np.uint8)
     e, f, g = m.energy_grad(torch.as_tensor(idx).cuda(), 2)
     fo, go = en.cnn.fit_grad(torch.as_tensor(idx.astype(np.int64)))
     assert np.abs(f.cpu().numpy() - fo.numpy()).max() <= 5e-6
