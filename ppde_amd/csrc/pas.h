@@ -498,9 +498,12 @@ __device__ __forceinline__ void propose_body(const PasArgs& a, const RowLds& lds
         // first barrier)
         const int old = lds.St[ls];
         const int wl = lds.Wt[ls];
-        // probability of the winner, recomputed by everyone exactly as its owner computed it (a drawn move is
-        // admissible, so its logit carries no mask)
-        const float zz = (G[win] - G[ls * 20 + old]) * 0.5f;
+        // probability of the winner, recomputed by everyone exactly as its owner computed it. The masks matter: a
+        // masked entry keeps probability 2^-23 after the clamp (ppde/utils.py:106-111), so it CAN win the race (about
+        // once per 10^4 draws with a narrow proposal range) and its forward log-probability is log(2^-23 / S3).
+        const bool outside = (ls < a.min_pos) | (ls > a.max_pos);
+        const bool masked = outside | (capped & !((old != wl) & (ks == wl)));
+        const float zz = masked ? -INFINITY : (G[win] - G[ls * 20 + old]) * 0.5f;
         const float pwin = clampp(expf((zz - lse) - mp) * inv);
         const float logp = logf(clampp(pwin / s3));   // Categorical.log_prob = log(clamp(p_hat))
 

@@ -568,6 +568,7 @@ int ppde_energy_grad(ppde_model* m, const uint8_t* idx_dev, int n, int which, fl
 // --------------------------------------------------------------------------------------------
 struct ppde_chains {
     ppde_model* m = nullptr;
+    int device = 0;                              // (kept here: destroy must not depend on the model still being alive)
     ppde_chain_config cfg{};
     hipStream_t stream = nullptr;                // == streams[0]
     std::vector<hipStream_t> streams;            // one per sub-population
@@ -712,7 +713,7 @@ int ppde_chains_create(ppde_chains** out, ppde_model* m, const ppde_chain_config
         if (rc0) return rc0;
     }
     ppde_chains* c = new ppde_chains();
-    c->m = m; c->cfg = *cfg; c->n = cfg->n_chains; c->T = cfg->max_steps; c->mu_max = 2 * cfg->pas_length - 1;
+    c->m = m; c->device = m->device; c->cfg = *cfg; c->n = cfg->n_chains; c->T = cfg->max_steps; c->mu_max = 2 * cfg->pas_length - 1;
     const Geom& g = m->g;
     const size_t n = c->n, T1 = (size_t)c->T + 1;
     const int nets = std::max(m->n_nets, 1);
@@ -764,7 +765,7 @@ int ppde_chains_create(ppde_chains** out, ppde_model* m, const ppde_chain_config
 
 int ppde_chains_destroy(ppde_chains* c) {
     if (!c) return PPDE_OK;
-    hipSetDevice(c->m->device);
+    hipSetDevice(c->device);
     for (hipStream_t st : c->streams) if (st) hipStreamSynchronize(st);
     if (c->graph_exec) hipGraphExecDestroy(c->graph_exec);
     if (c->graph) hipGraphDestroy(c->graph);

@@ -323,3 +323,37 @@ def test_long_replay_stays_on_the_oracle_trajectory():
     assert np.array_equal(res["best_idx"], ref["best_idx"].numpy())
     assert np.array_equal(res["random_traj"], ref["states"][:, 3].numpy())
     assert np.abs(res["energy_history"] - ref["energy_history"].numpy()).max() <= 5e-5
+
+
+def test_masked_entry_winning_the_race_keeps_the_clamp_probability():
+    """clamp_probs leaves every masked entry with probability 2^-23, so with a narrow proposal range a masked move wins
+    the exponential race now and then; its forward log-probability is log(2^-23 / sum), not that of its unmasked logit
+    (found by scripts/fuzz_sampler.py). Device RNG, oracle fed with the device's noise."""
+    from ppde_amd.energy import HipModel
+    from ppde_amd.sampler import Chains
+    from ppde_amd import synthetic
+    L, Lp, i0, n, T, pas, lo, hi = 64, 4, 49, 64, 40, 3, 29, 36
+    wt = np.random.default_rng(19).integers(0, 20, L).astype(np.uint8)
+    J, h = synthetic.make_potts(Lp, seed=19)
+    m = HipModel(wt, "cuda:0"); m.set_potts(J, h, i0); m.set_lamda(0.0)
+    ch = Chains(m, n, T, pas, 0, False, lo, hi, 1, 1, trace=True, random_chain=0, seed=1019, use_graph=False)
+    ch.init(torch.as_tensor(np.tile(wt, (n, 1))).cuda())
+    ch.run(T)
+    tr, res = ch.trace(), ch.collect()
+    noise = []
+    for t in range(T):
+        qs = [ch.philox_dump(t, s) for s in range(2 * pas - 1)]
+        noise.append((qs[-1][2].cpu().long(), torch.stack([q[0].cpu() for q in qs], 0), qs[-1][1].cpu()))
+    en = oracle_energy(J, h, i0, wt, None, 0.0)
+    ref = orc.run(en, np.tile(wt.astype(np.int64), (n, 1)), wt, lambda t: noise[t], T, lo, hi, pas, 0, False, trace=True)
+    outside = 0
+    for t in range(T):
+        U = noise[t][0].numpy()
+        for s in range(int(U.max())):
+            act = s < U
+            assert np.array_equal(tr["flat"][t, s][act], ref["traces"][t]["flat"][s].numpy()[act]), (t, s)
+            res_idx = tr["flat"][t, s][act] // 20
+            outside += int(((res_idx < lo) | (res_idx > hi)).sum())
+        assert np.allclose(tr["log_acc"][t], ref["traces"][t]["log_acc"].numpy(), atol=2e-4), t
+    assert np.array_equal(tr["accepted"].astype(bool), ref["accepted"].numpy())
+    assert outside >= 1, "the configuration no longer exercises a masked winner"
