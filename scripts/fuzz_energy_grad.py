@@ -46,10 +46,13 @@ for trial in range(40):
     idx = np.tile(wt, (n, 1))
     for b in range(n):
         pos = rng.choice(L, size=min(L, b % 23), replace=False); idx[b, pos] = rng.integers(0, 20, len(pos))
-    which = 3 if with_cnn else 1
-    print(f"trial {trial}: L={L} Lp={Lp} i0={i0} K={K} cnn={with_cnn} lam={lam} n={n}", flush=True)   # before the launch: a fault names its configuration
+    which = (3 if rng.integers(0, 4) else 2) if with_cnn else 1
+    print(f"trial {trial}: L={L} Lp={Lp} i0={i0} K={K} cnn={with_cnn} lam={lam} n={n} which={which}", flush=True)   # before the launch: a fault names its configuration
     e, f, g = m.energy_grad(torch.as_tensor(idx).cuda(), which)
     eo, fo, go = en.energy_grad(torch.as_tensor(idx.astype(np.int64)))
+    if which == 2:                                               # ProteinSupervised: e = fit, grad = d fit / dx
+        fo, go = en.cnn.fit_grad(torch.as_tensor(idx.astype(np.int64)))
+        eo, lam = fo, 1.0
     scale = abs(float(en.potts.wt_H)) + 1.0
     de = np.abs(e.cpu().numpy() - eo.numpy()).max(); df = np.abs(f.cpu().numpy() - fo.numpy()).max(); dg = np.abs(g.cpu().numpy() - go.numpy()).max()
     ok = de <= 2e-6 * 8 * (scale + np.abs(eo.numpy()).max()) + 1e-5 * lam and df <= 5e-6 and dg <= 2e-5 * max(1.0, lam)

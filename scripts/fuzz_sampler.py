@@ -21,9 +21,9 @@ bad = 0
 for trial in range(24):
     L = int(rng.integers(12, 260))
     Lp = int(rng.integers(4, L + 1)); i0 = int(rng.integers(0, L - Lp + 1))
-    with_cnn = bool(rng.integers(0, 3) == 0) and L <= 120      # (the CPU oracle's CNN is slow for long sequences)
+    with_cnn = bool(rng.integers(0, 3) == 0) and L <= 170      # (the CPU oracle's CNN is slow for long sequences)
     lam = float(rng.choice([0.5, 5.0])) if with_cnn else 0.0
-    n = int(rng.choice([1, 3, 8, 17])); T = int(rng.choice([6, 11, 23]))
+    n = int(rng.choice([1, 3, 8, 17, 70, 130])); T = int(rng.choice([6, 11, 23])) if n < 70 else 6
     pas = int(rng.choice([1, 2, 2, 3, 5])); nmut = int(rng.choice([0, 0, 2, 5])); paper = bool(rng.integers(0, 4) == 0)
     reuse = bool(rng.integers(0, 2)); graph = bool(rng.integers(0, 2))
     min_pos = int(rng.integers(0, L // 2)); max_pos = int(rng.integers(min_pos, L))
