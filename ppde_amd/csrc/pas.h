@@ -459,7 +459,7 @@ __device__ __forceinline__ void propose_body(const PasArgs& a, const RowLds& lds
         if (s + 1 < Ub) race_variates<GPT>(a, b, it, s + 1, qn);
         // ---- z - logsumexp -> softmax -> clamp (ppde/utils.py:106-111), exponential race argmax p / q, and the
         //      clamped row sum S3, in one pass + one barrier. Race values are >= 0, so their bit patterns order
-        //      like the floats: key = (bits << 32) | ~index picks the largest value, then the smallest index.
+        //      like the floats: key = (bits << 32) | (~index << 1 | masked) picks the largest value, then the smallest index.
         const float lse = logf(S1) + m;
         const float mp = m - lse;
         const float inv = 1.0f / S1;
@@ -473,10 +473,12 @@ __device__ __forceinline__ void propose_body(const PasArgs& a, const RowLds& lds
             p.x = clampp(expf((z[r].x - lse) - mp) * inv); p.y = clampp(expf((z[r].y - lse) - mp) * inv);
             p.z = clampp(expf((z[r].z - lse) - mp) * inv); p.w = clampp(expf((z[r].w - lse) - mp) * inv);
             s3 += p.x; s3 += p.y; s3 += p.z; s3 += p.w;
-            key = umax64(key, ((unsigned long long)__float_as_uint(p.x / q[r].x) << 32) | (0xffffffffu - (4 * g4 + 0)));
-            key = umax64(key, ((unsigned long long)__float_as_uint(p.y / q[r].y) << 32) | (0xffffffffu - (4 * g4 + 1)));
-            key = umax64(key, ((unsigned long long)__float_as_uint(p.z / q[r].z) << 32) | (0xffffffffu - (4 * g4 + 2)));
-            key = umax64(key, ((unsigned long long)__float_as_uint(p.w / q[r].w) << 32) | (0xffffffffu - (4 * g4 + 3)));
+            // low word: (2^31 - 1 - index) << 1 | [entry is masked]; the flag rides along for the winner's log-probability
+            const unsigned int lo0 = (0x7fffffffu - 4 * g4) << 1;
+            key = umax64(key, ((unsigned long long)__float_as_uint(p.x / q[r].x) << 32) | ((lo0 - 0) | (z[r].x == -INFINITY ? 1u : 0u)));
+            key = umax64(key, ((unsigned long long)__float_as_uint(p.y / q[r].y) << 32) | ((lo0 - 2) | (z[r].y == -INFINITY ? 1u : 0u)));
+            key = umax64(key, ((unsigned long long)__float_as_uint(p.z / q[r].z) << 32) | ((lo0 - 4) | (z[r].z == -INFINITY ? 1u : 0u)));
+            key = umax64(key, ((unsigned long long)__float_as_uint(p.w / q[r].w) << 32) | ((lo0 - 6) | (z[r].w == -INFINITY ? 1u : 0u)));
         }
         const float s3w = wave_sum(s3);
         key = wave_max_u64(key);
@@ -492,7 +494,8 @@ __device__ __forceinline__ void propose_body(const PasArgs& a, const RowLds& lds
             key = row8_max_u64(key);
         }
         PPDE_STAMP(a.dbg, 12 + 4 * min(s, 1), stamp);
-        const int win = min((int)(0xffffffffu - (unsigned int)key), g.N - 1);
+        const bool masked = ((unsigned int)key & 1u) != 0u;
+        const int win = min((int)(0x7fffffffu - ((unsigned int)key >> 1)), g.N - 1);
         const int ls = win / 20, ks = win - 20 * ls;
         // letter being replaced (lds.St follows the path: the previous move was applied behind this sub-step's
         // first barrier)
@@ -501,8 +504,7 @@ __device__ __forceinline__ void propose_body(const PasArgs& a, const RowLds& lds
         // probability of the winner, recomputed by everyone exactly as its owner computed it. The masks matter: a
         // masked entry keeps probability 2^-23 after the clamp (ppde/utils.py:106-111), so it CAN win the race (about
         // once per 10^4 draws with a narrow proposal range) and its forward log-probability is log(2^-23 / S3).
-        const bool outside = (ls < a.min_pos) | (ls > a.max_pos);
-        const bool masked = outside | (capped & !((old != wl) & (ks == wl)));
+        // (the owner's mask flag came with the key)
         const float zz = masked ? -INFINITY : (G[win] - G[ls * 20 + old]) * 0.5f;
         const float pwin = clampp(expf((zz - lse) - mp) * inv);
         const float logp = logf(clampp(pwin / s3));   // Categorical.log_prob = log(clamp(p_hat))
