@@ -30,7 +30,7 @@ def smallest_argmax_gap(cnn, rows):
 
 rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
 bad = 0
-for trial in range(40):
+for trial in range(int(os.environ.get("FZ_TRIALS", 40))):
     L = int(rng.integers(12, 280))
     Lp = int(rng.integers(4, L + 1)); i0 = int(rng.integers(0, L - Lp + 1))
     K = int(rng.choice([3, 5, 5, 5, 7])); K = min(K, L - 2)

@@ -18,7 +18,7 @@ from ppde_amd.sampler import Chains
 
 rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
 bad = 0
-for trial in range(24):
+for trial in range(int(os.environ.get("FZ_TRIALS", 24))):
     L = int(rng.integers(12, 260))
     Lp = int(rng.integers(4, L + 1)); i0 = int(rng.integers(0, L - Lp + 1))
     with_cnn = bool(rng.integers(0, 3) == 0) and L <= 170      # (the CPU oracle's CNN is slow for long sequences)
