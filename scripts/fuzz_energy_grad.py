@@ -31,8 +31,8 @@ def smallest_argmax_gap(cnn, rows):
 rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
 bad = 0
 for trial in range(int(os.environ.get("FZ_TRIALS", 40))):
-    L = int(rng.integers(12, 280))
-    Lp = int(rng.integers(4, L + 1)); i0 = int(rng.integers(0, L - Lp + 1))
+    L = int(rng.integers(5, 17)) if os.environ.get("FZ_SMALL") else int(rng.integers(12, 280))     # FZ_SMALL=1: edge sizes
+    Lp = int(rng.integers(1 if os.environ.get("FZ_SMALL") else 4, L + 1)); i0 = int(rng.integers(0, L - Lp + 1))
     K = int(rng.choice([3, 5, 5, 5, 7])); K = min(K, L - 2)
     with_cnn = bool(rng.integers(0, 2)); lam = float(rng.choice([0.5, 3.0, 15.0])) if with_cnn else 0.0
     n = int(rng.choice([1, 7, 64, 65, 130, 200]))

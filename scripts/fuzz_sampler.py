@@ -19,8 +19,8 @@ from ppde_amd.sampler import Chains
 rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
 bad = 0
 for trial in range(int(os.environ.get("FZ_TRIALS", 24))):
-    L = int(rng.integers(12, 260))
-    Lp = int(rng.integers(4, L + 1)); i0 = int(rng.integers(0, L - Lp + 1))
+    L = int(rng.integers(5, 17)) if os.environ.get("FZ_SMALL") else int(rng.integers(12, 260))     # FZ_SMALL=1: edge sizes
+    Lp = int(rng.integers(1 if os.environ.get("FZ_SMALL") else 4, L + 1)); i0 = int(rng.integers(0, L - Lp + 1))
     with_cnn = bool(rng.integers(0, 3) == 0) and L <= 170      # (the CPU oracle's CNN is slow for long sequences)
     lam = float(rng.choice([0.5, 5.0])) if with_cnn else 0.0
     n = int(rng.choice([1, 3, 8, 17, 70, 130])); T = int(rng.choice([6, 11, 23])) if n < 70 else 6
