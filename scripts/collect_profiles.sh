@@ -19,3 +19,5 @@ for c in FETCH_SIZE WRITE_SIZE; do
 done
 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_WAIT_ANY SQ_ACTIVE_INST_ANY --kernel-trace --output-format csv -d "$OUT/prof_SQ" -- python3 "$ROOT/bench.py" --steps 300 --warmup 50 --no-cpu-baseline > "$OUT/prof_SQ.log" 2>&1
 echo "SQ done"
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVES --kernel-trace --output-format csv -d "$OUT/prof_MFMA" -- python3 "$ROOT/bench.py" --workload potts+cnn --steps 200 --warmup 30 --no-cpu-baseline > "$OUT/prof_MFMA.log" 2>&1
+echo "MFMA (config 3) done"

@@ -34,6 +34,7 @@ def main():
     ap.add_argument("--fetch")
     ap.add_argument("--write")
     ap.add_argument("--sq")
+    ap.add_argument("--mfma", help="dir of a --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVES pass")
     a = ap.parse_args()
     os.makedirs(OUT, exist_ok=True)
     if a.stats:
@@ -41,11 +42,11 @@ def main():
         shutil.copy(f, os.path.join(OUT, f"{a.tag}_kernel_stats.csv"))
     lines = [f"# rocprofv3 PMC summary ({a.tag})", ""]
     vals = {}
-    for name, d in (("FETCH_SIZE", a.fetch), ("WRITE_SIZE", a.write), ("SQ", a.sq)):
+    for name, d in (("FETCH_SIZE", a.fetch), ("WRITE_SIZE", a.write), ("SQ", a.sq), ("MFMA", a.mfma)):
         if not d:
             continue
         g = counters(d)
-        g = g[g["kernel"].str.contains("potts_energy_grad|k_propose|k_accept|k_cnn")]
+        g = g[g["kernel"].str.contains("potts_energy_grad|k_propose|k_accept|k_cnn|k_experts")]
         lines += [f"## pass: {name}", "", "| kernel | counter | mean per launch | launches |", "|---|---|---|---|"]
         for _, r in g.iterrows():
             lines.append(f"| {r['kernel']} | {r['Counter_Name']} | {r['mean']:.1f} | {int(r['count'])} |")
@@ -59,6 +60,11 @@ def main():
                    "hbm_bytes_per_launch": hbm, "source": a.tag}, open(os.path.join(OUT, "potts_pmc.json"), "w"), indent=1)
         lines += [f"Potts kernel HBM-side traffic per launch = (2 x {vals['FETCH_SIZE']:.0f} + {vals['WRITE_SIZE']:.0f}) KiB "
                   f"= {hbm / 1e6:.2f} MB", ""]
+    if a.mfma:
+        lines += ["Reading the MFMA pass: SQ_VALU_MFMA_BUSY_CYCLES sums, over all SIMDs, the cycles the matrix pipe is busy;",
+                  "one v_mfma_f32_16x16x4_f32 occupies it for 32 cycles, so busy / 32 = MFMA instructions issued per launch",
+                  "(k_cnn at 128 chains x 3 networks: 384 x (1728 + 1008) = 1 050 624). Divided by 1024 SIMDs and by the",
+                  "kernel's duration in cycles it is the matrix-pipe utilisation averaged over the chip.", ""]
     open(os.path.join(OUT, f"{a.tag}_pmc.md"), "w").write("\n".join(lines))
     print("\n".join(lines))
 
