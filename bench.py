@@ -2,29 +2,42 @@
 """Benchmark of the PPDE hot path: MCMC steps/sec on synthetic PABP_YEAST-shaped inputs (BASELINE.json).
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
+
+With --gpus N > 1 and no RANK in the environment this process only LAUNCHES the ranks (a child
+`python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py <same arguments>`; the parent never
+touches the GPU) and relays rank 0's JSON line. Launched by torchrun it is one rank:
+
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
 One "step" = one path-auxiliary MCMC iteration (reference ppde/protein_samplers/ppde.py:65-153) over the
-128 chains a GPU holds. Workload = BASELINE.json configs[1]: PABP_YEAST Potts product of experts, L=96, L'=80,
+chains a GPU holds. Workload = BASELINE.json configs[1]: PABP_YEAST Potts product of experts, L=96, L'=80,
 A=20, 128 chains per GPU (weak scaling: every rank runs its own 128 independent chains, no data-path
 collective; the only collective is the final population gather, outside the timed region like the reference's
-own post-processing). Inputs are synthetic (seeded couplings, all chains start at the wild type) and resident in
-HBM before the timed region. Rank 0 prints ONE JSON line.
+own post-processing, and timed separately as `population_gather_ms`). `--protein GFP --gpus 8` is BASELINE
+configs[3] (1024 chains over 8 GPUs). Inputs are synthetic (seeded couplings, all chains start at the wild
+type) and resident in HBM before the timed region. Rank 0 prints ONE JSON line.
+
+Timing: W warm-up steps, then `--repeats` blocks of EXACTLY K steps, each block bracketed by barrier +
+synchronize on both sides and reduced with MAX over ranks; `value` is computed from the MEDIAN block. Every
+iteration of a block is replayed from hipGraphs captured by ppde_chains_init (never inside the timed region:
+`graph_captured_in_timed_region` comes from a counter in the library).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 import numpy as np
-import torch
 
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
-HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+MFMA_BF16_PEAK_TF = 2500.0   # dense bf16/f16 MFMA peak (MI355X_MICROARCH.md)
 
 
 def parse():
@@ -32,21 +45,42 @@ def parse():
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=2000)
     p.add_argument("--warmup", type=int, default=200)
+    p.add_argument("--repeats", type=int, default=5, help="timed blocks of --steps iterations; the median is reported")
     p.add_argument("--chains", type=int, default=128, help="chains per GPU")
-    p.add_argument("--workload", default="potts", choices=["potts", "potts+cnn"],
-                   help="potts = BASELINE configs[1] (Potts-only PoE); potts+cnn = configs[2] (lamda=5)")
+    p.add_argument("--workload", default="potts", choices=["potts", "potts+cnn", "transformer"],
+                   help="potts = BASELINE configs[1] (Potts-only PoE); potts+cnn = configs[2] (lamda=5); "
+                        "transformer = configs[4] (ESM2-style unsupervised expert + supervised CNN, UBE4B, 256 chains)")
     p.add_argument("--protein", default="PABP", choices=["PABP", "UBE4B", "GFP"],
-                   help="PABP = the configuration BASELINE.json's metric is quoted on; the others are auxiliary measurements")
+                   help="PABP = the configuration BASELINE.json's metric is quoted on; GFP at --gpus 8 = configs[3]")
     p.add_argument("--reuse-grad", type=int, default=0,
                    help="0 (default): evaluate energy+gradient twice per step exactly as the reference does; "
                         "1: carry the current state's gradient over (bit-identical results, half the expert calls)")
     p.add_argument("--nmut", type=int, default=0)
     p.add_argument("--pas", type=int, default=2, help="ppde_pas_length (reference default 2)")
     p.add_argument("--streams", type=int, default=1, help="sub-populations run on separate HIP streams")
-    p.add_argument("--graph", type=int, default=1, help="replay iterations from a captured hipGraph")
+    p.add_argument("--graph", type=int, default=1, help="replay iterations from hipGraphs captured at init")
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--no-large", action="store_true", help="skip the GFP-sized Potts kernel timing (roofline_large)")
     p.add_argument("--cpu-seconds", type=float, default=15.0)
+    p.add_argument("--tf-layers", type=int, default=30)
+    p.add_argument("--tf-dim", type=int, default=640)
+    p.add_argument("--tf-heads", type=int, default=20)
+    p.add_argument("--tf-ffn", type=int, default=2560)
     return p.parse_args()
+
+
+def launch_ranks(args):
+    """Parent of a multi-GPU run: start the ranks as a child process and relay its output. Nothing here touches
+    the GPU (no torch.cuda call, no HIP call), so the child ranks are the only processes on the cards."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    return subprocess.run(cmd, env=env).returncode
 
 
 def build_model(workload, device, protein="PABP"):
@@ -67,8 +101,29 @@ def build_model(workload, device, protein="PABP"):
     return m, wt, J, h, i0, Lp, cnn
 
 
+def potts_alg_bytes(n, L, Lp):
+    """couplings + fields + uint8 states + gradient rows + (e, fit)."""
+    return 4 * (Lp * 20) ** 2 + 4 * Lp * 20 + n * Lp + 4 * n * L * 20 + 8 * n
+
+
+def load_traffic(key):
+    """PMC traffic per launch of the Potts kernel as collected by scripts/collect_profiles.sh (separate rocprofv3
+    --pmc passes, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes). This run does not measure it: counters
+    cannot be read from inside the process."""
+    pmc = os.path.join(REPO, "profiles", "potts_pmc.json")
+    try:
+        d = json.load(open(pmc))
+    except Exception:
+        return None, None
+    ent = d.get(key) if isinstance(d.get(key), dict) else (d if key == "PABP" else None)
+    if not ent:
+        return None, None
+    return ent.get("hbm_bytes_per_launch"), f"profiles/potts_pmc.json[{key}] ({ent.get('collected', 'earlier rocprofv3 --pmc passes')}); a constant read from that file, not measured by this run"
+
+
 def cpu_baseline(args, wt, J, h, i0, Lp, cnn, n):
     """The oracle (torch-CPU restatement, pinned to the reference by tests/golden) on this box's host cores."""
+    import torch
     sys.path.insert(0, os.path.join(REPO, "oracle"))
     import ppde_oracle as orc
     cores = min(os.cpu_count() or 1, 16)      # a 1-GPU box's CPU share; torch's intra-op pool beyond that only adds overhead
@@ -93,19 +148,31 @@ def cpu_baseline(args, wt, J, h, i0, Lp, cnn, n):
     t_probe = timed(3)
     T = int(max(5, min(2000, args.cpu_seconds / max(t_probe / 3, 1e-4))))
     dt = timed(T)
+    note = ("" if cnn is not None else
+            " The supervised CNN is SKIPPED here (lamda = 0): the reference with --energy_lamda 0 would still run its CNN "
+            "forward + backward (energy.py:104-108), so this port does less work than the reference would and the "
+            "GPU/CPU ratio is conservative; the reference itself measured 9.1-9.6 steps/s on 8 cores (BASELINE.md).")
     return {"value": T / dt, "unit": "MCMC steps/s", "cores": int(torch.get_num_threads()), "kind": "port",
             "sample": f"{T} iterations of the same workload ({n} chains, pas_length {args.pas}, noise drawn with torch's CPU "
-                      f"generator as the reference does) through oracle/ppde_oracle.py; {dt:.1f} s"}
+                      f"generator as the reference does) through oracle/ppde_oracle.py; {dt:.1f} s." + note}
 
 
 def main():
     args = parse()
+    if args.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(launch_ranks(args))
+    import torch
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: refusing to report a value for a different rank count")
     backend = os.environ.get("PPDE_BENCH_BACKEND", "nccl")          # "gloo" + PPDE_BENCH_ONE_GPU=1: rehearse N ranks on one card
     if os.environ.get("PPDE_BENCH_ONE_GPU"):
         local = 0
+    if args.workload == "transformer":
+        import bench_transformer
+        return bench_transformer.main(args, rank, world, local, backend)
     if world > 1:
         import torch.distributed as dist
         torch.cuda.set_device(local)
@@ -118,38 +185,45 @@ def main():
     torch.cuda.set_device(local)
 
     from ppde_amd.sampler import Chains
+    from ppde_amd.parallel import all_gather_rows
     m, wt, J, h, i0, Lp, cnn = build_model(args.workload, device, args.protein)
     n, L = args.chains, wt.shape[0]
     which = 3 if args.workload == "potts+cnn" else 1
     IN_SITU = 200
-    T = args.warmup + args.steps + IN_SITU
+    T = args.warmup + args.repeats * args.steps + IN_SITU
 
     def barrier():
         if world > 1:
             torch.distributed.barrier()
 
-    def timed_run(reuse):
+    def timed_run(reuse, repeats):
         ch = Chains(m, n, T, args.pas, args.nmut, False, i0, i0 + Lp - 1, which, 1, reuse_grad=reuse,
                     random_chain=0, use_graph=bool(args.graph), seed=1, chain_offset=rank * n, n_streams=args.streams)
-        ch.init(torch.as_tensor(np.tile(wt, (n, 1))).to(device))
+        ch.init(torch.as_tensor(np.tile(wt, (n, 1))).to(device))       # (captures the hipGraphs)
         ch.run(args.warmup)
         ch.sync()
-        torch.cuda.synchronize()
-        barrier()
-        t0 = time.perf_counter()
-        ch.run(args.steps)
-        ch.sync()
-        torch.cuda.synchronize()
-        barrier()
-        dt = time.perf_counter() - t0
-        if world > 1:
-            t = torch.tensor([dt], device=device if backend == "nccl" else "cpu", dtype=torch.float64)
-            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-            dt = float(t.item())
-        return ch, dt
+        dts = []
+        for _ in range(repeats):
+            torch.cuda.synchronize()
+            barrier()
+            t0 = time.perf_counter()
+            ch.run(args.steps)
+            ch.sync()
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            barrier()
+            if world > 1:
+                t = torch.tensor([dt], device=device if backend == "nccl" else "cpu", dtype=torch.float64)
+                torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+                dt = float(t.item())
+            dts.append(dt)
+        return ch, dts
 
-    ch, dt = timed_run(bool(args.reuse_grad))
-    ch_other, dt_other = timed_run(not bool(args.reuse_grad))      # the other evaluation policy, for the record
+    ch, dts = timed_run(bool(args.reuse_grad), args.repeats)
+    dt = float(np.median(dts))
+    stats = ch.graph_stats()
+    ch_other, dts_other = timed_run(not bool(args.reuse_grad), min(args.repeats, 3))   # the other evaluation policy, for the record
+    dt_other = float(np.median(dts_other))
     del ch_other
 
     # dominant kernel: potts_energy_grad, timed live with HIP events on the stream it is launched on: 500 launches
@@ -158,22 +232,52 @@ def main():
     # real, eagerly launched iterations; that figure includes the two event packets themselves.
     pk_situ_us, pk_launches = ch.time_potts_in_situ(IN_SITU)
     pk_us = ch.time_potts_kernel(500)
-    alg_bytes = 4 * (Lp * 20) ** 2 + 4 * Lp * 20 + n * Lp + 4 * n * L * 20 + 8 * n
+    alg_bytes = potts_alg_bytes(n, L, Lp)
     achieved = alg_bytes / (pk_us * 1e-6) / 1e9
-    traffic = None
-    pmc = os.path.join(REPO, "profiles", "potts_pmc.json")
-    if os.path.exists(pmc):
-        try:
-            traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
-        except Exception:
-            traffic = None
+    traffic, traffic_source = load_traffic(args.protein)
 
     res = ch.collect()
     assert np.isfinite(res["energy_history"]).all()
 
+    # final population collect: one all_gather of best states / energies / histories, outside the
+    # timed region, timed on its own
+    gather_ms, rccl_ranks = None, None
+    if world > 1:
+        ones = torch.ones(1, device=device if backend == "nccl" else "cpu")
+        torch.distributed.all_reduce(ones)
+        rccl_ranks = int(ones.item())
+        torch.cuda.synchronize()
+        barrier()
+        t0 = time.perf_counter()
+        g_best = all_gather_rows(torch.from_numpy(res["best_idx"]), n * world)
+        g_e = all_gather_rows(torch.from_numpy(res["best_energy"]), n * world)
+        g_hist = all_gather_rows(torch.from_numpy(res["energy_history"]), n * world, dim=1)
+        torch.cuda.synchronize()
+        gather_ms = (time.perf_counter() - t0) * 1e3
+        assert g_best.shape[0] == n * world and g_e.shape[0] == n * world and g_hist.shape[1] == n * world
+
+    # second roofline entry at the size where the HBM target is reachable: the GFP window (L' = 237, 90 MB of couplings)
+    roofline_large = None
+    if rank == 0 and world == 1 and args.protein == "PABP" and not args.no_large:
+        del ch
+        mg, wtg, _, _, i0g, Lpg, _ = build_model("potts", device, "GFP")
+        chg = Chains(mg, n, 4, args.pas, 0, False, i0g, i0g + Lpg - 1, 1, 1, reuse_grad=False, random_chain=0,
+                     use_graph=False, seed=1)
+        chg.init(torch.as_tensor(np.tile(wtg, (n, 1))).to(device))
+        chg.time_potts_kernel(50)
+        us = chg.time_potts_kernel(300)
+        ab = potts_alg_bytes(n, wtg.shape[0], Lpg)
+        tr, trs = load_traffic("GFP")
+        roofline_large = {"kernel": "potts_energy_grad_kernel (ring variant)", "workload": f"GFP_AEQVI window L'={Lpg}, {n} chains",
+                          "bound": "hbm", "achieved": ab / (us * 1e-6) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                          "frac": ab / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, "traffic": tr, "traffic_source": trs,
+                          "algorithmic_bytes_per_launch": ab, "avg_launch_us": us, "launches_timed": 300}
+        del chg, mg
+
     if rank == 0:
+        pname = {"PABP": "PABP_YEAST", "UBE4B": "UBE4B_MOUSE", "GFP": "GFP_AEQVI"}[args.protein]
         out = {
-            "metric": "MCMC steps/sec (128 chains, PABP Potts PoE)" if args.protein == "PABP" else f"MCMC steps/sec ({n} chains, {args.protein} Potts PoE)",
+            "metric": "MCMC steps/sec (128 chains, PABP Potts PoE)" if args.protein == "PABP" else f"MCMC steps/sec ({n} chains/GPU, {args.protein} Potts PoE)",
             "value": world * args.steps / dt,
             "unit": "steps/s",
             "n_gpus": world,
@@ -185,19 +289,30 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": {"PABP": "PABP_YEAST", "UBE4B": "UBE4B_MOUSE", "GFP": "GFP_AEQVI"}[args.protein]
-                                   + " Potts product of experts" + (" + supervised CNN (lamda=5)" if cnn else "")
+            "config": {"workload": pname + " Potts product of experts" + (" + supervised CNN (lamda=5)" if cnn else "")
                                    + f", L={L}, L'={Lp}, A=20, {n} chains/GPU, pas_length={args.pas}, nmut_threshold={args.nmut}, "
                                      "device Philox RNG, all chains start at WT",
                        "chains_per_gpu": n, "total_chains": n * world, "parallelism": f"chains sharded x{world}, no per-step collective",
                        "energy_evaluations_per_step": 1 if args.reuse_grad else 2, "hip_streams": args.streams},
             "chain_steps_per_s": world * n * args.steps / dt,
+            "timed_blocks": {"repeats": len(dts), "statistic": "median", "ms_per_block": [round(x * 1e3, 4) for x in dts]},
+            "graph_captured_in_timed_region": bool(stats["captures_in_run"]),
+            "graph": stats,
             "roofline": {"kernel": "potts_energy_grad_kernel", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
+                         "traffic_note": "FETCH_SIZE/WRITE_SIZE count L2<->fabric requests: at this size the couplings stay "
+                                         "resident in the 256 MB Infinity Cache (MALL) between launches, so this is fabric "
+                                         "traffic, not DRAM traffic",
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_us": pk_us, "launches_timed": 500,
                          "avg_launch_us_event_pair_per_launch_in_situ": pk_situ_us},
             ("value_reuse_grad" if not args.reuse_grad else "value_reevaluate"): world * args.steps / dt_other,
         }
+        if roofline_large:
+            out["roofline_large"] = roofline_large
+        if world > 1:
+            out["rccl_ranks"] = rccl_ranks
+            out["backend"] = backend
+            out["population_gather_ms"] = gather_ms
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, wt, J, h, i0, Lp, cnn, n)
         print(json.dumps(out), flush=True)

@@ -17,7 +17,20 @@
  *   - states are residue indices, one byte per residue (alphabet ACDEFGHIKLMNPQRSTVWY -> 0..19,
  *     ppde/third_party/hsu/data_utils.py:48-70); fp32 one-hot [n, L, 20] exists only at the API edge;
  *   - a ppde_model is immutable after its set_* calls and may be shared by several ppde_chains; a
- *     ppde_chains owns one HIP stream and is not thread-safe.
+ *     ppde_chains owns one HIP stream (and every scratch buffer its kernels and captured graphs touch)
+ *     and is not thread-safe; the stateless calls (ppde_energy_grad ...) share one scratch set per model
+ *     and must not run concurrently with each other on the same model.
+ *
+ * Shape limits (checked; violations return PPDE_ERR_INVALID with a message, nothing falls back):
+ *   - alphabet 20; sequence length 5 <= L <= 4096 for the model, L <= 307 for ppde_chains (a chain's
+ *     L*20 proposal logits live in the registers of one 512-thread workgroup);
+ *   - state rows (L + alignment padding) <= 512 bytes for the Potts kernel, i.e. L <= ~500;
+ *   - Potts window 1 <= Lp <= L; windows of more than 128 residues stream through an LDS ring
+ *     (no upper bound besides the state-row limit), shorter ones keep a resident slab of <= 32 KiB
+ *     pieces per wave;
+ *   - supervised expert: 1..4 networks of one shape, kernel size 1..8, embedding width F <= 512
+ *     for the single-launch kernel (wider or longer networks take the chunked kernels);
+ *   - ppde_pas_length 1..64; chain_offset + n_chains < 2^32.
  */
 #ifndef PPDE_HIP_H
 #define PPDE_HIP_H
@@ -114,7 +127,7 @@ typedef struct {
                                 --device cpu aliasing artefact); 0 = pre-reset (its cuda behaviour) */
     int32_t trace;           /* 1 = keep per-iteration draws / accept bits / log-acceptance for tests */
     int32_t random_chain;    /* local index of the chain whose trajectory is kept (ppde.py:37,47,142), or -1 */
-    int32_t use_graph;       /* 1 = replay iterations from a captured hipGraph (rng_mode 1 only) */
+    int32_t use_graph;       /* 1 = replay iterations from hipGraphs captured at ppde_chains_init (rng_mode 1 only) */
     int32_t n_streams;       /* >1: the chains are cut into this many sub-populations whose iterations run on
                                 separate HIP streams and overlap on the GPU (chains are independent, results
                                 are unchanged); 0/1 = one stream. rng_mode 1 only. */
@@ -150,6 +163,13 @@ int ppde_chains_peek(ppde_chains* c, uint8_t* idx, float* energy, float* fitness
  * histories [steps_done+1, n], random trajectory [steps_done+1, L]. Any pointer may be NULL. Synchronises. */
 int ppde_chains_collect(ppde_chains* c, uint8_t* best_idx, float* best_energy, float* best_fitness,
                         int32_t* best_step, float* energy_history, float* fitness_history, uint8_t* random_traj);
+
+/* hipGraph bookkeeping for bench.py: graphs are captured and instantiated by ppde_chains_init (segments of
+ * 100 and 20 iterations when max_steps allows, or PPDE_GRAPH_LEN), never inside ppde_chains_run;
+ * captures_in_run counts violations of that (always 0), replayed/eager_steps say how the iterations of all runs
+ * so far were issued. Any pointer may be NULL. */
+int ppde_chains_graph_stats(ppde_chains* c, int32_t* captures, int32_t* captures_in_run,
+                            int64_t* replayed_steps, int64_t* eager_steps);
 
 /* Trace buffers (cfg.trace = 1): flat host int32 [steps_done, 2*pas-1, n] (-1 = not drawn),
  * accepted host uint8 [steps_done, n], log_acc host fp32 [steps_done, n], U host int32 [steps_done, n]. */

@@ -11,6 +11,7 @@ Gibbs-with-gradients / path-auxiliary sampler inner loop and the energy evaluati
   CnnOracle.fit_grad          <- ppde/nets.py:363-376 (OnehotCNN.forward), :434-442 (EnsembleProtein.__call__)
                                  + autograd of it at ppde/energy.py:108
   EnergyOracle.energy_grad    <- ppde/energy.py:97-108,132 (ProteinProductOfExperts.get_energy[_and_grads], potts branch)
+  AlrOracle.__call__          <- ppde/nets.py:332-347 (AugmentedLinearRegression.forward, the ground-truth model)
   categorical_probs           <- ppde/utils.py:106-111 (safe_logits_to_probs) followed by
                                  torch.distributions.Categorical.__init__ (probs / probs.sum)
   race_sample                 <- torch.multinomial(p, 1) == argmax(p / q), q ~ Exp(1)  (Categorical.sample)
@@ -159,6 +160,28 @@ class EnergyOracle:
 
 # --------------------------------------------------------------------------------------------------
 # categorical machinery
+class AlrOracle:
+    """Ground-truth fitness (ppde/nets.py:315-347): mean over the ridge models k of
+    W_k . [ sqrt(1/r_ev) * Delta-H(x),  sqrt(1/r_k) * x_flat ] + b_k,  r_ev = potts reg_coef, in the reference's
+    operation order (elementwise product, row sum, stack, mean)."""
+
+    def __init__(self, potts, linear, reg_ev=1.0):
+        """linear: list of (coef_ [1 + L*A], intercept_, reg_coef) as stored in the *-linear.pkl files."""
+        self.potts = potts
+        self.reg_ev = float(reg_ev)
+        self.lin = [(torch.as_tensor(np.asarray(c)).float(), torch.tensor([float(b)], dtype=torch.float32), float(r))
+                    for c, b, r in linear]
+
+    def __call__(self, idx):
+        dH, _ = self.potts.energy_grad(idx)
+        x = onehot(idx).reshape(idx.shape[0], -1)
+        y = []
+        for W, b, r in self.lin:
+            xi = torch.cat((math.sqrt(1 / self.reg_ev) * dH[..., None], math.sqrt(1 / r) * x), 1)
+            y.append((W * xi).sum(1) + b)
+        return torch.stack(y, 0).mean(0)
+
+
 # --------------------------------------------------------------------------------------------------
 def categorical_probs(z):
     """Rows of logits (may hold -inf) -> the probability vector torch's Categorical ends up sampling from.

@@ -22,6 +22,7 @@ struct PasArgs {
     int which;                  // bit0 Potts, bit1 CNN
     // sampler configuration
     int pas, thr, paper, min_pos, max_pos, rng_mode, reuse, rec_after_reset, random_chain, mu_max;
+    int mu_cap;                 // sub-steps the supplied noise of this iteration covers (rng_mode 0: max_u[it]; else mu_max)
     RngKey key;
     const int* it_base;         // device iteration base (graph replay) or NULL
     int it_local;
@@ -409,6 +410,7 @@ __device__ __forceinline__ void race_variates(const PasArgs& a, int b, int it, i
 template <int GPT>
 struct ProposePrefetch {
     int Ub;
+    int Uraw;                   // path length as drawn / supplied, before the clamp
     int dist;                   // mutation count of the current state (from the chain record)
     float4 q0[GPT];
 };
@@ -417,7 +419,8 @@ __device__ __forceinline__ ProposePrefetch<GPT> propose_prefetch(const PasArgs& 
     ProposePrefetch<GPT> p;
     if (a.rng_mode == 0) p.Ub = a.U_in[b + opaque_zero()];
     else p.Ub = pathlen_from_bits(philox4x32_10(U4{a.key.chain_lo + (uint32_t)b, (uint32_t)it, 0u, 0u}, a.key.k0, a.key.k1).x, a.pas);
-    p.Ub = min(max(p.Ub, 1), a.mu_max);
+    p.Uraw = p.Ub;
+    p.Ub = min(max(p.Ub, 1), min(a.mu_max, a.mu_cap));
     p.dist = rec_of(a, b + opaque_zero())->dist_cur;
     race_variates<GPT>(a, b, it, 0, p.q0);
     return p;
@@ -434,6 +437,8 @@ __device__ __forceinline__ void propose_body(const PasArgs& a, const RowLds& lds
     const int tid = threadIdx.x, lane = tid & 63;
     const float* G = (const float*)lds.G;
     const int Ub = __builtin_amdgcn_readfirstlane(pp.Ub);
+    // a supplied path length beyond the supplied noise block (rng_mode 0): flagged, never read past the block
+    if (tid == 0 && pp.Uraw > a.mu_cap) atomicOr(a.err_flag, 2);
     float4 q[GPT];
 #pragma unroll
     for (int r = 0; r < GPT; ++r) q[r] = pp.q0[r];

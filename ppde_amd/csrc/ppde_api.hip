@@ -39,6 +39,21 @@ static hipError_t dalloc(T** p, size_t count) {
     return hipMalloc((void**)p, count * sizeof(T));
 }
 
+// Scope guards for the temporaries of the host layer: every early return (HIPCHK / ARGCHK) releases them.
+struct DevTmp {
+    void* p = nullptr;
+    DevTmp() = default;
+    DevTmp(const DevTmp&) = delete;
+    DevTmp& operator=(const DevTmp&) = delete;
+    ~DevTmp() { if (p) hipFree(p); }
+    template <typename T> hipError_t alloc(size_t count) { T* q = nullptr; hipError_t e = dalloc(&q, count); p = q; return e; }
+    template <typename T> T* as() const { return (T*)p; }
+};
+struct EventPair {
+    hipEvent_t a = nullptr, b = nullptr;
+    ~EventPair() { if (a) hipEventDestroy(a); if (b) hipEventDestroy(b); }
+};
+
 // --------------------------------------------------------------------------------------------
 struct ppde_model {
     int device = 0;
@@ -105,6 +120,13 @@ struct EvalTargets {
     float* fitC;      // [slots][nets][n]
     int slot;
     unsigned long long* dbg = nullptr;
+    // chunk maxima / arg-max rows / ReLU gate bits of the long-sequence CNN path. They belong to whoever owns the
+    // slot buffers (one set per ppde_chains, one for the stateless API), never to the model: a captured hipGraph
+    // has these pointers baked into its kernel arguments, and two owners run on different streams.
+    float* cmax = nullptr;
+    int* carg = nullptr;
+    uint32_t* cgate = nullptr;
+    int cnn_cap = 0;          // chains the chunk scratch is sized for
 };
 
 // chain groups (of 64) per Potts workgroup. Measured at 256 / 512 / 1024 chains: 4 groups 7.1 / 11.3 / 18.7 us,
@@ -116,6 +138,7 @@ static int potts_ng_for(int n) { return n <= 64 ? 1 : n <= 128 ? 2 : 4; }
 struct EventPool {
     std::vector<hipEvent_t> ev;
     size_t used = 0;
+    ~EventPool() { for (hipEvent_t e : ev) if (e) hipEventDestroy(e); }
 };
 static thread_local EventPool* g_potts_events = nullptr;
 
@@ -171,13 +194,18 @@ static bool cnn_single_launch(const ppde_model* m) {
     return 2 * lds <= 160 * 1024 || chunked_override == 0;
 }
 
+static size_t cnn_chunk_max_count(const ppde_model* m, int n) { return (size_t)m->n_nets * n * cnn_fwd_chunks(m->T) * m->FP; }
+static size_t cnn_chunk_gate_count(const ppde_model* m, int n) {
+    return (size_t)m->n_nets * n * cnn_fwd_chunks(m->T) * CNN_FCH_RT * 16 * ((m->CP + 31) / 32);
+}
+// chunk scratch of the STATELESS API only (ppde_energy_grad); every ppde_chains owns its own (ppde_chains_create)
 static int ensure_cnn_scratch(ppde_model* m, int n) {
     if (cnn_single_launch(m) || n <= m->cnn_scratch_n) return PPDE_OK;
     hipFree(m->cnn_cmax); hipFree(m->cnn_carg); hipFree(m->cnn_cgate);
-    const size_t cnt = (size_t)m->n_nets * n * cnn_fwd_chunks(m->T) * m->FP;
-    HIPCHK(dalloc(&m->cnn_cmax, cnt));
-    HIPCHK(dalloc(&m->cnn_carg, cnt));
-    HIPCHK(dalloc(&m->cnn_cgate, (size_t)m->n_nets * n * cnn_fwd_chunks(m->T) * CNN_FCH_RT * 16 * ((m->CP + 31) / 32)));
+    m->cnn_cmax = nullptr; m->cnn_carg = nullptr; m->cnn_cgate = nullptr; m->cnn_scratch_n = 0;
+    HIPCHK(dalloc(&m->cnn_cmax, cnn_chunk_max_count(m, n)));
+    HIPCHK(dalloc(&m->cnn_carg, cnn_chunk_max_count(m, n)));
+    HIPCHK(dalloc(&m->cnn_cgate, cnn_chunk_gate_count(m, n)));
     m->cnn_scratch_n = n;
     return PPDE_OK;
 }
@@ -194,10 +222,10 @@ static int launch_cnn(const ppde_model* m, const uint8_t* states, int n, const E
     a.g = m->g;
     if (!cnn_single_launch(m)) {
         // long sequences: forward chunks, then merge + backward chunks
-        ARGCHK(m->cnn_scratch_n >= n, "CNN chunk scratch not allocated for this batch size");
+        ARGCHK(t.cmax && t.carg && t.cgate && t.cnn_cap >= n, "CNN chunk scratch not allocated for this batch size");
         ARGCHK(cnn_fwd_chunk_lds(m->CP) <= 160 * 1024 && cnn_bwd_chunk_lds(m->CP, m->FP, m->J) <= 160 * 1024,
                "sequence too long for the chunked CNN kernels");
-        CnnChunkArgs ca{a, m->cnn_cmax, m->cnn_carg, m->cnn_cgate, cnn_fwd_chunks(m->T)};
+        CnnChunkArgs ca{a, t.cmax, t.carg, t.cgate, cnn_fwd_chunks(m->T)};
         const dim3 gf(n_sub, m->n_nets, ca.NCH), gb(n_sub, m->n_nets, want_grad ? cnn_bwd_chunks(m->L, m->KT) : 1);
         if (m->KT == 5) {
             hipLaunchKernelGGL(k_cnn_fwd_chunk<5>, gf, dim3(256), cnn_fwd_chunk_lds(m->CP), s, ca);
@@ -383,32 +411,31 @@ int ppde_model_set_potts(ppde_model* m, const float* J, const float* h, int Lp, 
     if (rc) return rc;
     const Geom& g = m->g;
     const size_t nJ = (size_t)Lp * Lp * 400;
-    float* d_raw = nullptr;
-    HIPCHK(dalloc(&d_raw, nJ));
-    HIPCHK(hipMemcpy(d_raw, J, nJ * sizeof(float), hipMemcpyHostToDevice));
-    if (m->d_Jt) hipFree(m->d_Jt);
-    if (m->d_h) hipFree(m->d_h);
+    DevTmp raw;
+    HIPCHK(raw.alloc<float>(nJ));
+    HIPCHK(hipMemcpy(raw.p, J, nJ * sizeof(float), hipMemcpyHostToDevice));
+    if (m->d_Jt) { hipFree(m->d_Jt); m->d_Jt = nullptr; }
+    if (m->d_h) { hipFree(m->d_h); m->d_h = nullptr; }
+    m->has_potts = false;
     const size_t nJt = (size_t)Lp * 5 * g.NC * 320;           // float4s
     HIPCHK(dalloc(&m->d_Jt, nJt));
     HIPCHK(dalloc(&m->d_h, (size_t)Lp * 20));
     HIPCHK(hipMemcpy(m->d_h, h, (size_t)Lp * 20 * sizeof(float), hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(potts_prepare_kernel, dim3(1024), dim3(256), 0, 0, d_raw, (float*)m->d_Jt, Lp, g.NC);
+    hipLaunchKernelGGL(potts_prepare_kernel, dim3(1024), dim3(256), 0, 0, raw.as<float>(), (float*)m->d_Jt, Lp, g.NC);
     HIPCHK(hipGetLastError());
     HIPCHK(hipDeviceSynchronize());
-    HIPCHK(hipFree(d_raw));
     m->has_potts = true;
     // wt_H = H(wild type) with the same kernel that evaluates every other state
-    float *d_grad = nullptr, *d_ep = nullptr, *d_e = nullptr;
-    HIPCHK(dalloc(&d_grad, (size_t)g.N));
-    HIPCHK(dalloc(&d_ep, (size_t)Lp));
-    HIPCHK(dalloc(&d_e, 1));
-    EvalTargets t{d_grad, d_ep, nullptr, nullptr, 0};
+    DevTmp grad, ep, e;
+    HIPCHK(grad.alloc<float>((size_t)g.N));
+    HIPCHK(ep.alloc<float>((size_t)Lp));
+    HIPCHK(e.alloc<float>(1));
+    EvalTargets t{grad.as<float>(), ep.as<float>(), nullptr, nullptr, 0};
     rc = launch_potts(m, m->d_wt, 1, t, 0);
     if (rc) return rc;
-    hipLaunchKernelGGL(potts_energy_finalize_kernel, dim3(1), dim3(64), 0, 0, d_ep, Lp, 0.0f, d_e, 1);
+    hipLaunchKernelGGL(potts_energy_finalize_kernel, dim3(1), dim3(64), 0, 0, ep.as<float>(), Lp, 0.0f, e.as<float>(), 1);
     HIPCHK(hipGetLastError());
-    HIPCHK(hipMemcpy(&m->wt_H, d_e, sizeof(float), hipMemcpyDeviceToHost));
-    hipFree(d_grad); hipFree(d_ep); hipFree(d_e);
+    HIPCHK(hipMemcpy(&m->wt_H, e.p, sizeof(float), hipMemcpyDeviceToHost));
     return PPDE_OK;
 }
 
@@ -547,6 +574,7 @@ int ppde_energy_grad(ppde_model* m, const uint8_t* idx_dev, int n, int which, fl
     hipLaunchKernelGGL(k_pack_state, dim3((n * g.Ls + 255) / 256), dim3(256), 0, s, idx_dev, m->s_state, n, g.L, g.Ls, g.sh);
     HIPCHK(hipGetLastError());
     EvalTargets t{m->s_grad, m->s_epart, m->s_gradC, m->s_fitC, 0};
+    t.cmax = m->cnn_cmax; t.carg = m->cnn_carg; t.cgate = m->cnn_cgate; t.cnn_cap = m->cnn_scratch_n;
     // the scratch is laid out for scratch_n chains; kernels index slot 0 with stride n, which is fine for slot 0
     rc = eval_experts(m, which, m->s_state, n, t, grad_dev != nullptr, s);
     if (rc) return rc;
@@ -588,10 +616,15 @@ struct ppde_chains {
     int *tmp_bt = nullptr, *tr_flat = nullptr, *tr_U = nullptr, *err_flag = nullptr,
         *d_it = nullptr, *tmp_dist = nullptr;
     unsigned long long* dbg = nullptr;           // stamps of the diagnostic build (64 x (cycles, 100 MHz ticks))
-    // graph replay
-    hipGraph_t graph = nullptr;
-    hipGraphExec_t graph_exec = nullptr;
-    int graph_len = 0;
+    // chunk scratch of the long-sequence CNN path (this object's own: its graphs hold these pointers)
+    float* cnn_cmax = nullptr;
+    int* cnn_carg = nullptr;
+    uint32_t* cnn_cgate = nullptr;
+    // graph replay: segments of different lengths, longest first, captured once by ppde_chains_init
+    struct GraphSeg { hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr; int len = 0; };
+    std::vector<GraphSeg> graphs;
+    int n_captures = 0, n_captures_in_run = 0;   // graphs captured in all / inside ppde_chains_run (must stay 0)
+    long long n_replayed_steps = 0, n_eager_steps = 0;
     std::vector<void*> allocs;
 };
 
@@ -602,7 +635,7 @@ static PasArgs chain_args(const ppde_chains* c) {
     a.thr = c->cfg.nmut_threshold == 0 ? 0x7fffffff : c->cfg.nmut_threshold;
     a.paper = c->cfg.paper_results; a.min_pos = c->cfg.min_pos; a.max_pos = c->cfg.max_pos;
     a.rng_mode = c->cfg.rng_mode; a.reuse = c->cfg.reuse_grad; a.rec_after_reset = c->cfg.record_after_reset;
-    a.random_chain = c->cfg.random_chain; a.mu_max = c->mu_max;
+    a.random_chain = c->cfg.random_chain; a.mu_max = c->mu_max; a.mu_cap = c->mu_max;
     a.key.k0 = (uint32_t)c->cfg.seed;
     a.key.k1 = (uint32_t)(c->cfg.seed >> 32) ^ (uint32_t)(c->cfg.chain_offset >> 32);
     a.key.chain_lo = (uint32_t)c->cfg.chain_offset;
@@ -619,7 +652,9 @@ static PasArgs chain_args(const ppde_chains* c) {
 }
 
 static EvalTargets chain_targets(const ppde_chains* c, int slot) {
-    return EvalTargets{c->grad, c->epart, c->gradC, c->fitC, slot, c->dbg};
+    EvalTargets t{c->grad, c->epart, c->gradC, c->fitC, slot, c->dbg};
+    t.cmax = c->cnn_cmax; t.carg = c->cnn_carg; t.cgate = c->cnn_cgate; t.cnn_cap = c->n;
+    return t;
 }
 
 enum ChainKernel { KP_PROPOSE, KP_ACCEPT, KP_ACCEPT_PROPOSE };
@@ -645,12 +680,13 @@ static int launch_chain_kernel(ppde_chains* c, ChainKernel which, const PasArgs&
 // `count` iterations of ppde.py:65-153 for sub-population k, enqueued on that sub-population's stream.
 // Re-evaluating mode: EG(x) P EG(y) A per iteration. Reuse mode: P, then EG(y) + fused [accept | next propose].
 static int enqueue_iterations(ppde_chains* c, int k, const int* it_base, int first_local, int count, const int* U,
-                              const float* q, const float* u) {
+                              const float* q, const float* u, int mu_cap = 0) {
     const ppde_model* m = c->m;
     hipStream_t s = c->streams[k];
     const int b_off = c->sub_off[k], n_sub = c->sub_n[k];
     PasArgs a = chain_args(c);
     a.b_off = b_off; a.it_base = it_base; a.U_in = U; a.q_in = q; a.u_in = u;
+    if (mu_cap > 0) a.mu_cap = mu_cap;              // caller-supplied noise holds only max_u[i] sub-steps of variates
     const bool fuse = c->cfg.reuse_grad && c->cfg.rng_mode == 1;
     int rc;
     for (int i = 0; i < count; ++i) {
@@ -691,6 +727,42 @@ static int enqueue_block(ppde_chains* c, const int* it_base, int first_local, in
     return PPDE_OK;
 }
 
+// Capture `len` iterations (iteration index = device counter + node-local offset) into a graph segment.
+static int capture_segment(ppde_chains* c, int len, bool inside_run) {
+    ppde_chains::GraphSeg gs;
+    HIPCHK(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+    int rc = enqueue_block(c, c->d_it, 0, len);
+    if (rc == PPDE_OK) hipLaunchKernelGGL(k_bump, dim3(1), dim3(1), 0, c->stream, c->d_it, len);
+    hipError_t e = hipStreamEndCapture(c->stream, &gs.graph);
+    if (rc == PPDE_OK && e == hipSuccess) e = hipGraphInstantiate(&gs.exec, gs.graph, nullptr, nullptr, 0);
+    if (rc != PPDE_OK || e != hipSuccess) {
+        if (gs.exec) hipGraphExecDestroy(gs.exec);
+        if (gs.graph) hipGraphDestroy(gs.graph);
+        if (rc) return rc;
+        return fail(PPDE_ERR_HIP, std::string("hipGraph capture: ") + hipGetErrorString(e));
+    }
+    gs.len = len;
+    c->graphs.push_back(gs);
+    c->n_captures++;
+    if (inside_run) c->n_captures_in_run++;
+    return PPDE_OK;
+}
+
+// Graph segments of a chains object: PPDE_GRAPH_LEN (one length) or {100, 20}, each only if the histories can hold
+// it. Captured and instantiated here, from ppde_chains_init, so that no ppde_chains_run pays for it.
+static int capture_segments(ppde_chains* c) {
+    if (!c->cfg.use_graph || c->cfg.rng_mode != 1 || !c->graphs.empty()) return PPDE_OK;
+    static const int gl_env = []() { const char* e = getenv("PPDE_GRAPH_LEN"); const int v = e ? atoi(e) : 0; return v >= 1 && v <= 1000 ? v : 0; }();
+    const int lens_default[2] = {100, 20};
+    for (int k = 0; k < (gl_env ? 1 : 2); ++k) {
+        const int len = gl_env ? gl_env : lens_default[k];
+        if (len > c->T) continue;
+        int rc = capture_segment(c, len, false);
+        if (rc) return rc;
+    }
+    return PPDE_OK;
+}
+
 extern "C" {
 
 int ppde_chains_create(ppde_chains** out, ppde_model* m, const ppde_chain_config* cfg) {
@@ -708,10 +780,6 @@ int ppde_chains_create(ppde_chains** out, ppde_model* m, const ppde_chain_config
     ARGCHK(cfg->chain_offset + (uint64_t)cfg->n_chains <= 0xffffffffull, "chain_offset + n_chains must fit 32 bits");
     ARGCHK(pas_lds_bytes(m->g) <= 160 * 1024 && m->g.N / 4 <= 3 * PPDE_BLOCK, "sequence too long for the chain kernels (L <= 307)");
     HIPCHK(hipSetDevice(m->device));
-    if (cfg->which & 2) {
-        int rc0 = ensure_cnn_scratch(m, cfg->n_chains);
-        if (rc0) return rc0;
-    }
     ppde_chains* c = new ppde_chains();
     c->m = m; c->device = m->device; c->cfg = *cfg; c->n = cfg->n_chains; c->T = cfg->max_steps; c->mu_max = 2 * cfg->pas_length - 1;
     const Geom& g = m->g;
@@ -731,7 +799,13 @@ int ppde_chains_create(ppde_chains** out, ppde_model* m, const ppde_chain_config
     A(&c->grad_cur, cfg->reuse_grad ? n * g.N : 1, true); A(&c->best_state, n * g.L, true); A(&c->rtraj, T1 * g.L, true); A(&c->tmp_acc, n, true);
     A(&c->tmp_idx, n * g.L, true); A(&c->tmp_dist, n, true);
     A(&c->grad, 2 * n * g.N, true); A(&c->epart, 2 * n * std::max(g.Lp, 1), true);
-    if (cfg->which & 2) { A(&c->gradC, 2 * nets * n * g.N, true); A(&c->fitC, 2 * nets * n, true); }
+    if (cfg->which & 2) {
+        A(&c->gradC, 2 * nets * n * g.N, true); A(&c->fitC, 2 * nets * n, true);
+        if (!cnn_single_launch(m)) {
+            A(&c->cnn_cmax, cnn_chunk_max_count(m, c->n), true); A(&c->cnn_carg, cnn_chunk_max_count(m, c->n), true);
+            A(&c->cnn_cgate, cnn_chunk_gate_count(m, c->n), true);
+        }
+    }
     A(&c->fb_grad, (cfg->paper_results ? n : 1) * g.N, true);
     A(&c->fb_e, cfg->paper_results ? n : 1, true); A(&c->fb_f, cfg->paper_results ? n : 1, true);
     A(&c->e_hist, T1 * n, true); A(&c->f_hist, T1 * n, true);
@@ -767,8 +841,10 @@ int ppde_chains_destroy(ppde_chains* c) {
     if (!c) return PPDE_OK;
     hipSetDevice(c->device);
     for (hipStream_t st : c->streams) if (st) hipStreamSynchronize(st);
-    if (c->graph_exec) hipGraphExecDestroy(c->graph_exec);
-    if (c->graph) hipGraphDestroy(c->graph);
+    for (auto& gs : c->graphs) {
+        if (gs.exec) hipGraphExecDestroy(gs.exec);
+        if (gs.graph) hipGraphDestroy(gs.graph);
+    }
     for (void* p : c->allocs) hipFree(p);
     for (hipStream_t st : c->streams) if (st) hipStreamDestroy(st);
     for (hipEvent_t ev : c->events) if (ev) hipEventDestroy(ev);
@@ -828,6 +904,8 @@ int ppde_chains_init(ppde_chains* c, const uint8_t* idx0_dev) {
     HIPCHK(hipStreamSynchronize(s));
     c->steps_done = 0;
     c->initialised = true;
+    rc = capture_segments(c);                       // (replayed by every later run; never captured inside one)
+    if (rc) return rc;
     return PPDE_OK;
 }
 
@@ -844,7 +922,7 @@ int ppde_chains_run(ppde_chains* c, int steps, const int32_t* U_dev, const float
         for (int i = 0; i < steps; ++i) {
             ARGCHK(max_u[i] >= 1 && max_u[i] <= c->mu_max, "max_u out of range");
             int rc = enqueue_iterations(c, 0, nullptr, c->steps_done + i, 1, U_dev + (size_t)i * c->n,
-                                        q_dev + qoff * c->n * g.N, u_dev + (size_t)i * c->n);
+                                        q_dev + qoff * c->n * g.N, u_dev + (size_t)i * c->n, max_u[i]);
             if (rc) return rc;
             qoff += max_u[i];
         }
@@ -852,35 +930,36 @@ int ppde_chains_run(ppde_chains* c, int steps, const int32_t* U_dev, const float
         return PPDE_OK;
     }
     int done = 0;
-    if (c->cfg.use_graph) {
-        // iterations per captured graph: 100 when the first run is long enough (26.56 vs 26.89 us/step with 20), else 20
-        static const int gl_env = []() { const char* e = getenv("PPDE_GRAPH_LEN"); const int v = e ? atoi(e) : 0; return v >= 1 && v <= 1000 ? v : 0; }();
-        const int GL = gl_env ? gl_env : (steps >= 100 ? 100 : 20);
-        if (steps >= GL && !c->graph_exec) {
-            HIPCHK(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
-            int rc = enqueue_block(c, c->d_it, 0, GL);
-            if (rc == PPDE_OK) {
-                hipLaunchKernelGGL(k_bump, dim3(1), dim3(1), 0, c->stream, c->d_it, GL);
-            }
-            hipError_t e = hipStreamEndCapture(c->stream, &c->graph);
-            if (rc) return rc;
-            HIPCHK(e);
-            HIPCHK(hipGraphInstantiate(&c->graph_exec, c->graph, nullptr, nullptr, 0));
-            c->graph_len = GL;
-        }
-        if (c->graph_exec && steps >= c->graph_len) {
-            HIPCHK(hipMemsetD32Async((hipDeviceptr_t)c->d_it, c->steps_done, 1, c->stream));
-            while (steps - done >= c->graph_len) {
-                HIPCHK(hipGraphLaunch(c->graph_exec, c->stream));
-                done += c->graph_len;
+    if (!c->graphs.empty()) {
+        bool counter_set = false;
+        for (const auto& gs : c->graphs) {          // longest segment first
+            while (steps - done >= gs.len) {
+                if (!counter_set) {
+                    HIPCHK(hipMemsetD32Async((hipDeviceptr_t)c->d_it, c->steps_done, 1, c->stream));
+                    counter_set = true;
+                }
+                HIPCHK(hipGraphLaunch(gs.exec, c->stream));
+                done += gs.len;
             }
         }
+        c->n_replayed_steps += done;
     }
     if (done < steps) {
         int rc = enqueue_block(c, nullptr, c->steps_done + done, steps - done);
         if (rc) return rc;
+        c->n_eager_steps += steps - done;
     }
     c->steps_done += steps;
+    return PPDE_OK;
+}
+
+int ppde_chains_graph_stats(ppde_chains* c, int32_t* captures, int32_t* captures_in_run, int64_t* replayed_steps,
+                            int64_t* eager_steps) {
+    ARGCHK(c, "null chains");
+    if (captures) *captures = c->n_captures;
+    if (captures_in_run) *captures_in_run = c->n_captures_in_run;
+    if (replayed_steps) *replayed_steps = c->n_replayed_steps;
+    if (eager_steps) *eager_steps = c->n_eager_steps;
     return PPDE_OK;
 }
 
@@ -890,6 +969,7 @@ int ppde_chains_sync(ppde_chains* c) {
     HIPCHK(hipStreamSynchronize(c->stream));
     int err = 0;
     HIPCHK(hipMemcpy(&err, c->err_flag, sizeof(int), hipMemcpyDeviceToHost));
+    if (err & 2) return fail(PPDE_ERR_INVALID, "a supplied path length U exceeds the max_u of its iteration (the noise block holds only max_u sub-steps)");
     if (err) return fail(PPDE_ERR_NUMERIC, "a proposal row had no finite logit (every move masked out): the categorical is undefined");
     return PPDE_OK;
 }
@@ -994,7 +1074,7 @@ int ppde_chains_time_potts_in_situ(ppde_chains* c, int iters, float* avg_us, int
     ARGCHK(c->steps_done + iters <= c->T, "run would exceed max_steps");
     HIPCHK(hipSetDevice(c->m->device));
     EventPool pool;
-    pool.ev.resize((size_t)iters * 2 * 2 * c->streams.size());
+    pool.ev.assign((size_t)iters * 2 * 2 * c->streams.size(), nullptr);
     for (auto& e : pool.ev) HIPCHK(hipEventCreate(&e));
     g_potts_events = &pool;
     int rc = enqueue_block(c, nullptr, c->steps_done, iters);
@@ -1010,7 +1090,6 @@ int ppde_chains_time_potts_in_situ(ppde_chains* c, int iters, float* avg_us, int
             float ms = 0.f;
             if (hipEventElapsedTime(&ms, pool.ev[i], pool.ev[i + 1]) == hipSuccess) { tot += ms; ++cnt; }
         }
-    for (auto& e : pool.ev) hipEventDestroy(e);
     if (rc) return rc;
     ARGCHK(cnt > 0, "no Potts launch was timed");
     *avg_us = (float)(tot * 1000.0 / cnt);
@@ -1022,9 +1101,10 @@ int ppde_chains_time_potts_kernel(ppde_chains* c, int reps, float* avg_us) {
     ARGCHK(c && c->initialised && avg_us && reps >= 1, "bad argument");
     ARGCHK(c->cfg.which & 1, "no Potts expert in this energy");
     HIPCHK(hipSetDevice(c->m->device));
-    hipEvent_t e0, e1;
-    HIPCHK(hipEventCreate(&e0));
-    HIPCHK(hipEventCreate(&e1));
+    EventPair ev;
+    HIPCHK(hipEventCreate(&ev.a));
+    HIPCHK(hipEventCreate(&ev.b));
+    hipEvent_t e0 = ev.a, e1 = ev.b;
     // writes the proposal slot, exactly as the launch inside an iteration does
     EvalTargets t = chain_targets(c, 1);
     int rc = launch_potts(c->m, c->cur, c->n, t, c->stream);   // warm
@@ -1039,8 +1119,6 @@ int ppde_chains_time_potts_kernel(ppde_chains* c, int reps, float* avg_us) {
     float ms = 0.f;
     HIPCHK(hipEventElapsedTime(&ms, e0, e1));
     *avg_us = ms * 1000.f / reps;
-    hipEventDestroy(e0);
-    hipEventDestroy(e1);
     return PPDE_OK;
 }
 

@@ -11,6 +11,7 @@ everything else happens in the HIP kernels (ppde_amd/csrc). There is no CPU path
 """
 import ctypes as C
 import os
+import weakref
 
 import numpy as np
 import torch
@@ -132,6 +133,39 @@ class HipModel:
         return e, fit, grad
 
 
+# One device copy of a potts.pkl per process and device: the energy function, the ground-truth oracle
+# (nets.AugmentedLinearRegression) and the Potts score (nets.proteins_potts_score) all evaluate the SAME couplings,
+# so whoever uploads them first registers its model here and the others reuse it (a GFP-sized window is 90 MB
+# and one symmetrise-and-tile pass per upload). Consumers of a shared model only call the stateless
+# WHICH_POTTS evaluation; they never change its experts.
+_POTTS_MODELS = {}
+
+
+def _potts_key(dataset, device_index):
+    st = os.stat(os.path.join(dataset, "potts.pkl"))
+    return (os.path.realpath(dataset), st.st_size, st.st_mtime_ns, int(device_index))
+
+
+def register_potts_model(dataset, model, params):
+    model._potts_params = params
+    _POTTS_MODELS[_potts_key(dataset, model.device_index)] = weakref.ref(model)
+
+
+def shared_potts_model(dataset, device="cuda"):
+    """-> (HipModel holding dataset's Potts expert, its PottsParams): an already uploaded one if there is one."""
+    key = _potts_key(dataset, _device_index(device))
+    ref = _POTTS_MODELS.get(key)
+    m = ref() if ref is not None else None
+    if m is not None and m.handle.value and m.has_potts:
+        return m, m._potts_params
+    params = PottsParams(dataset)
+    _, wt_idx = load_wt(dataset)
+    m = HipModel(wt_idx[0], device)
+    m.set_potts(params.J, params.h, params.win_start)
+    register_potts_model(dataset, m, params)
+    return m, params
+
+
 class PottsWindow:
     """What callers read off the reference's PottsModel (ppde/nets.py:244-299): index_list, wtseqs, seq_len, ...
     and the Delta-H evaluation itself."""
@@ -181,6 +215,7 @@ class _HipEnergy(torch.nn.Module):
         if with_potts:
             params = PottsParams(dataset)
             self.model.set_potts(params.J, params.h, params.win_start)
+            register_potts_model(dataset, self.model, params)
             self.unsupervised_expert = PottsWindow(params, self.model)
         self.model.set_cnn(load_cnn_states(dataset))
         if getattr(args, "ppde_rng", "torch") == "torch":

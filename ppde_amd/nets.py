@@ -11,17 +11,15 @@ import math
 import numpy as np
 import torch
 
-from .energy import HipModel, PottsWindow, WHICH_POTTS
-from .weights import PottsParams, load_linear, load_wt
+from .energy import PottsWindow, WHICH_POTTS, shared_potts_model
+from .weights import load_linear
 
 
 class AugmentedLinearRegression(torch.nn.Module):
     def __init__(self, protein, device="cuda"):
         super().__init__()
-        params = PottsParams(protein)
-        _, wt_idx = load_wt(protein)
-        self.model = HipModel(wt_idx[0], device)
-        self.model.set_potts(params.J, params.h, params.win_start)
+        # the device copy of the couplings is shared with the energy function when it holds the same potts.pkl
+        self.model, params = shared_potts_model(protein, device)
         self.potts = PottsWindow(params, self.model)
         lin = load_linear(protein)
         dev = self.model.device
@@ -50,10 +48,7 @@ class AugmentedLinearRegression(torch.nn.Module):
 
 def proteins_potts_score(population, dataset_name, device=None):
     """Delta-H of a one-hot population [n, L, 20] under the Potts model stored in `dataset_name`."""
-    params = PottsParams(dataset_name)
-    _, wt_idx = load_wt(dataset_name)
     dev = device if device is not None else (population.device if population.device.type == "cuda" else "cuda")
-    m = HipModel(wt_idx[0], dev)
-    m.set_potts(params.J, params.h, params.win_start)
+    m, _ = shared_potts_model(dataset_name, dev)
     e, _, _ = m.energy_grad(m.onehot_to_idx(population), WHICH_POTTS, want_grad=False)
     return e

@@ -50,3 +50,13 @@ def broadcast_from(t, src):
         dist.broadcast(t, src)
         t = t.to(home)
     return t
+
+
+def agree_from_rank0(values):
+    """Rank 0's integers on every rank (random chain index, default seed): ranks that were seeded differently must
+    still record the same chain and draw the same Philox stream."""
+    rank, ws = world()
+    if ws == 1:
+        return [int(v) for v in values]
+    t = torch.tensor([int(v) for v in values], dtype=torch.int64)
+    return [int(v) for v in broadcast_from(t, 0).tolist()]

@@ -30,7 +30,7 @@ from . import _hip
 from .base_sampler import BaseSampler
 from .encoding import idx_to_onehot
 from .noise import draw_chunk
-from .parallel import all_gather_rows, broadcast_from, shard_range, world
+from .parallel import agree_from_rank0, all_gather_rows, broadcast_from, shard_range, world
 
 
 class Chains:
@@ -116,6 +116,13 @@ class Chains:
         _hip.check(self.lib.ppde_chains_trace(self.handle, *[_hip.ptr(out[k]) for k in ("flat", "accepted", "log_acc", "U")]))
         return out
 
+    def graph_stats(self):
+        """How the iterations so far were issued: graphs captured (all by init), captured inside a run (0), steps
+        replayed from graphs / launched eagerly."""
+        a, b, r, e = C.c_int32(), C.c_int32(), C.c_int64(), C.c_int64()
+        _hip.check(self.lib.ppde_chains_graph_stats(self.handle, C.byref(a), C.byref(b), C.byref(r), C.byref(e)))
+        return dict(captures=a.value, captures_in_run=b.value, replayed_steps=r.value, eager_steps=e.value)
+
     def philox_dump(self, it, s):
         dev, n, N = self.model.device, self.n, self.model.L * 20
         q = torch.empty(n, N, device=dev)
@@ -176,6 +183,8 @@ class PPDE_PAS(BaseSampler):
         n = hi - lo
         idx0 = model.onehot_to_idx(initial_population)
         seed = self.seed if self.seed is not None else torch.initial_seed()
+        if ws > 1:      # one recorded chain and one Philox key for the whole job, whatever each rank's host RNG state is
+            random_idx, seed = agree_from_rank0([random_idx, seed & (2 ** 63 - 1)])
         chains = Chains(model, n, num_steps, self.ppde_pas_length, self.nmut_threshold, self.paper_results, min_pos,
                         max_pos, energy_function.which, 0 if self.rng == "torch" else 1, self.reuse_grad, self.cpu_alias,
                         self.trace, random_idx - lo if lo <= random_idx < hi else -1, self.use_graph, seed, lo,

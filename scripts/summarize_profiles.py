@@ -5,7 +5,7 @@
          [--fetch <dir of a --pmc FETCH_SIZE pass>] [--write <dir of a --pmc WRITE_SIZE pass>] [--sq <dir of an SQ pass>]
 
 Writes profiles/<tag>_kernel_stats.csv (verbatim copy of rocprofv3's per-kernel table), profiles/<tag>_pmc.md and,
-when both TCC passes are given, profiles/potts_pmc.json with the HBM-side bytes per launch of the Potts kernel:
+when both TCC passes are given, the `--key` entry of profiles/potts_pmc.json with the HBM-side bytes per launch of the Potts kernel:
 FETCH_SIZE and WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE counts 128-byte fabric reads as 64 bytes, so it is
 doubled before use (MI355X_MICROARCH.md, HBM section). WRITE_SIZE is taken as is."""
 import argparse
@@ -35,6 +35,8 @@ def main():
     ap.add_argument("--write")
     ap.add_argument("--sq")
     ap.add_argument("--mfma", help="dir of a --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVES pass")
+    ap.add_argument("--key", default="PABP", help="entry of profiles/potts_pmc.json the TCC passes describe (PABP, GFP, ...)")
+    ap.add_argument("--min-launches", type=int, default=10)
     a = ap.parse_args()
     os.makedirs(OUT, exist_ok=True)
     if a.stats:
@@ -50,14 +52,18 @@ def main():
         lines += [f"## pass: {name}", "", "| kernel | counter | mean per launch | launches |", "|---|---|---|---|"]
         for _, r in g.iterrows():
             lines.append(f"| {r['kernel']} | {r['Counter_Name']} | {r['mean']:.1f} | {int(r['count'])} |")
-            if r["kernel"].startswith("potts_energy_grad") and r["count"] > 10:
+            if r["kernel"].startswith("potts_energy_grad") and r["count"] > a.min_launches:
                 vals[r["Counter_Name"]] = float(r["mean"])
         lines.append("")
     if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals:
         hbm = (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0
-        json.dump({"kernel": "potts_energy_grad_kernel", "FETCH_SIZE_KiB_raw": vals["FETCH_SIZE"],
-                   "WRITE_SIZE_KiB": vals["WRITE_SIZE"], "fetch_correction": "x2 (gfx950, MI355X_MICROARCH.md HBM section)",
-                   "hbm_bytes_per_launch": hbm, "source": a.tag}, open(os.path.join(OUT, "potts_pmc.json"), "w"), indent=1)
+        pj = os.path.join(OUT, "potts_pmc.json")
+        allk = json.load(open(pj)) if os.path.exists(pj) else {}
+        allk[a.key] = {"kernel": "potts_energy_grad_kernel", "FETCH_SIZE_KiB_raw": vals["FETCH_SIZE"],
+                       "WRITE_SIZE_KiB": vals["WRITE_SIZE"], "fetch_correction": "x2 (gfx950, MI355X_MICROARCH.md HBM section)",
+                       "hbm_bytes_per_launch": hbm, "source": a.tag,
+                       "collected": f"{a.tag}: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (scripts/collect_profiles.sh)"}
+        json.dump(allk, open(pj, "w"), indent=1)
         lines += [f"Potts kernel HBM-side traffic per launch = (2 x {vals['FETCH_SIZE']:.0f} + {vals['WRITE_SIZE']:.0f}) KiB "
                   f"= {hbm / 1e6:.2f} MB", ""]
     if a.mfma:

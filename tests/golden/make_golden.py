@@ -122,6 +122,33 @@ def ops_case(root, protein, potts_seed, symmetric, lamda, n, state_seed, out):
     print("wrote", out)
 
 
+def file_sha(path):
+    with open(path, "rb") as fh:
+        return hashlib.sha256(fh.read()).hexdigest()
+
+
+def real_case(protein, lamda, n, state_seed, out):
+    """The reference on the REAL shipped supervised / ground-truth weights (weights/<protein>/onehot_cnn_seed=*.pt,
+    results-...-linear.pkl, wt.fasta) next to a synthetic potts.pkl (the real one is a missing blob). The fixture
+    holds the files' SHA-256, the states and the reference's outputs: no weight values."""
+    src = os.path.join("/root/reference/weights", protein)
+    with tempfile.TemporaryDirectory() as root:
+        d = synthetic.write_weights_dir(root, protein, potts_seed=1234, cnn_seeds=(), linear_seeds=())
+        real_wt = read_fasta(os.path.join(src, "wt.fasta"), return_ids=True)
+        assert real_wt == read_fasta(os.path.join(d, "wt.fasta"), return_ids=True), "synthetic.PROTEINS differs from the shipped wt.fasta"
+        names = sorted(f for f in os.listdir(src) if f.endswith(".pt") or f.endswith("-linear.pkl"))
+        for f in names:
+            os.symlink(os.path.join(src, f), os.path.join(d, f))
+        tmp = out + ".tmp.npz"
+        ops_case(root, protein, 1234, True, lamda, n, state_seed, tmp)
+        fx = dict(np.load(tmp))
+        os.remove(tmp)
+    fx["files"] = np.array(names + ["wt.fasta"])
+    fx["file_sha"] = np.array([file_sha(os.path.join(src, f)) for f in names + ["wt.fasta"]])
+    np.savez_compressed(out, **fx)
+    print("wrote", out, f"({os.path.getsize(out) / 1e3:.0f} kB)")
+
+
 def run_case(root, protein, lamda, n, T, seed, pas, nmut, paper, out, store_q):
     """One reference sampler run with everything it drew recorded."""
     from ppde.energy import ProteinProductOfExperts
@@ -271,6 +298,12 @@ def main():
     install_stubs()
     only = sys.argv[1:]
     torch.set_num_threads(1)  # reference CPU path is bit-stable at a fixed thread count
+    if only and "real" in only:
+        # lamda per protein as the reference's README recommends for the Potts expert (README.md:65-69)
+        for protein, lam, seed in (("PABP_YEAST_Fields2013", 5.0, 21), ("UBE4B_MOUSE_Klevit2013-nscor_log2_ratio", 0.5, 22),
+                                   ("GFP_AEQVI_Sarkisyan2016", 15.0, 23)):
+            real_case(protein, lam, 6, seed, os.path.join(HERE, f"real_{protein.split('_')[0].lower()}.npz"))
+        return
     if only and "script" in only:
         with tempfile.TemporaryDirectory() as root:
             synthetic.write_weights_dir(root, "PABP_YEAST_Fields2013", potts_seed=1234)

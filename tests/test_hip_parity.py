@@ -1,7 +1,8 @@
 """GPU parity tests: the HIP path (through the C ABI) against the CPU oracle and the reference's fixtures.
 
-Tolerances (fp32): energies |d| <= 2e-6 * (|H| + |wt_H| + 1) (H and wt_H are each sums of ~L' terms of O(1) and are
-subtracted), fitness 5e-6, gradients 2e-6 * max(1, lamda); sampled indices, accept bits, best states: exact.
+Tolerances (fp32): Potts energies |d| <= 5e-6 * max(1, |e|) (+ 5e-6 * lamda for the fitness term of
+a product of experts), fitness 5e-6, gradients 2e-6 * max(1, lamda); sampled indices, accept bits, best states:
+exact. The largest observed error / tolerance ratios are appended to gpurun_out/parity_observed.json.
 """
 import glob
 import os
@@ -28,8 +29,24 @@ def hip_model(J, h, i0, wt_idx, cnn, lamda):
     return m
 
 
-def e_tol(e, wt_H):
-    return 2e-6 * (np.abs(e) + abs(wt_H) + 1.0) * 4
+def e_tol(e, lam=0.0):
+    return 5e-6 * np.maximum(1.0, np.abs(e)) + 5e-6 * lam
+
+
+def observed(tag, err, tol):
+    """Record max(err / tol) of a check next to the test run (gpurun_out/ travels back from the GPU box)."""
+    import json
+    ratio = float(np.max(np.asarray(err, dtype=np.float64) / np.asarray(tol, dtype=np.float64)))
+    path = os.path.join(os.path.dirname(GOLDEN), "..", "gpurun_out", "parity_observed.json")
+    try:
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        d = json.load(open(path)) if os.path.exists(path) else {}
+        d[tag] = {"max_err_over_tol": ratio, "max_abs_err": float(np.max(err))}
+        json.dump(d, open(path, "w"), indent=1, sort_keys=True)
+    except OSError:
+        pass
+    print(f"[parity] {tag}: max |err| {float(np.max(err)):.3e} = {ratio:.2f} of the tolerance")
+    return ratio
 
 
 @pytest.mark.parametrize("name", ["ops_toy24_lam5.npz", "ops_pabp_lam5.npz", "ops_pabp_lam0.npz", "ops_toy24_nonsym.npz"])
@@ -42,11 +59,11 @@ def test_energy_grad_vs_reference_fixture(name):
     wt_H = float(np.ravel(fx["wt_H"])[0])
     assert abs(m.wt_hamiltonian - wt_H) <= 4e-6 * (abs(wt_H) + 1)
     e, fit, g = m.energy_grad(idx, 3)
-    assert np.all(np.abs(e.cpu().numpy() - fx["e"]) <= e_tol(fx["e"], wt_H) + 5e-6 * lam)
+    assert observed(f"{name}:e", np.abs(e.cpu().numpy() - fx["e"]), e_tol(fx["e"], lam)) <= 1.0
     assert np.abs(fit.cpu().numpy() - fx["fit"]).max() <= 5e-6
     assert np.abs(g.cpu().numpy() - fx["grad"]).max() <= 2e-6 * max(1.0, lam)
     e1, f1, g1 = m.energy_grad(idx, 1)
-    assert np.all(np.abs(e1.cpu().numpy() - fx["unsupervised"]) <= e_tol(fx["unsupervised"], wt_H))
+    assert observed(f"{name}:potts_e", np.abs(e1.cpu().numpy() - fx["unsupervised"]), e_tol(fx["unsupervised"])) <= 1.0
     assert float(f1.abs().max()) == 0.0
     e2, f2, g2 = m.energy_grad(idx, 2)
     assert np.abs(f2.cpu().numpy() - fx["supervised"]).max() <= 5e-6
@@ -69,7 +86,7 @@ def test_energy_grad_vs_oracle_batch_sizes(n):
     en = oracle_energy(J, h, i0, wt_idx, cnn, 5.0)
     eo, fo, go = en.energy_grad(torch.as_tensor(idx.astype(np.int64)))
     wt_H = float(en.potts.wt_H)
-    assert np.all(np.abs(e.cpu().numpy() - eo.numpy()) <= e_tol(eo.numpy(), wt_H) + 2.5e-5)
+    assert observed(f"batch{n}:e_vs_oracle", np.abs(e.cpu().numpy() - eo.numpy()), e_tol(eo.numpy(), 5.0)) <= 1.0
     assert np.abs(fit.cpu().numpy() - fo.numpy()).max() <= 5e-6
     assert np.abs(g.cpu().numpy() - go.numpy()).max() <= 1e-5
     # a chain's numbers do not depend on which batch it sits in

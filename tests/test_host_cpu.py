@@ -150,6 +150,7 @@ assert torch.allclose(eh, full["energy_history"], atol=1e-5, rtol=0), "sharded h
 assert torch.equal(bi, full["best_idx"])
 rt = parallel.broadcast_from(torch.full((3,), float(rank)), 1)
 assert float(rt[0]) == 1.0
+assert parallel.agree_from_rank0([100 + rank, 7 * (rank + 1)]) == [100, 7]   # every rank ends up with rank 0's integers
 dist.destroy_process_group()
 print("rank", rank, "ok")
 '''
@@ -170,3 +171,36 @@ def test_sharded_run_gathers_to_the_unsharded_result_gloo():
         assert r.stdout.count("ok") == 2
     finally:
         os.unlink(path)
+
+
+def test_bench_launches_its_own_ranks(monkeypatch):
+    """`python bench.py --gpus N` without a launcher: the parent starts torch.distributed.run with N ranks and the same
+    arguments, and never touches the GPU itself; as a rank it refuses a world size that differs from --gpus."""
+    import importlib
+    sys.path.insert(0, REPO)
+    bench = importlib.import_module("bench")
+    seen = {}
+
+    class R:
+        returncode = 0
+
+    def fake_run(cmd, env=None, **k):
+        seen["cmd"], seen["env"] = cmd, env
+        return R()
+
+    monkeypatch.setattr(bench.subprocess, "run", fake_run)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "20", "--warmup", "5"])
+    monkeypatch.delenv("RANK", raising=False)
+    with pytest.raises(SystemExit) as ex:
+        bench.main()
+    assert ex.value.code == 0
+    cmd = seen["cmd"]
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=4" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[-6:] == ["--gpus", "4", "--steps", "20", "--warmup", "5"] and cmd[-7].endswith("bench.py")
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    monkeypatch.undo()                                               # (bench.subprocess IS this module's subprocess)
+    # as a rank: WORLD_SIZE must equal --gpus
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2"], capture_output=True, text=True,
+                       env=dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0"), timeout=300)
+    assert r.returncode != 0 and "WORLD_SIZE=1" in (r.stdout + r.stderr)

@@ -39,6 +39,60 @@ def test_energy_fitness_gradient(name):
     assert abs(float(en.potts.wt_H) - float(np.ravel(fx["wt_H"])[0])) <= 5e-6 * max(1, abs(float(np.ravel(fx["wt_H"])[0])))
 
 
+@pytest.mark.parametrize("name", ["ops_toy24_lam5.npz", "ops_pabp_lam5.npz"])
+def test_ground_truth_model(name):
+    """AlrOracle against the reference's AugmentedLinearRegression on the synthetic ridge weights."""
+    from ppde_amd import synthetic
+    fx = load(name)
+    J, h, i0, wt_idx, _ = model_from_fixture(fx)
+    en = oracle_energy(J, h, i0, wt_idx, None, 0.0)
+    lin = [synthetic.make_linear(wt_idx.shape[0], s) for s in range(20)]
+    alr = orc.AlrOracle(en.potts, [(d["coef_"], d["intercept_"], d["reg_coef"]) for d in lin])
+    y = alr(torch.as_tensor(fx["idx"].astype(np.int64)))
+    assert np.abs(y.numpy() - fx["oracle_alr"]).max() <= 5e-6 * max(1.0, np.abs(fx["oracle_alr"]).max())
+
+
+REAL = [("real_pabp.npz", "PABP_YEAST_Fields2013"), ("real_ube4b.npz", "UBE4B_MOUSE_Klevit2013-nscor_log2_ratio"),
+        ("real_gfp.npz", "GFP_AEQVI_Sarkisyan2016")]
+REF_WEIGHTS = "/root/reference/weights"
+
+
+@pytest.mark.skipif(not os.path.isdir(REF_WEIGHTS), reason="the shipped weight files exist in the build container only")
+@pytest.mark.parametrize("name,protein", REAL)
+def test_real_shipped_weights(name, protein):
+    """The REAL onehot_cnn_seed=*.pt / *-linear.pkl / wt.fasta files of all three proteins, read by the product's
+    loaders (ppde_amd/weights.py) and evaluated by the oracle, against what the reference itself computed from those
+    files (fixture: file hashes + outputs, no weight values; synthetic couplings, the real potts.pkl is a missing blob).
+    Reads DATA files only; the reference's code is not imported here."""
+    import hashlib
+    from ppde_amd import synthetic
+    from ppde_amd.weights import load_cnn_states, load_linear, load_wt
+    fx = load(name)
+    d = os.path.join(REF_WEIGHTS, protein)
+    for f, want in zip(fx["files"], fx["file_sha"]):
+        with open(os.path.join(d, str(f)), "rb") as fh:
+            assert hashlib.sha256(fh.read()).hexdigest() == str(want), f"{f} is not the file the fixture was generated on"
+    seqs, wt_idx = load_wt(d)
+    assert np.array_equal(wt_idx[0], fx["wt_idx"])
+    Lp, i0 = int(fx["Lp"]), int(fx["win_start"])
+    J, h = synthetic.make_potts(Lp, seed=int(fx["potts_seed"]))
+    from helpers import sha
+    assert sha(J) == str(fx["J_sha"])
+    lam = float(fx["lamda"])
+    en = oracle_energy(J, h, i0, wt_idx[0], load_cnn_states(d), lam)
+    idx = torch.as_tensor(fx["idx"].astype(np.int64))
+    e, fit, g = en.energy_grad(idx)
+    gscale = max(1.0, float(np.abs(fx["grad"]).max()))
+    assert np.all(np.abs(fit.numpy() - fx["fit"]) <= 4e-6 * np.maximum(1.0, np.abs(fx["fit"])))
+    assert np.all(np.abs(e.numpy() - fx["e"]) <= etol(fx["e"]) + 4e-6 * lam * np.maximum(1.0, np.abs(fx["fit"])))
+    assert np.abs(g.numpy() - fx["grad"]).max() <= 2e-6 * max(1.0, lam) * gscale
+    f3, g3 = en.cnn.fit_grad(idx)
+    assert np.abs(g3.numpy() - fx["supervised_grad"]).max() <= 2e-6 * max(1.0, float(np.abs(fx["supervised_grad"]).max()))
+    alr = orc.AlrOracle(en.potts, load_linear(d))
+    y = alr(idx)
+    assert np.abs(y.numpy() - fx["oracle_alr"]).max() <= 5e-6 * max(1.0, np.abs(fx["oracle_alr"]).max())
+
+
 def test_wild_type_delta_is_zero():
     fx = load("ops_toy24_lam5.npz")
     J, h, i0, wt_idx, cnn = model_from_fixture(fx)
