@@ -29,6 +29,9 @@ struct PasArgs {
     // state
     uint8_t* cur;               // [n][Ls]
     uint8_t* prop;              // [n][Ls]
+    uint8_t* curT;              // T4 copies of cur / prop for the Potts kernel (potts.h), written next to the rows
+    uint8_t* propT;
+    int n_pad;
     const uint8_t* fb_state;    // fallback state rows (wild type: stride 0; initial population: stride Ls)
     int fb_state_stride;
     float* grad;                // [2][n][N]  Potts gradient (zero outside the window)
@@ -104,6 +107,13 @@ __device__ __forceinline__ RowLds carve_lds(unsigned char* base, const Geom& g) 
 }
 __host__ __device__ inline size_t pas_lds_bytes(const Geom& g) {
     return (size_t)g.N * 4 + 16 * PPDE_NW * 4 + 1024 + 2 * (size_t)((g.L + 15) & ~15);
+}
+
+// a state byte in both forms: the row (CNN, chain kernels) and, for residues of the padded Potts window, its T4 slot
+__device__ __forceinline__ void store_letter(uint8_t* rows, uint8_t* T, const Geom& g, int n_pad, int b, int l, uint8_t v) {
+    rows[(size_t)b * g.Ls + g.sh + l] = v;
+    const int wl = l - g.i0;
+    if (g.Lp > 0 && wl >= 0 && wl < 16 * g.NC) T[state_t4_offset_dev(g.NC, n_pad, b, wl)] = v;
 }
 
 __device__ __forceinline__ float clampp(float p) { return fminf(fmaxf(p, PPDE_EPS), 1.0f - PPDE_EPS); }
@@ -545,7 +555,7 @@ __device__ __forceinline__ void propose_body(const PasArgs& a, const RowLds& lds
     }
 #pragma unroll
     for (int r = 0; r < GPT; ++r)
-        if (R.valid[r] && R.kb[r] == 0) a.prop[(size_t)b * g.Ls + g.sh + R.l[r]] = (uint8_t)R.cur[r];
+        if (R.valid[r] && R.kb[r] == 0) store_letter(a.prop, a.propT, g, a.n_pad, b, R.l[r], (uint8_t)R.cur[r]);
     PPDE_STAMP(a.dbg, 19, stamp);
 }
 
@@ -733,7 +743,7 @@ __device__ __forceinline__ AcceptOut accept_body(const PasArgs& a, const RowLds&
         const uint8_t rec = (a.rec_after_reset & reset) ? w : v;
         if (better) a.best_state[(size_t)b * g.L + l] = rec;
         if (b == a.random_chain) a.rtraj[(size_t)(it + 1) * g.L + l] = rec;
-        a.cur[(size_t)b * g.Ls + g.sh + l] = reset ? w : v;
+        store_letter(a.cur, a.curT, g, a.n_pad, b, l, reset ? w : v);
     }
     if (tid == 0) {
         a.e_hist[(size_t)(it + 1) * a.n + b] = e_new;

@@ -61,6 +61,7 @@ struct ppde_model {
     Geom g{};
     std::vector<uint8_t> h_wt;       // plain [L]
     uint8_t* d_wt = nullptr;         // state layout [Ls]
+    uint32_t* d_wtT = nullptr;       // its T4 copy (potts.h), for one chain
     // Potts
     bool has_potts = false;
     float4* d_Jt = nullptr;
@@ -75,6 +76,7 @@ struct ppde_model {
     // scratch of the stateless API
     int scratch_n = 0;
     uint8_t* s_state = nullptr;
+    uint32_t* s_stateT = nullptr;
     float *s_grad = nullptr, *s_epart = nullptr, *s_gradC = nullptr, *s_fitC = nullptr;
     int* s_flag = nullptr;
     // chunk maxima of the long-sequence CNN path, sized for `cnn_scratch_n` chains
@@ -97,18 +99,42 @@ static void set_geom(ppde_model* m, int Lp, int i0) {
     if (((g.Ls >> 2) & 1) == 0) g.Ls += 4;   // odd number of dwords per row: strided LDS reads of state rows hit distinct banks
 }
 
+// A population of states as the expert kernels read it: rows in state layout (CNN, chain kernels) and the transposed
+// window letters (Potts kernel; potts.h "T4").
+struct States {
+    const uint8_t* rows;
+    const uint32_t* T;
+    int n_pad;
+};
+static int state_rows_to_t4(const ppde_model* m, const uint8_t* rows, uint32_t* T, int n, int n_pad, hipStream_t s) {
+    if (m->g.Lp <= 0 || n <= 0) return PPDE_OK;
+    const int tot = n * 16 * m->g.NC;
+    hipLaunchKernelGGL(k_state_to_t4, dim3((tot + 255) / 256), dim3(256), 0, s, rows, T, n, n_pad, m->g);
+    HIPCHK(hipGetLastError());
+    return PPDE_OK;
+}
+
 static int upload_wt(ppde_model* m) {
     if (m->d_wt) HIPCHK(hipFree(m->d_wt));
     std::vector<uint8_t> row(m->g.Ls, 0);
     for (int l = 0; l < m->L; ++l) row[m->g.sh + l] = m->h_wt[l];
     HIPCHK(dalloc(&m->d_wt, (size_t)m->g.Ls));
     HIPCHK(hipMemcpy(m->d_wt, row.data(), row.size(), hipMemcpyHostToDevice));
+    if (m->d_wtT) { hipFree(m->d_wtT); m->d_wtT = nullptr; }
+    if (m->g.Lp > 0) {
+        const size_t words = potts_t4_words(m->g.NC, potts_t4_pad(1));
+        HIPCHK(dalloc(&m->d_wtT, words));
+        HIPCHK(hipMemset(m->d_wtT, 0, words * sizeof(uint32_t)));
+        int rc = state_rows_to_t4(m, m->d_wt, m->d_wtT, 1, potts_t4_pad(1), 0);
+        if (rc) return rc;
+        HIPCHK(hipDeviceSynchronize());
+    }
     return PPDE_OK;
 }
 
 static void free_scratch(ppde_model* m) {
-    hipFree(m->s_state); hipFree(m->s_grad); hipFree(m->s_epart); hipFree(m->s_gradC); hipFree(m->s_fitC);
-    m->s_state = nullptr; m->s_grad = m->s_epart = m->s_gradC = m->s_fitC = nullptr;
+    hipFree(m->s_state); hipFree(m->s_stateT); hipFree(m->s_grad); hipFree(m->s_epart); hipFree(m->s_gradC); hipFree(m->s_fitC);
+    m->s_state = nullptr; m->s_stateT = nullptr; m->s_grad = m->s_epart = m->s_gradC = m->s_fitC = nullptr;
     m->scratch_n = 0;
 }
 
@@ -142,40 +168,42 @@ struct EventPool {
 };
 static thread_local EventPool* g_potts_events = nullptr;
 
-static int launch_potts(const ppde_model* m, const uint8_t* states, int n, const EvalTargets& t, hipStream_t s,
+static int launch_potts(const ppde_model* m, const States& st, int n, const EvalTargets& t, hipStream_t s,
                         int b_off = 0, int n_sub = -1) {
     if (n_sub < 0) n_sub = n;
     EventPool* ep = g_potts_events;
     if (ep && ep->used + 2 <= ep->ev.size()) HIPCHK(hipEventRecord(ep->ev[ep->used++], s));
     else ep = nullptr;
+    ARGCHK(st.T && st.n_pad >= n + 256, "the states have no transposed copy for the Potts kernel");
     PottsArgs a{};
     a.b_off = b_off; a.n_sub = n_sub; a.dbg = t.dbg;
-    a.Jt = m->d_Jt; a.h = m->d_h; a.idx = states; a.grad = t.grad; a.epart = t.epart;
+    a.Jt = m->d_Jt; a.h = m->d_h; a.idxT = st.T; a.n_pad = st.n_pad; a.grad = t.grad; a.epart = t.epart;
     a.slot = t.slot; a.n = n;
     a.g = m->g;
     int NG = potts_ng_for(n_sub);
     static const int ng_override = []() { const char* e = getenv("PPDE_POTTS_NG"); return e ? atoi(e) : 0; }();   // tuning knob
     if (ng_override == 1 || ng_override == 2 || ng_override == 4) NG = ng_override;
-    ARGCHK(m->g.Ls <= 512, "state rows longer than 512 bytes are not supported by the Potts kernel staging");
     static const int ring_override = []() { const char* e = getenv("PPDE_POTTS_RING"); return e ? atoi(e) : -1; }();   // tuning knob
-    const bool ring = ring_override >= 0 ? ring_override != 0 : m->g.NC > POTTS_RING_CHUNKS;   // long windows stream through a ring
+    const bool ring = ring_override >= 0 ? ring_override != 0 : m->g.NC > 8;   // long windows stream through a ring
+    const int tiles = m->g.Lp * 5;
     if (ring) {
         NG = std::min(NG, 2);
-        const size_t lds = potts_ring_lds_bytes(NG, m->g.Ls);
-        ARGCHK(lds <= 160 * 1024, "state rows too long for the Potts kernel staging");
-        dim3 grid(m->g.Lp * 5, (n_sub + NG * 64 - 1) / (NG * 64));
-        if (NG == 1) hipLaunchKernelGGL((potts_energy_grad_kernel<1, true>), grid, dim3(256), lds, s, a);
-        else hipLaunchKernelGGL((potts_energy_grad_kernel<2, true>), grid, dim3(256), lds, s, a);
+        const size_t lds = potts_ring_lds_bytes();
+        const int nby = (n_sub + NG * 64 - 1) / (NG * 64);
+        ARGCHK(m->g.NC <= 32, "Potts window longer than 512 residues");
+        const bool g4 = potts_groups(m->g.NC) <= 4;             // letters of <= 4 chunk groups per wave: 5 workgroups per CU
+        if (NG == 1 && g4) hipLaunchKernelGGL((potts_energy_grad_kernel<1, true, 4>), dim3(tiles * nby), dim3(256), lds, s, a, nby);
+        else if (NG == 1) hipLaunchKernelGGL((potts_energy_grad_kernel<1, true, 8>), dim3(tiles * nby), dim3(256), lds, s, a, nby);
+        else if (g4) hipLaunchKernelGGL((potts_energy_grad_kernel<2, true, 4>), dim3(tiles * nby), dim3(256), lds, s, a, nby);
+        else hipLaunchKernelGGL((potts_energy_grad_kernel<2, true, 8>), dim3(tiles * nby), dim3(256), lds, s, a, nby);
     } else {
-        size_t lds = potts_lds_bytes(m->g.NC, NG, m->g.Ls);
-        while (lds > 150 * 1024 && NG > 1) { NG >>= 1; lds = potts_lds_bytes(m->g.NC, NG, m->g.Ls); }
-        ARGCHK(((m->g.NC * 1280 + 1023) >> 10) <= 32, "Potts window too long for the LDS-DMA pipeline");
-        ARGCHK(lds <= 160 * 1024, "Potts window too long for one LDS slab");
-        dim3 grid(m->g.Lp * 5, (n_sub + NG * 64 - 1) / (NG * 64));
+        ARGCHK(m->g.NC <= 8, "Potts window too long for the resident-slab kernel (the ring variant takes it)");
+        const size_t lds = potts_lds_bytes(m->g.NC, NG);
+        const int nby = (n_sub + NG * 64 - 1) / (NG * 64);
         switch (NG) {
-            case 1: hipLaunchKernelGGL(potts_energy_grad_kernel<1>, grid, dim3(256), lds, s, a); break;
-            case 2: hipLaunchKernelGGL(potts_energy_grad_kernel<2>, grid, dim3(256), lds, s, a); break;
-            default: hipLaunchKernelGGL(potts_energy_grad_kernel<4>, grid, dim3(256), lds, s, a); break;
+            case 1: hipLaunchKernelGGL(potts_energy_grad_kernel<1>, dim3(tiles * nby), dim3(256), lds, s, a, nby); break;
+            case 2: hipLaunchKernelGGL(potts_energy_grad_kernel<2>, dim3(tiles * nby), dim3(256), lds, s, a, nby); break;
+            default: hipLaunchKernelGGL(potts_energy_grad_kernel<4>, dim3(tiles * nby), dim3(256), lds, s, a, nby); break;
         }
     }
     HIPCHK(hipGetLastError());
@@ -210,14 +238,14 @@ static int ensure_cnn_scratch(ppde_model* m, int n) {
     return PPDE_OK;
 }
 
-static int launch_cnn(const ppde_model* m, const uint8_t* states, int n, const EvalTargets& t, int want_grad,
+static int launch_cnn(const ppde_model* m, const States& st, int n, const EvalTargets& t, int want_grad,
                       float scale, hipStream_t s, int b_off = 0, int n_sub = -1) {
     if (n_sub < 0) n_sub = n;
     CnnArgs a{};
     a.b_off = b_off; a.dbg = t.dbg;
     for (int k = 0; k < m->n_nets; ++k) a.net[k] = m->nets[k];
     a.n_nets = m->n_nets; a.C = m->C; a.CP = m->CP; a.K = m->K; a.KT = m->KT; a.F = m->F; a.FP = m->FP; a.T = m->T; a.J = m->J; a.JP = m->JP;
-    a.idx = states; a.gradC = t.gradC; a.fitC = t.fitC;
+    a.idx = st.rows; a.gradC = t.gradC; a.fitC = t.fitC;
     a.slot = t.slot; a.n = n; a.want_grad = want_grad; a.scale = scale;
     a.g = m->g;
     if (!cnn_single_launch(m)) {
@@ -268,7 +296,7 @@ struct ExpertsArgs {
     CnnArgs c;
     PottsArgs p;
     int cnn_bx, cnn_ni;        // CNN workgroups = cnn_bx (chains) x cnn_ni (networks), first in block order
-    int potts_tiles;           // then potts_tiles x (chain blocks) Potts workgroups
+    int potts_items, potts_nby;   // then potts_items = tiles x potts_nby (chain blocks) Potts workgroups
 };
 template <int RT, int NG>
 __global__ __launch_bounds__(256, 2) void k_experts(ExpertsArgs a) {
@@ -279,36 +307,37 @@ __global__ __launch_bounds__(256, 2) void k_experts(ExpertsArgs a) {
         const int ni = w / a.cnn_bx;
         cnn_body<RT, 5>(a.c, w - ni * a.cnn_bx, ni, a.cnn_bx, a.cnn_ni, (unsigned char*)smem_experts);
     } else {
-        const int q = w - n_cnn, by = q / a.potts_tiles;
-        potts_body<NG>(a.p, q - by * a.potts_tiles, by, smem_experts);
+        const int v = xcd_contiguous(w - n_cnn, a.potts_items);
+        potts_body<NG>(a.p, v / a.potts_nby, v % a.potts_nby, smem_experts);
     }
 }
 
-static int launch_experts_fused(const ppde_model* m, const uint8_t* states, int n, const EvalTargets& t, float scale,
+static int launch_experts_fused(const ppde_model* m, const States& st, int n, const EvalTargets& t, float scale,
                                 hipStream_t s, int b_off, int n_sub, bool* done) {
     *done = false;
     static const bool enabled = []() { const char* e = getenv("PPDE_FUSE_EXPERTS"); return !e || atoi(e) != 0; }();
     const int NG = potts_ng_for(n_sub);
     if (!enabled || !cnn_single_launch(m) || m->KT != 5 || NG > 2 || g_potts_events) return PPDE_OK;
-    const size_t lds_c = cnn_lds_bytes(m->T, m->CP, m->FP, m->J, m->L), lds_p = potts_lds_bytes(m->g.NC, NG, m->g.Ls);
-    if (lds_p > lds_c || 2 * lds_c > 160 * 1024 || m->g.NC > POTTS_RING_CHUNKS) return PPDE_OK;   // (needs the free second slot)
+    const size_t lds_c = cnn_lds_bytes(m->T, m->CP, m->FP, m->J, m->L), lds_p = potts_lds_bytes(m->g.NC, NG);
+    if (lds_p > lds_c || 2 * lds_c > 160 * 1024 || m->g.NC > 8) return PPDE_OK;   // (needs the free second slot)
     ExpertsArgs a{};
     CnnArgs& c = a.c;
     c.b_off = b_off; c.dbg = t.dbg;
     for (int k = 0; k < m->n_nets; ++k) c.net[k] = m->nets[k];
     c.n_nets = m->n_nets; c.C = m->C; c.CP = m->CP; c.K = m->K; c.KT = m->KT; c.F = m->F; c.FP = m->FP; c.T = m->T; c.J = m->J; c.JP = m->JP;
-    c.idx = states; c.gradC = t.gradC; c.fitC = t.fitC;
+    c.idx = st.rows; c.gradC = t.gradC; c.fitC = t.fitC;
     c.slot = t.slot; c.n = n; c.want_grad = 1; c.scale = scale;
     c.g = m->g;
     PottsArgs& p = a.p;
     p.b_off = b_off; p.n_sub = n_sub; p.dbg = t.dbg;
-    p.Jt = m->d_Jt; p.h = m->d_h; p.idx = states; p.grad = t.grad; p.epart = t.epart;
+    p.Jt = m->d_Jt; p.h = m->d_h; p.idxT = st.T; p.n_pad = st.n_pad; p.grad = t.grad; p.epart = t.epart;
     p.slot = t.slot; p.n = n;
     p.g = m->g;
     a.cnn_bx = n_sub; a.cnn_ni = m->n_nets;
-    a.potts_tiles = m->g.Lp * 5;
     const int CPB = NG * 64;
-    const dim3 grid(a.cnn_bx * a.cnn_ni + a.potts_tiles * ((n_sub + CPB - 1) / CPB));
+    a.potts_nby = (n_sub + CPB - 1) / CPB;
+    a.potts_items = m->g.Lp * 5 * a.potts_nby;
+    const dim3 grid(a.cnn_bx * a.cnn_ni + a.potts_items);
 #define PPDE_EX(RTV)                                                                              \
     if (NG == 1) hipLaunchKernelGGL((k_experts<RTV, 1>), grid, dim3(256), lds_c, s, a);            \
     else hipLaunchKernelGGL((k_experts<RTV, 2>), grid, dim3(256), lds_c, s, a);
@@ -328,7 +357,7 @@ static int launch_experts_fused(const ppde_model* m, const uint8_t* states, int 
     return PPDE_OK;
 }
 
-static int eval_experts(const ppde_model* m, int which, const uint8_t* states, int n, const EvalTargets& t,
+static int eval_experts(const ppde_model* m, int which, const States& states, int n, const EvalTargets& t,
                         int want_grad, hipStream_t s, int b_off = 0, int n_sub = -1) {
     if ((which & 3) == 3 && want_grad && m->has_potts && m->has_cnn) {
         bool done = false;
@@ -389,7 +418,7 @@ int ppde_model_destroy(ppde_model* m) {
     hipSetDevice(m->device);
     free_scratch(m);
     hipFree(m->s_flag);
-    hipFree(m->d_wt); hipFree(m->d_Jt); hipFree(m->d_h); hipFree(m->cnn_cmax); hipFree(m->cnn_carg); hipFree(m->cnn_cgate);
+    hipFree(m->d_wt); hipFree(m->d_wtT); hipFree(m->d_Jt); hipFree(m->d_h); hipFree(m->cnn_cmax); hipFree(m->cnn_carg); hipFree(m->cnn_cgate);
     for (void* p : m->cnn_allocs) hipFree(p);
     delete m;
     return PPDE_OK;
@@ -431,7 +460,7 @@ int ppde_model_set_potts(ppde_model* m, const float* J, const float* h, int Lp, 
     HIPCHK(ep.alloc<float>((size_t)Lp));
     HIPCHK(e.alloc<float>(1));
     EvalTargets t{grad.as<float>(), ep.as<float>(), nullptr, nullptr, 0};
-    rc = launch_potts(m, m->d_wt, 1, t, 0);
+    rc = launch_potts(m, States{m->d_wt, m->d_wtT, potts_t4_pad(1)}, 1, t, 0);
     if (rc) return rc;
     hipLaunchKernelGGL(potts_energy_finalize_kernel, dim3(1), dim3(64), 0, 0, ep.as<float>(), Lp, 0.0f, e.as<float>(), 1);
     HIPCHK(hipGetLastError());
@@ -521,6 +550,11 @@ static int ensure_scratch(ppde_model* m, int n) {
     free_scratch(m);
     const Geom& g = m->g;
     HIPCHK(dalloc(&m->s_state, (size_t)n * g.Ls));
+    if (g.Lp > 0) {
+        const size_t words = potts_t4_words(g.NC, potts_t4_pad(n));
+        HIPCHK(dalloc(&m->s_stateT, words));
+        HIPCHK(hipMemset(m->s_stateT, 0, words * sizeof(uint32_t)));
+    }
     HIPCHK(dalloc(&m->s_grad, (size_t)n * g.N));
     HIPCHK(hipMemset(m->s_grad, 0, (size_t)n * g.N * sizeof(float)));
     HIPCHK(dalloc(&m->s_epart, (size_t)n * std::max(g.Lp, 1)));
@@ -573,10 +607,12 @@ int ppde_energy_grad(ppde_model* m, const uint8_t* idx_dev, int n, int which, fl
     const Geom& g = m->g;
     hipLaunchKernelGGL(k_pack_state, dim3((n * g.Ls + 255) / 256), dim3(256), 0, s, idx_dev, m->s_state, n, g.L, g.Ls, g.sh);
     HIPCHK(hipGetLastError());
+    const States st{m->s_state, m->s_stateT, potts_t4_pad(m->scratch_n)};
+    if ((which & 1) && (rc = state_rows_to_t4(m, m->s_state, m->s_stateT, n, st.n_pad, s))) return rc;
     EvalTargets t{m->s_grad, m->s_epart, m->s_gradC, m->s_fitC, 0};
     t.cmax = m->cnn_cmax; t.carg = m->cnn_carg; t.cgate = m->cnn_cgate; t.cnn_cap = m->cnn_scratch_n;
     // the scratch is laid out for scratch_n chains; kernels index slot 0 with stride n, which is fine for slot 0
-    rc = eval_experts(m, which, m->s_state, n, t, grad_dev != nullptr, s);
+    rc = eval_experts(m, which, st, n, t, grad_dev != nullptr, s);
     if (rc) return rc;
     PasArgs a = base_pas_args(m, which, n);
     a.grad = m->s_grad; a.epart = m->s_epart; a.gradC = m->s_gradC; a.fitC = m->s_fitC;
@@ -605,6 +641,8 @@ struct ppde_chains {
     int n = 0, T = 0, mu_max = 1, steps_done = 0;
     bool initialised = false;
     // device buffers
+    uint32_t *curT = nullptr, *propT = nullptr;  // T4 copies of cur / prop (potts.h), n_pad chains per row
+    int n_pad = 0;
     uint8_t *cur = nullptr, *prop = nullptr, *fb_state = nullptr, *best_state = nullptr,
             *rtraj = nullptr, *tmp_acc = nullptr, *tr_acc = nullptr, *tmp_idx = nullptr;
     unsigned char* rec = nullptr;                // [n] chain records
@@ -640,6 +678,7 @@ static PasArgs chain_args(const ppde_chains* c) {
     a.key.k1 = (uint32_t)(c->cfg.seed >> 32) ^ (uint32_t)(c->cfg.chain_offset >> 32);
     a.key.chain_lo = (uint32_t)c->cfg.chain_offset;
     a.cur = c->cur; a.prop = c->prop; a.fb_state = c->fb_state;
+    a.curT = (uint8_t*)c->curT; a.propT = (uint8_t*)c->propT; a.n_pad = c->n_pad;
     a.fb_state_stride = c->cfg.paper_results ? m->g.Ls : 0;
     a.grad = c->grad; a.epart = c->epart; a.gradC = c->gradC; a.fitC = c->fitC;
     a.grad_cur = c->grad_cur; a.rec = c->rec; a.rec_stride = c->rec_stride; a.wt_e = c->wt_e; a.wt_f = c->wt_f;
@@ -651,6 +690,8 @@ static PasArgs chain_args(const ppde_chains* c) {
     return a;
 }
 
+static States cur_states(const ppde_chains* c) { return States{c->cur, c->curT, c->n_pad}; }
+static States prop_states(const ppde_chains* c) { return States{c->prop, c->propT, c->n_pad}; }
 static EvalTargets chain_targets(const ppde_chains* c, int slot) {
     EvalTargets t{c->grad, c->epart, c->gradC, c->fitC, slot, c->dbg};
     t.cmax = c->cnn_cmax; t.carg = c->cnn_carg; t.cgate = c->cnn_cgate; t.cnn_cap = c->n;
@@ -692,7 +733,7 @@ static int enqueue_iterations(ppde_chains* c, int k, const int* it_base, int fir
     for (int i = 0; i < count; ++i) {
         a.it_local = first_local + i;
         if (!c->cfg.reuse_grad) {   // energy and gradient at the current state (ppde.py:79)
-            rc = eval_experts(m, c->cfg.which, c->cur, c->n, chain_targets(c, 0), 1, s, b_off, n_sub);
+            rc = eval_experts(m, c->cfg.which, cur_states(c), c->n, chain_targets(c, 0), 1, s, b_off, n_sub);
             if (rc) return rc;
         }
         if (!fuse || i == 0) {
@@ -700,7 +741,7 @@ static int enqueue_iterations(ppde_chains* c, int k, const int* it_base, int fir
             if (rc) return rc;
         }
         // energy and gradient at the proposal (ppde.py:119)
-        rc = eval_experts(m, c->cfg.which, c->prop, c->n, chain_targets(c, 1), 1, s, b_off, n_sub);
+        rc = eval_experts(m, c->cfg.which, prop_states(c), c->n, chain_targets(c, 1), 1, s, b_off, n_sub);
         if (rc) return rc;
         rc = launch_chain_kernel(c, (fuse && i + 1 < count) ? KP_ACCEPT_PROPOSE : KP_ACCEPT, a, n_sub, s);
         if (rc) return rc;
@@ -793,6 +834,8 @@ int ppde_chains_create(ppde_chains** out, ppde_model* m, const ppde_chain_config
         if (zero && hipMemset((void*)*p, 0, std::max<size_t>(count, 1) * sizeof(**p)) != hipSuccess) ok = false;
     };
     A(&c->cur, n * g.Ls, true); A(&c->prop, n * g.Ls, true);
+    c->n_pad = potts_t4_pad(c->n);
+    A(&c->curT, g.Lp > 0 ? potts_t4_words(g.NC, c->n_pad) : 1, true); A(&c->propT, g.Lp > 0 ? potts_t4_words(g.NC, c->n_pad) : 1, true);
     A(&c->fb_state, (cfg->paper_results ? n : 1) * g.Ls, true);
     c->rec_stride = chain_rec_stride(c->mu_max);
     A(&c->rec, n * c->rec_stride, true);
@@ -861,14 +904,15 @@ int ppde_chains_init(ppde_chains* c, const uint8_t* idx0_dev) {
     const int n = c->n;
     hipLaunchKernelGGL(k_pack_state, dim3((n * g.Ls + 255) / 256), dim3(256), 0, s, idx0_dev, c->cur, n, g.L, g.Ls, g.sh);
     HIPCHK(hipGetLastError());
+    int rc = state_rows_to_t4(m, c->cur, c->curT, n, c->n_pad, s);
+    if (rc) return rc;
     HIPCHK(hipMemsetAsync(c->err_flag, 0, sizeof(int), s));
     HIPCHK(hipMemsetAsync(c->d_it, 0, sizeof(int), s));
     PasArgs a = chain_args(c);
-    int rc;
     if (c->cfg.reuse_grad || c->cfg.paper_results) {
         // fallback rows: the wild type (mutation-cap reset) or the initial population (paper_results)
         const int nf = c->cfg.paper_results ? n : 1;
-        const uint8_t* fstates = c->cfg.paper_results ? c->cur : m->d_wt;
+        const States fstates = c->cfg.paper_results ? cur_states(c) : States{m->d_wt, m->d_wtT, potts_t4_pad(1)};
         if (c->cfg.paper_results) HIPCHK(hipMemcpyAsync(c->fb_state, c->cur, (size_t)n * g.Ls, hipMemcpyDeviceToDevice, s));
         else HIPCHK(hipMemcpyAsync(c->fb_state, m->d_wt, (size_t)g.Ls, hipMemcpyDeviceToDevice, s));
         if (c->cfg.reuse_grad) {
@@ -893,7 +937,7 @@ int ppde_chains_init(ppde_chains* c, const uint8_t* idx0_dev) {
         a.wt_e = c->wt_e; a.wt_f = c->wt_f;
     }
     // energies (and, when gradients are reused, the gradient) of the initial population -> slot 0
-    rc = eval_experts(m, c->cfg.which, c->cur, n, chain_targets(c, 0), 1, s);
+    rc = eval_experts(m, c->cfg.which, cur_states(c), n, chain_targets(c, 0), 1, s);
     if (rc) return rc;
     hipLaunchKernelGGL(k_init_chain, dim3((n + 3) / 4), dim3(256), 0, s, a);
     HIPCHK(hipGetLastError());
@@ -1107,11 +1151,11 @@ int ppde_chains_time_potts_kernel(ppde_chains* c, int reps, float* avg_us) {
     hipEvent_t e0 = ev.a, e1 = ev.b;
     // writes the proposal slot, exactly as the launch inside an iteration does
     EvalTargets t = chain_targets(c, 1);
-    int rc = launch_potts(c->m, c->cur, c->n, t, c->stream);   // warm
+    int rc = launch_potts(c->m, cur_states(c), c->n, t, c->stream);   // warm
     if (rc) return rc;
     HIPCHK(hipEventRecord(e0, c->stream));
     for (int i = 0; i < reps; ++i) {
-        rc = launch_potts(c->m, c->cur, c->n, t, c->stream);
+        rc = launch_potts(c->m, cur_states(c), c->n, t, c->stream);
         if (rc) return rc;
     }
     HIPCHK(hipEventRecord(e1, c->stream));

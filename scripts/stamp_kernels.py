@@ -13,7 +13,8 @@ import torch
 from ppde_amd import build as B, _hip
 
 dbg = os.path.join(REPO, "ppde_amd", "libppde_hip_dbg.so")
-B.build(force=True, extra=["-DPPDE_STAMPS"], out=dbg)
+if not os.path.exists(dbg) or any(os.path.getmtime(d) > os.path.getmtime(dbg) for d in B.DEPS):
+    B.build(force=True, extra=["-DPPDE_STAMPS"], out=dbg)        # (cross-compiles in the build container; the .so travels)
 _hip.LIB_PATH = dbg
 from bench import build_model
 from ppde_amd.sampler import Chains
