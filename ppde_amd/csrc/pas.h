@@ -116,6 +116,11 @@ __device__ __forceinline__ void store_letter(uint8_t* rows, uint8_t* T, const Ge
     if (g.Lp > 0 && wl >= 0 && wl < 16 * g.NC) T[state_t4_offset_dev(g.NC, n_pad, b, wl)] = v;
 }
 
+// the error word lives in host memory mapped into the device (ppde_api.hip): system scope, error paths only
+__device__ __forceinline__ void flag_error(int* flag, int bits) {
+    __hip_atomic_fetch_or(flag, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 __device__ __forceinline__ float clampp(float p) { return fminf(fmaxf(p, PPDE_EPS), 1.0f - PPDE_EPS); }
 
 // Gradient row of one chain = Potts row + the CNN networks' rows (summed in this fixed order), or one
@@ -263,21 +268,29 @@ __device__ __forceinline__ void load_row(const RowLds& lds, const Geom& g, const
 }
 
 // ---- reduction 1 of a sub-step: logits z (registers) -> (m, S1) with m = max z, S1 = sum exp(z - m).
-// Each wave reduces against its own maximum; the NW (max, sum) pairs are merged after ONE barrier as
-// S1 = sum_w s_w * exp(m_w - m) by lanes 0..NW-1 of every wave (same tree everywhere).
+// Each wave reduces against its own maximum m_w; the NW (max, sum) pairs are merged after ONE barrier as
+// S1 = sum_w s_w * exp(m_w - m) by lanes 0..NW-1 of every wave (same tree everywhere). The per-element exponentials
+// e = exp(z - m_w) stay in registers: exp(z - m) = e * exp(m_w - m), and `scale` returns this wave's exp(m_w - m), so
+// the normalisation pass multiplies instead of evaluating expf a second time.
+__device__ __forceinline__ float my_wave_entry(float v) {        // lane w holds wave w's value: every lane gets its own wave's
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6))));
+}
 template <int GPT>
 __device__ __forceinline__ void row_max_sumexp(const RowLds& lds, const float4 (&z)[GPT], const bool (&valid)[GPT],
-                                               float& m, float& S1) {
+                                               float4 (&e)[GPT], float& m, float& S1, float& scale) {
     float lm = -INFINITY;
 #pragma unroll
     for (int r = 0; r < GPT; ++r)
         if (valid[r]) lm = fmaxf(fmaxf(lm, fmaxf(z[r].x, z[r].y)), fmaxf(z[r].z, z[r].w));
     const float mw = wave_max(lm);
     float s = 0.f;
-    if (mw != -INFINITY) {
 #pragma unroll
-        for (int r = 0; r < GPT; ++r)
-            if (valid[r]) { s += expf(z[r].x - mw); s += expf(z[r].y - mw); s += expf(z[r].z - mw); s += expf(z[r].w - mw); }
+    for (int r = 0; r < GPT; ++r) {
+        e[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (valid[r] && mw != -INFINITY) {
+            e[r].x = expf(z[r].x - mw); e[r].y = expf(z[r].y - mw); e[r].z = expf(z[r].z - mw); e[r].w = expf(z[r].w - mw);
+            s += e[r].x; s += e[r].y; s += e[r].z; s += e[r].w;
+        }
     }
     const float sw = wave_sum(s);
     const int lane = threadIdx.x & 63;
@@ -287,15 +300,16 @@ __device__ __forceinline__ void row_max_sumexp(const RowLds& lds, const float4 (
     const float sj = lane < PPDE_NW ? lds.xa[2 * (lane & (PPDE_NW - 1)) + 1] : 0.f;
     static_assert(PPDE_NW == 4 || PPDE_NW == 8 || PPDE_NW == 16, "the cross-wave merges cover 4, 8 or 16 waves");
     m = row8_max(mj);
-    const float term = (mj == -INFINITY) ? 0.f : sj * expf(mj - m);
-    S1 = row8_sum(term);
+    const float ex = (mj == -INFINITY) ? 0.f : expf(mj - m);
+    S1 = row8_sum(sj * ex);
+    scale = my_wave_entry(ex);
 }
 
 // The same for NR independent rows at once (the reverse path): per row the operations and their order are those
 // of row_max_sumexp, so the results are bit-identical; the rows share the barrier and overlap their chains.
 template <int GPT, int NR>
 __device__ __forceinline__ void row_max_sumexp_batch(const RowLds& lds, const float4 (&z)[NR][GPT], const bool (&valid)[GPT],
-                                                     float (&m)[NR], float (&S1)[NR]) {
+                                                     float4 (&e)[NR][GPT], float (&m)[NR], float (&S1)[NR], float (&scale)[NR]) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     float mw[NR], sw[NR];
 #pragma unroll
@@ -311,8 +325,14 @@ __device__ __forceinline__ void row_max_sumexp_batch(const RowLds& lds, const fl
         float sm = 0.f;
         const float mref = mw[j] != -INFINITY ? mw[j] : 0.f;    // (an all-masked wave contributes exp(-inf) = 0 terms)
 #pragma unroll
-        for (int r = 0; r < GPT; ++r)
-            if (valid[r]) { sm += expf(z[j][r].x - mref); sm += expf(z[j][r].y - mref); sm += expf(z[j][r].z - mref); sm += expf(z[j][r].w - mref); }
+        for (int r = 0; r < GPT; ++r) {
+            e[j][r] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (valid[r]) {
+                e[j][r].x = expf(z[j][r].x - mref); e[j][r].y = expf(z[j][r].y - mref);
+                e[j][r].z = expf(z[j][r].z - mref); e[j][r].w = expf(z[j][r].w - mref);
+                sm += e[j][r].x; sm += e[j][r].y; sm += e[j][r].z; sm += e[j][r].w;
+            }
+        }
         sw[j] = wave_sum(sm);
     }
     if (lane == 0) {
@@ -326,8 +346,9 @@ __device__ __forceinline__ void row_max_sumexp_batch(const RowLds& lds, const fl
         const float mj = lane < PPDE_NW ? lds.xa[2 * (wj * PAS_SB + j)] : -INFINITY;
         const float sj = lane < PPDE_NW ? lds.xa[2 * (wj * PAS_SB + j) + 1] : 0.f;
         m[j] = row8_max(mj);
-        const float term = (mj == -INFINITY) ? 0.f : sj * expf(mj - m[j]);
-        S1[j] = row8_sum(term);
+        const float ex = (mj == -INFINITY) ? 0.f : expf(mj - m[j]);
+        S1[j] = row8_sum(sj * ex);
+        scale[j] = my_wave_entry(ex);
     }
 }
 
@@ -351,19 +372,20 @@ __device__ __forceinline__ void reverse_rows(const RowLds& lds, RowRegs<GPT>& R,
             z[j][r] = make_float4((gv.x - gc) * 0.5f, (gv.y - gc) * 0.5f, (gv.z - gc) * 0.5f, (gv.w - gc) * 0.5f);
         }
     }
-    float m[NR], S1[NR], lse[NR], mp[NR], inv[NR], s3w[NR];
-    row_max_sumexp_batch<GPT, NR>(lds, z, R.valid, m, S1);
+    float m[NR], S1[NR], sc[NR], inv[NR], s3w[NR];
+    float4 e[NR][GPT];
+    row_max_sumexp_batch<GPT, NR>(lds, z, R.valid, e, m, S1, sc);
 #pragma unroll
     for (int j = 0; j < NR; ++j) {
-        lse[j] = logf(S1[j]) + m[j];
-        mp[j] = m[j] - lse[j];
+        // softmax -> clamp (ppde/utils.py:106-111): p = clamp(exp(z - m) / S1) with exp(z - m) = e * exp(m_w - m)
         inv[j] = 1.0f / S1[j];
+        const float c = sc[j] * inv[j];
         float s3 = 0.f;
 #pragma unroll
         for (int r = 0; r < GPT; ++r) {
             if (!R.valid[r]) continue;
-            s3 += clampp(expf((z[j][r].x - lse[j]) - mp[j]) * inv[j]); s3 += clampp(expf((z[j][r].y - lse[j]) - mp[j]) * inv[j]);
-            s3 += clampp(expf((z[j][r].z - lse[j]) - mp[j]) * inv[j]); s3 += clampp(expf((z[j][r].w - lse[j]) - mp[j]) * inv[j]);
+            s3 += clampp(e[j][r].x * c); s3 += clampp(e[j][r].y * c);
+            s3 += clampp(e[j][r].z * c); s3 += clampp(e[j][r].w * c);
         }
         s3w[j] = wave_sum(s3);
     }
@@ -376,7 +398,7 @@ __device__ __forceinline__ void reverse_rows(const RowLds& lds, RowRegs<GPT>& R,
     for (int j = 0; j < NR; ++j) {
         // probability of the recorded move under the reverse proposal: its residue now holds letter ks, so the
         // logit is (g[win] - g[win]) / 2 = 0 exactly
-        const float pwin = clampp(expf((0.f - lse[j]) - mp[j]) * inv[j]);
+        const float pwin = clampp(expf(0.f - m[j]) * inv[j]);
         const float S3 = row8_sum(lane < PPDE_NW ? lds.xb[8 * (lane & (PPDE_NW - 1)) + j] : 0.f);
         const float logp_rev = logf(clampp(pwin / S3));
         log_ratio += logp_rev - lpf[s0 + j];
@@ -448,7 +470,7 @@ __device__ __forceinline__ void propose_body(const PasArgs& a, const RowLds& lds
     const float* G = (const float*)lds.G;
     const int Ub = __builtin_amdgcn_readfirstlane(pp.Ub);
     // a supplied path length beyond the supplied noise block (rng_mode 0): flagged, never read past the block
-    if (tid == 0 && pp.Uraw > a.mu_cap) atomicOr(a.err_flag, 2);
+    if (tid == 0 && pp.Uraw > a.mu_cap) flag_error(a.err_flag, 2);
     float4 q[GPT];
 #pragma unroll
     for (int r = 0; r < GPT; ++r) q[r] = pp.q0[r];
@@ -461,68 +483,90 @@ __device__ __forceinline__ void propose_body(const PasArgs& a, const RowLds& lds
 #pragma unroll
         for (int r = 0; r < GPT; ++r) z[r] = forward_logits(a, G, R.gv[r], R.l[r], R.kb[r], R.cur[r], R.wt[r], capped);
         PPDE_STAMP(a.dbg, 10 + 4 * min(s, 1), stamp);
-        float m, S1;
-        row_max_sumexp<GPT>(lds, z, R.valid, m, S1);
+        float m, S1, scale;
+        float4 e[GPT];
+        row_max_sumexp<GPT>(lds, z, R.valid, e, m, S1, scale);
         if (tid == 0 && s > 0) lds.St[pend_l] = (uint8_t)pend_k;   // every wave has left the previous sub-step
         PPDE_STAMP(a.dbg, 11 + 4 * min(s, 1), stamp);
         if (m == -INFINITY) {                       // no admissible move: the reference raises ValueError here
-            if (tid == 0) atomicOr(a.err_flag, 1);
+            if (tid == 0) flag_error(a.err_flag, 1);
             m = 0.f; S1 = 1.f;
         }
         // next sub-step's race variates: state independent, so the Philox + log chains overlap with pass 2
         float4 qn[GPT];
         if (s + 1 < Ub) race_variates<GPT>(a, b, it, s + 1, qn);
-        // ---- z - logsumexp -> softmax -> clamp (ppde/utils.py:106-111), exponential race argmax p / q, and the
-        //      clamped row sum S3, in one pass + one barrier. Race values are >= 0, so their bit patterns order
-        //      like the floats: key = (bits << 32) | (~index << 1 | masked) picks the largest value, then the smallest index.
-        const float lse = logf(S1) + m;
-        const float mp = m - lse;
-        const float inv = 1.0f / S1;
-        float s3 = 0.f;
-        unsigned long long key = 0;
+        // ---- softmax -> clamp (ppde/utils.py:106-111): p = clamp(exp(z - m) / S1), exp(z - m) = e * exp(m_w - m); the
+        //      exponential race arg-max of p / q (torch.multinomial) and the clamped row sum S3 in one pass + one
+        //      barrier. Each thread keeps its best entry (value, flat index, probability; strict > in index order: the
+        //      first index wins a tie), the wave its best lane, the workgroup its best wave.
+        const float c = scale * (1.0f / S1);
+        float s3 = 0.f, bv = -1.f, bp = 0.f;
+        int bi = 0;
 #pragma unroll
         for (int r = 0; r < GPT; ++r) {
             if (!R.valid[r]) continue;
-            const unsigned int g4 = tid + r * PPDE_BLOCK;
+            const int g4 = tid + r * PPDE_BLOCK;
             float4 p;
-            p.x = clampp(expf((z[r].x - lse) - mp) * inv); p.y = clampp(expf((z[r].y - lse) - mp) * inv);
-            p.z = clampp(expf((z[r].z - lse) - mp) * inv); p.w = clampp(expf((z[r].w - lse) - mp) * inv);
+            p.x = clampp(e[r].x * c); p.y = clampp(e[r].y * c); p.z = clampp(e[r].z * c); p.w = clampp(e[r].w * c);
             s3 += p.x; s3 += p.y; s3 += p.z; s3 += p.w;
-            // low word: (2^31 - 1 - index) << 1 | [entry is masked]; the flag rides along for the winner's log-probability
-            const unsigned int lo0 = (0x7fffffffu - 4 * g4) << 1;
-            key = umax64(key, ((unsigned long long)__float_as_uint(p.x / q[r].x) << 32) | ((lo0 - 0) | (z[r].x == -INFINITY ? 1u : 0u)));
-            key = umax64(key, ((unsigned long long)__float_as_uint(p.y / q[r].y) << 32) | ((lo0 - 2) | (z[r].y == -INFINITY ? 1u : 0u)));
-            key = umax64(key, ((unsigned long long)__float_as_uint(p.z / q[r].z) << 32) | ((lo0 - 4) | (z[r].z == -INFINITY ? 1u : 0u)));
-            key = umax64(key, ((unsigned long long)__float_as_uint(p.w / q[r].w) << 32) | ((lo0 - 6) | (z[r].w == -INFINITY ? 1u : 0u)));
+            const float vx = p.x * __builtin_amdgcn_rcpf(q[r].x), vy = p.y * __builtin_amdgcn_rcpf(q[r].y);
+            const float vz = p.z * __builtin_amdgcn_rcpf(q[r].z), vw = p.w * __builtin_amdgcn_rcpf(q[r].w);
+            if (vx > bv) { bv = vx; bi = 4 * g4; bp = p.x; }
+            if (vy > bv) { bv = vy; bi = 4 * g4 + 1; bp = p.y; }
+            if (vz > bv) { bv = vz; bi = 4 * g4 + 2; bp = p.z; }
+            if (vw > bv) { bv = vw; bi = 4 * g4 + 3; bp = p.w; }
         }
         const float s3w = wave_sum(s3);
-        key = wave_max_u64(key);
-        if (lane == 0) {
-            float* e = lds.xb + 8 * (tid >> 6);
-            e[0] = s3w; e[1] = __uint_as_float((unsigned int)(key >> 32)); e[2] = __uint_as_float((unsigned int)key);
+        {
+            const float vmax = wave_max(bv);
+            unsigned long long tie = __ballot(bv == vmax);
+            if (__popcll(tie) > 1) {                // exact tie between lanes: the smallest flat index wins
+                int mi = (bv == vmax) ? bi : 0x7fffffff;
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) mi = min(mi, __shfl_xor(mi, o));
+                tie = __ballot(bv == vmax && bi == mi);
+            }
+            const int L = __builtin_amdgcn_readfirstlane(__ffsll((long long)tie) - 1);
+            const int wi = __builtin_amdgcn_readlane(bi, L);
+            const float wp = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, bp), L));
+            if (lane == 0) {
+                float* x = lds.xb + 8 * (tid >> 6);
+                x[0] = s3w; x[1] = vmax; x[2] = __int_as_float(wi); x[3] = wp;
+            }
         }
         __syncthreads();
+        int win;
+        float pwin;
         {
-            const float* e = lds.xb + 8 * (lane & (PPDE_NW - 1));
-            s3 = row8_sum(lane < PPDE_NW ? e[0] : 0.f);
-            key = lane < PPDE_NW ? (((unsigned long long)__float_as_uint(e[1]) << 32) | __float_as_uint(e[2])) : 0ull;
-            key = row8_max_u64(key);
+            const float* x = lds.xb + 8 * (lane & (PPDE_NW - 1));
+            s3 = row8_sum(lane < PPDE_NW ? x[0] : 0.f);
+            const float v8 = lane < PPDE_NW ? x[1] : -1.f;
+            const int i8 = lane < PPDE_NW ? __float_as_int(x[2]) : 0x7fffffff;
+            const float p8 = x[3];
+            const float vm = row8_max(v8);
+            unsigned long long tie = __ballot(lane < PPDE_NW && v8 == vm);
+            if (__popcll(tie) > 1) {
+                int mi = (lane < PPDE_NW && v8 == vm) ? i8 : 0x7fffffff;
+#pragma unroll
+                for (int o = 1; o < PPDE_NW; o <<= 1) mi = min(mi, __shfl_xor(mi, o));
+                mi = __builtin_amdgcn_readfirstlane(mi);
+                tie = __ballot(lane < PPDE_NW && v8 == vm && i8 == mi);
+            }
+            const int W = __builtin_amdgcn_readfirstlane(__ffsll((long long)tie) - 1);
+            win = min(__builtin_amdgcn_readlane(i8, W), g.N - 1);
+            pwin = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, p8), W));
         }
         PPDE_STAMP(a.dbg, 12 + 4 * min(s, 1), stamp);
-        const bool masked = ((unsigned int)key & 1u) != 0u;
-        const int win = min((int)(0x7fffffffu - ((unsigned int)key >> 1)), g.N - 1);
         const int ls = win / 20, ks = win - 20 * ls;
         // letter being replaced (lds.St follows the path: the previous move was applied behind this sub-step's
         // first barrier)
         const int old = lds.St[ls];
         const int wl = lds.Wt[ls];
-        // probability of the winner, recomputed by everyone exactly as its owner computed it. The masks matter: a
-        // masked entry keeps probability 2^-23 after the clamp (ppde/utils.py:106-111), so it CAN win the race (about
-        // once per 10^4 draws with a narrow proposal range) and its forward log-probability is log(2^-23 / S3).
-        // (the owner's mask flag came with the key)
-        const float zz = masked ? -INFINITY : (G[win] - G[ls * 20 + old]) * 0.5f;
-        const float pwin = clampp(expf((zz - lse) - mp) * inv);
-        const float logp = logf(clampp(pwin / s3));   // Categorical.log_prob = log(clamp(p_hat))
+        // forward log-probability of the winner, Categorical.log_prob = log(clamp(p_hat)), p_hat = p / S3 with the
+        // winner's own clamped p (a masked entry keeps 2^-23 after the clamp, ppde/utils.py:106-111, so it CAN win the
+        // race, about once per 10^4 draws with a narrow proposal range). Only the first wave needs it: thread 0 records it.
+        float logp = 0.f;
+        if (tid < 64) logp = logf(clampp(pwin / s3));
 
         // ---- apply the substitution (l*, k*) to the register copies and log it for later sub-steps
 #pragma unroll

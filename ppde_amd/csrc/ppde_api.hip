@@ -651,6 +651,8 @@ struct ppde_chains {
     float *grad_cur = nullptr, *grad = nullptr, *epart = nullptr, *gradC = nullptr, *fitC = nullptr,
           *fb_grad = nullptr, *fb_e = nullptr, *fb_f = nullptr, *e_hist = nullptr,
           *f_hist = nullptr, *tmp_be = nullptr, *tmp_bf = nullptr, *tr_logacc = nullptr;
+    int* h_err = nullptr;                        // pinned, device-mapped host word behind err_flag: the sync reads it without a copy
+    long long d_it_val = -1;                     // value the device iteration counter holds (-1: unknown)
     int *tmp_bt = nullptr, *tr_flat = nullptr, *tr_U = nullptr, *err_flag = nullptr,
         *d_it = nullptr, *tmp_dist = nullptr;
     unsigned long long* dbg = nullptr;           // stamps of the diagnostic build (64 x (cycles, 100 MHz ticks))
@@ -782,6 +784,7 @@ static int capture_segment(ppde_chains* c, int len, bool inside_run) {
         if (rc) return rc;
         return fail(PPDE_ERR_HIP, std::string("hipGraph capture: ") + hipGetErrorString(e));
     }
+    hipGraphUpload(gs.exec, c->stream);              // (best effort: the first replay then finds the graph on the device)
     gs.len = len;
     c->graphs.push_back(gs);
     c->n_captures++;
@@ -853,7 +856,12 @@ int ppde_chains_create(ppde_chains** out, ppde_model* m, const ppde_chain_config
     A(&c->fb_e, cfg->paper_results ? n : 1, true); A(&c->fb_f, cfg->paper_results ? n : 1, true);
     A(&c->e_hist, T1 * n, true); A(&c->f_hist, T1 * n, true);
     A(&c->tmp_be, n, true); A(&c->tmp_bf, n, true); A(&c->tmp_bt, n, true);
-    A(&c->err_flag, 1, true); A(&c->d_it, 1, true); A(&c->dbg, PPDE_DBG_WORDS, true);
+    A(&c->d_it, 1, true); A(&c->dbg, PPDE_DBG_WORDS, true);
+    // error word in pinned host memory mapped into the device: kernels set it with system-scope atomics (error paths
+    // only), ppde_chains_sync reads it after the stream has drained, without a device-to-host copy
+    if (ok && (hipHostMalloc((void**)&c->h_err, sizeof(int), hipHostMallocMapped) != hipSuccess ||
+               hipHostGetDevicePointer((void**)&c->err_flag, c->h_err, 0) != hipSuccess)) ok = false;
+    if (ok) *c->h_err = 0;
     if (cfg->trace) {
         A(&c->tr_flat, (size_t)c->T * c->mu_max * n, true); A(&c->tr_acc, (size_t)c->T * n, true);
         A(&c->tr_logacc, (size_t)c->T * n, true); A(&c->tr_U, (size_t)c->T * n, true);
@@ -870,6 +878,7 @@ int ppde_chains_create(ppde_chains** out, ppde_model* m, const ppde_chain_config
     }
     if (!ok) {
         for (void* p : c->allocs) hipFree(p);
+        if (c->h_err) hipHostFree(c->h_err);
         for (hipStream_t st : c->streams) if (st) hipStreamDestroy(st);
         for (hipEvent_t ev : c->events) if (ev) hipEventDestroy(ev);
         delete c;
@@ -889,6 +898,7 @@ int ppde_chains_destroy(ppde_chains* c) {
         if (gs.graph) hipGraphDestroy(gs.graph);
     }
     for (void* p : c->allocs) hipFree(p);
+    if (c->h_err) hipHostFree(c->h_err);
     for (hipStream_t st : c->streams) if (st) hipStreamDestroy(st);
     for (hipEvent_t ev : c->events) if (ev) hipEventDestroy(ev);
     delete c;
@@ -906,8 +916,10 @@ int ppde_chains_init(ppde_chains* c, const uint8_t* idx0_dev) {
     HIPCHK(hipGetLastError());
     int rc = state_rows_to_t4(m, c->cur, c->curT, n, c->n_pad, s);
     if (rc) return rc;
-    HIPCHK(hipMemsetAsync(c->err_flag, 0, sizeof(int), s));
+    HIPCHK(hipStreamSynchronize(s));
+    *c->h_err = 0;
     HIPCHK(hipMemsetAsync(c->d_it, 0, sizeof(int), s));
+    c->d_it_val = 0;
     PasArgs a = chain_args(c);
     if (c->cfg.reuse_grad || c->cfg.paper_results) {
         // fallback rows: the wild type (mutation-cap reset) or the initial population (paper_results)
@@ -975,15 +987,17 @@ int ppde_chains_run(ppde_chains* c, int steps, const int32_t* U_dev, const float
     }
     int done = 0;
     if (!c->graphs.empty()) {
-        bool counter_set = false;
         for (const auto& gs : c->graphs) {          // longest segment first
             while (steps - done >= gs.len) {
-                if (!counter_set) {
-                    HIPCHK(hipMemsetD32Async((hipDeviceptr_t)c->d_it, c->steps_done, 1, c->stream));
-                    counter_set = true;
+                // every segment ends by adding its length to the device counter: it only needs setting after eager
+                // iterations (which take their index from the launch arguments and leave the counter behind)
+                if (c->d_it_val != (long long)c->steps_done + done) {
+                    HIPCHK(hipMemsetD32Async((hipDeviceptr_t)c->d_it, c->steps_done + done, 1, c->stream));
+                    c->d_it_val = (long long)c->steps_done + done;
                 }
                 HIPCHK(hipGraphLaunch(gs.exec, c->stream));
                 done += gs.len;
+                c->d_it_val += gs.len;
             }
         }
         c->n_replayed_steps += done;
@@ -1010,9 +1024,13 @@ int ppde_chains_graph_stats(ppde_chains* c, int32_t* captures, int32_t* captures
 int ppde_chains_sync(ppde_chains* c) {
     ARGCHK(c, "null chains");
     HIPCHK(hipSetDevice(c->m->device));
-    HIPCHK(hipStreamSynchronize(c->stream));
-    int err = 0;
-    HIPCHK(hipMemcpy(&err, c->err_flag, sizeof(int), hipMemcpyDeviceToHost));
+    // short runs are latency-bound on the host side too: poll the stream for a while before blocking in the driver
+    // (a blocking wait wakes up tens of microseconds after the last kernel; a 20-iteration block is 500 us)
+    hipError_t q = hipErrorNotReady;
+    for (int spin = 0; spin < 20000 && (q = hipStreamQuery(c->stream)) == hipErrorNotReady; ++spin) { }
+    if (q == hipErrorNotReady) q = hipStreamSynchronize(c->stream);
+    HIPCHK(q);
+    const int err = *(volatile int*)c->h_err;
     if (err & 2) return fail(PPDE_ERR_INVALID, "a supplied path length U exceeds the max_u of its iteration (the noise block holds only max_u sub-steps)");
     if (err) return fail(PPDE_ERR_NUMERIC, "a proposal row had no finite logit (every move masked out): the categorical is undefined");
     return PPDE_OK;

@@ -78,6 +78,39 @@ def make_cnn_state(L, seed, kernel_size=5):
     }
 
 
+ESM_VOCAB = 33
+
+
+def make_esm2_state(n_layers, dim, heads, ffn, seed=0):
+    """Seeded random weights with ESM-2's parameter names and shapes (facebookresearch/esm `ESM2`): the real
+    checkpoints (esm2_t30_150M_UR50D = 30 layers, 640 wide, 20 heads, 2560 ffn) come from torch hub at run time in the
+    reference and are not available offline. Scales follow the usual transformer initialisation (0.02-sigma normal
+    matrices, unit layer-norm gains) with the embedding made larger so that the logits have a spread."""
+    rng = np.random.default_rng(30_000 + seed)
+    nrm = lambda *shape, s=0.02: (rng.standard_normal(shape) * s).astype(np.float32)
+    st = {"embed_tokens.weight": nrm(ESM_VOCAB, dim, s=0.1)}
+    for i in range(n_layers):
+        pre = f"layers.{i}."
+        for nm in ("q_proj", "k_proj", "v_proj", "out_proj"):
+            st[pre + f"self_attn.{nm}.weight"] = nrm(dim, dim, s=1.0 / np.sqrt(dim))
+            st[pre + f"self_attn.{nm}.bias"] = nrm(dim)
+        for nm in ("self_attn_layer_norm", "final_layer_norm"):
+            st[pre + nm + ".weight"] = (1.0 + nrm(dim, s=0.05)).astype(np.float32)
+            st[pre + nm + ".bias"] = nrm(dim)
+        st[pre + "fc1.weight"] = nrm(ffn, dim, s=1.0 / np.sqrt(dim))
+        st[pre + "fc1.bias"] = nrm(ffn)
+        st[pre + "fc2.weight"] = nrm(dim, ffn, s=1.0 / np.sqrt(ffn))
+        st[pre + "fc2.bias"] = nrm(dim)
+    st["emb_layer_norm_after.weight"] = (1.0 + nrm(dim, s=0.05)).astype(np.float32)
+    st["emb_layer_norm_after.bias"] = nrm(dim)
+    st["lm_head.dense.weight"] = nrm(dim, dim, s=1.0 / np.sqrt(dim))
+    st["lm_head.dense.bias"] = nrm(dim)
+    st["lm_head.layer_norm.weight"] = (1.0 + nrm(dim, s=0.05)).astype(np.float32)
+    st["lm_head.layer_norm.bias"] = nrm(dim)
+    st["lm_head.bias"] = nrm(ESM_VOCAB)
+    return st
+
+
 def make_linear(L, seed):
     rng = np.random.default_rng(20_000 + seed)
     return {

@@ -1,23 +1,53 @@
 #!/bin/bash
-# Collect the rocprofv3 runs that profiles/ is built from. Run on the GPU box from the repository root:
-#   bash scripts/collect_profiles.sh          (writes gpurun_out/prof_*; summarise with scripts/summarize_profiles.py)
+# Collect the rocprofv3 runs and stamp logs that profiles/ is built from. Run on the GPU box from the repository root:
+#   bash scripts/collect_profiles.sh <tag>     (e.g. r02; writes gpurun_out/prof_<tag>_* and copies the summaries to profiles/)
 # Counters are collected in their own passes (never together with a trace domain other than the kernel trace).
 set -e -o pipefail
+TAG=${1:-r02}
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 OUT=$ROOT/gpurun_out
-mkdir -p "$OUT"
+P=$ROOT/profiles
+mkdir -p "$OUT" "$P"
 cd /tmp && export TMPDIR=/tmp
-python3 "$ROOT/bench.py" > "$OUT/prof_bench_stdout.log" 2>&1
+run() { echo "== $*"; "$@"; }
+# 1. the bench line as the driver sees it (default arguments, and the driver's --steps 20 --warmup 5)
+python3 "$ROOT/bench.py" > "$OUT/prof_${TAG}_bench_stdout.log" 2>&1
+python3 "$ROOT/bench.py" --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline > "$OUT/prof_${TAG}_bench_steps20.log" 2>&1
+grep '^{' "$OUT/prof_${TAG}_bench_stdout.log" > "$P/${TAG}_bench_stdout.log"
+grep '^{' "$OUT/prof_${TAG}_bench_steps20.log" > "$P/${TAG}_bench_steps20_stdout.log"
 echo "bench done"
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_stats" -- python3 "$ROOT/bench.py" --no-cpu-baseline > "$OUT/prof_stats.log" 2>&1
-echo "stats done"
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_stats3" -- python3 "$ROOT/bench.py" --workload potts+cnn --steps 500 --warmup 50 --no-cpu-baseline > "$OUT/prof_stats3.log" 2>&1
-echo "stats config 3 done"
+# 2. per-kernel table of the same command (config 2), and of config 3, GFP, UBE4B, 1024 chains
+stats() {   # name, bench args...
+    local name=$1; shift
+    rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_${TAG}_$name" -- python3 "$ROOT/bench.py" --no-cpu-baseline "$@" > "$OUT/prof_${TAG}_$name.log" 2>&1
+    python3 "$ROOT/scripts/summarize_profiles.py" "${TAG}_$name" --stats "$OUT/prof_${TAG}_$name" > /dev/null
+    grep '^{' "$OUT/prof_${TAG}_$name.log" > "$P/${TAG}_${name}_bench_under_rocprof.json" || true
+    echo "stats $name done"
+}
+stats config2
+stats config3 --workload potts+cnn --steps 500 --warmup 50 --no-large
+stats gfp --protein GFP --steps 300 --warmup 50 --no-large
+stats gfp_cnn --protein GFP --workload potts+cnn --steps 60 --warmup 20 --no-large
+stats ube4b --protein UBE4B --steps 500 --warmup 50 --no-large
+stats ube4b_cnn --protein UBE4B --workload potts+cnn --steps 200 --warmup 30 --no-large
+stats pabp_1024chains --chains 1024 --steps 300 --warmup 50 --no-large
+# 3. counters: fabric-side bytes of the Potts kernel (PABP and GFP), instruction counts of the chain kernels, matrix pipe of the CNN
 for c in FETCH_SIZE WRITE_SIZE; do
-    rocprofv3 --pmc $c --kernel-trace --output-format csv -d "$OUT/prof_$c" -- python3 "$ROOT/bench.py" --steps 300 --warmup 50 --no-cpu-baseline > "$OUT/prof_$c.log" 2>&1
+    rocprofv3 --pmc $c --kernel-trace --output-format csv -d "$OUT/prof_${TAG}_$c" -- python3 "$ROOT/bench.py" --steps 300 --warmup 50 --no-cpu-baseline --no-large > "$OUT/prof_${TAG}_$c.log" 2>&1
+    rocprofv3 --pmc $c --kernel-trace --output-format csv -d "$OUT/prof_${TAG}_gfp_$c" -- python3 "$ROOT/bench.py" --protein GFP --steps 100 --warmup 20 --no-cpu-baseline --no-large > "$OUT/prof_${TAG}_gfp_$c.log" 2>&1
     echo "$c done"
 done
-rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_WAIT_ANY SQ_ACTIVE_INST_ANY --kernel-trace --output-format csv -d "$OUT/prof_SQ" -- python3 "$ROOT/bench.py" --steps 300 --warmup 50 --no-cpu-baseline > "$OUT/prof_SQ.log" 2>&1
+rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_WAIT_ANY SQ_ACTIVE_INST_ANY --kernel-trace --output-format csv -d "$OUT/prof_${TAG}_SQ" -- python3 "$ROOT/bench.py" --steps 300 --warmup 50 --no-cpu-baseline --no-large > "$OUT/prof_${TAG}_SQ.log" 2>&1
 echo "SQ done"
-rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVES --kernel-trace --output-format csv -d "$OUT/prof_MFMA" -- python3 "$ROOT/bench.py" --workload potts+cnn --steps 200 --warmup 30 --no-cpu-baseline > "$OUT/prof_MFMA.log" 2>&1
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVES --kernel-trace --output-format csv -d "$OUT/prof_${TAG}_MFMA" -- python3 "$ROOT/bench.py" --workload potts+cnn --steps 200 --warmup 30 --no-cpu-baseline --no-large > "$OUT/prof_${TAG}_MFMA.log" 2>&1
 echo "MFMA (config 3) done"
+python3 "$ROOT/scripts/summarize_profiles.py" "${TAG}" --fetch "$OUT/prof_${TAG}_FETCH_SIZE" --write "$OUT/prof_${TAG}_WRITE_SIZE" --sq "$OUT/prof_${TAG}_SQ" --key PABP > /dev/null
+python3 "$ROOT/scripts/summarize_profiles.py" "${TAG}_gfp" --fetch "$OUT/prof_${TAG}_gfp_FETCH_SIZE" --write "$OUT/prof_${TAG}_gfp_WRITE_SIZE" --key GFP > /dev/null
+python3 "$ROOT/scripts/summarize_profiles.py" "${TAG}_config3" --mfma "$OUT/prof_${TAG}_MFMA" > /dev/null
+# 4. in-kernel stamps (diagnostic build; shares, not lengths) and the per-workgroup Potts timelines
+cd "$ROOT"
+python3 scripts/stamp_kernels.py > "$P/${TAG}_stamps_pabp.log" 2>&1 || true
+python3 scripts/stamp_kernels.py --cnn > "$P/${TAG}_stamps_pabp_cnn.log" 2>&1 || true
+python3 scripts/stamp_potts_wgs.py > "$P/${TAG}_stamps_potts_workgroups_pabp.log" 2>&1 || true
+python3 scripts/stamp_potts_wgs.py --protein=GFP > "$P/${TAG}_stamps_potts_workgroups_gfp.log" 2>&1 || true
+echo "all done"

@@ -48,7 +48,7 @@ def main():
         if not d:
             continue
         g = counters(d)
-        g = g[g["kernel"].str.contains("potts_energy_grad|k_propose|k_accept|k_cnn|k_experts")]
+        g = g[g["kernel"].str.contains("potts_energy_grad|k_propose|k_accept|k_cnn|k_experts|tf_")]
         lines += [f"## pass: {name}", "", "| kernel | counter | mean per launch | launches |", "|---|---|---|---|"]
         for _, r in g.iterrows():
             lines.append(f"| {r['kernel']} | {r['Counter_Name']} | {r['mean']:.1f} | {int(r['count'])} |")
@@ -71,7 +71,8 @@ def main():
                   "one v_mfma_f32_16x16x4_f32 occupies it for 32 cycles, so busy / 32 = MFMA instructions issued per launch",
                   "(k_cnn at 128 chains x 3 networks: 384 x (1728 + 1008) = 1 050 624). Divided by 1024 SIMDs and by the",
                   "kernel's duration in cycles it is the matrix-pipe utilisation averaged over the chip.", ""]
-    open(os.path.join(OUT, f"{a.tag}_pmc.md"), "w").write("\n".join(lines))
+    if a.fetch or a.write or a.sq or a.mfma:
+        open(os.path.join(OUT, f"{a.tag}_pmc.md"), "w").write("\n".join(lines))
     print("\n".join(lines))
 
 
