@@ -1,0 +1,130 @@
+"""bench.py --workload transformer: BASELINE configs[4] — UBE4B_MOUSE, transformer unsupervised expert (ESM-2 150M
+shapes: 30 layers x 640, 20 heads, ffn 2560; synthetic seeded weights) + supervised CNN product of experts (lamda = 3,
+README.md:70-72), 256 chains on one GPU. One step = one MCMC iteration = two energy+gradient evaluations of the
+transformer (forward and input gradient over 256 x 104 tokens) plus the chain kernels.
+
+Roofline entry: the GEMM kernel that carries ~95 % of the arithmetic, timed live at the fc1 shape against the dense
+fp16 MFMA peak; `eval_tflops` is the whole evaluation (all kernels) at its algorithmic GEMM + attention flops."""
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+MFMA_F16_PEAK_TF = 2500.0
+
+
+def eval_flops(n, L, layers, D, F):
+    """Algorithmic flops of one energy+gradient evaluation: every linear layer forward and input-gradient backward
+    (2 * M * N * K each), attention (QK^T, PV forward; four products backward), head."""
+    M = n * L
+    lin = 2.0 * M * (3 * D * D + D * D + 2 * D * F)            # qkv, out, fc1, fc2
+    att_f = 2.0 * 2 * n * (D // 32) * L * L * 32
+    head = 2.0 * M * (D * D + 33 * D)
+    return layers * (2 * lin + att_f * 3.5) + 2 * head + 2.0 * M * 33 * D
+
+
+def main(args, rank, world, local, backend):
+    import torch
+    sys.path.insert(0, REPO)
+    from ppde_amd import _hip, synthetic
+    from ppde_amd.encoding import seqs_to_idx
+    from ppde_amd.energy import HipModel
+    from ppde_amd.sampler import Chains
+    assert world == 1, "the transformer workload is a single-GPU configuration (BASELINE configs[4])"
+    assert torch.cuda.is_available(), "bench.py needs a HIP device; there is no CPU fallback for the product path"
+    device = f"cuda:{local}"
+    torch.cuda.set_device(local)
+    steps = args.steps if args.steps != 2000 else 20            # (the defaults of the Potts workload would run for minutes)
+    warmup = args.warmup if args.warmup != 200 else 3
+    repeats = min(args.repeats, 3)
+    n = args.chains if args.chains != 128 else 256
+    name = [k for k in synthetic.PROTEINS if k.startswith("UBE4B")][0]
+    _, seq, _ = synthetic.PROTEINS[name]
+    wt = seqs_to_idx([seq])[0]
+    L = wt.shape[0]
+    layers, D, H, F = args.tf_layers, args.tf_dim, args.tf_heads, args.tf_ffn
+    st = synthetic.make_esm2_state(layers, D, H, F, seed=0)
+    cnn = [synthetic.make_cnn_state(L, s) for s in range(3)]
+    m = HipModel(wt, device)
+    m.set_cnn(cnn)
+    m.set_transformer(st, H)
+    lam = 3.0
+    m.set_lamda(lam)
+    T = warmup + repeats * steps + 4
+
+    def timed(reuse):
+        ch = Chains(m, n, T, args.pas, args.nmut, False, 0, L - 1, 6, 1, reuse_grad=reuse, random_chain=0, use_graph=False, seed=1)
+        ch.init(torch.as_tensor(np.tile(wt, (n, 1))).to(device))
+        ch.run(warmup)
+        ch.sync()
+        dts = []
+        for _ in range(repeats):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            ch.run(steps)
+            ch.sync()
+            torch.cuda.synchronize()
+            dts.append(time.perf_counter() - t0)
+        res = ch.collect()
+        assert np.isfinite(res["energy_history"]).all()
+        return float(np.median(dts)), dts
+
+    dt, dts = timed(bool(args.reuse_grad))
+    dt_other, _ = timed(not bool(args.reuse_grad))
+    # dominant kernel: tf_gemm_nt at the fc1 shape
+    M = (n * L + 127) // 128 * 128
+    us = C.c_float()
+    _hip.check(_hip.load().ppde_transformer_time_gemm(local, M, F, D, 50, C.byref(us)))
+    gemm_tf = 2.0 * M * F * D / (us.value * 1e-6) / 1e12
+    # one evaluation on its own
+    x = torch.as_tensor(np.tile(wt, (n, 1))).to(device)
+    m.energy_grad(x, 4)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(3):
+        m.energy_grad(x, 4)
+    torch.cuda.synchronize()
+    ev = (time.perf_counter() - t0) / 3
+    fl = eval_flops(n, L, layers, D, F)
+
+    out = {
+        "metric": f"MCMC steps/sec ({n} chains, UBE4B transformer PoE)",
+        "value": steps / dt, "unit": "steps/s", "n_gpus": 1, "steps": steps, "warmup": warmup,
+        "ms_per_step": dt / steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f16 (fp32 accumulate and statistics, as the reference's autocast)", "data": "synthetic",
+        "config": {"workload": f"UBE4B_MOUSE transformer unsupervised expert (ESM-2 shapes: {layers} layers x {D}, {H} heads, ffn {F}; "
+                               f"seeded random weights) + supervised CNN (lamda={lam}), L={L}, A=20, {n} chains, pas_length={args.pas}, "
+                               "device Philox RNG, all chains start at WT",
+                   "chains_per_gpu": n, "total_chains": n, "parallelism": "1 GPU",
+                   "energy_evaluations_per_step": 1 if args.reuse_grad else 2},
+        "chain_steps_per_s": n * steps / dt,
+        "timed_blocks": {"repeats": len(dts), "statistic": "median", "ms_per_block": [round(x * 1e3, 3) for x in dts]},
+        "graph_captured_in_timed_region": False,
+        "roofline": {"kernel": "tf_gemm_nt<bias+GELU> (fc1 shape)", "bound": "mfma", "achieved": gemm_tf, "peak": MFMA_F16_PEAK_TF / 1.0,
+                     "unit": "TFLOP/s", "frac": gemm_tf / MFMA_F16_PEAK_TF, "traffic": None,
+                     "traffic_source": None, "algorithmic_flops_per_launch": 2.0 * M * F * D, "avg_launch_us": us.value,
+                     "launches_timed": 50, "shape": [M, F, D]},
+        "evaluation": {"ms": ev * 1e3, "algorithmic_tflop": fl / 1e12, "tflops": fl / ev / 1e12,
+                       "note": "one transformer energy+gradient evaluation of all chains (forward + input gradient, every kernel)"},
+        ("value_reuse_grad" if not args.reuse_grad else "value_reevaluate"): steps / dt_other,
+    }
+    if not args.no_cpu_baseline:
+        sys.path.insert(0, os.path.join(REPO, "oracle"))
+        import esm_oracle as eo
+        cores = min(os.cpu_count() or 1, 16)
+        torch.set_num_threads(cores)
+        orc = eo.EsmOracle(st, layers, D, H, half_points=True)
+        ns = 4
+        idx = np.tile(wt.astype(np.int64), (ns, 1))
+        t0 = time.perf_counter()
+        orc.score_grad(idx)
+        te = time.perf_counter() - t0
+        out["cpu_baseline"] = {"value": 1.0 / (2 * te * n / ns), "unit": "MCMC steps/s", "cores": int(torch.get_num_threads()), "kind": "port",
+                               "sample": f"ONE transformer energy+gradient evaluation of {ns} chains through oracle/esm_oracle.py ({te:.1f} s), "
+                                         f"scaled to {n} chains and two evaluations per step; the supervised CNN and the sampler "
+                                         "arithmetic are not included (they are < 1 % of the step on the CPU)"}
+    print(json.dumps(out), flush=True)

@@ -30,6 +30,7 @@
  *     pieces per wave;
  *   - supervised expert: 1..4 networks of one shape, kernel size 1..8, embedding width F <= 512
  *     for the single-launch kernel (wider or longer networks take the chunked kernels);
+ *   - transformer expert: head width 32, dim and ffn multiples of 128, dim <= 1024, L <= 128;
  *   - ppde_pas_length 1..64; chain_offset + n_chains < 2^32.
  */
 #ifndef PPDE_HIP_H
@@ -83,6 +84,43 @@ int ppde_model_set_cnn(ppde_model* m, int n_nets, int C, int K, int F,
                        const float* const* lin_w, const float* const* lin_b,
                        const float* const* dec_w, const float* const* dec_b);
 
+/* Transformer unsupervised expert (nets.py:172-240 `Transformer`, :302-312 `PottsTransformer`): an ESM-2 encoder
+ * evaluated on one-hot input, score = sum x * log_softmax(logits) minus the wild type's (nets.py:219-240), under the
+ * reference's autocast (fp16 matmuls, fp32 statistics). The reference takes the model from the third-party
+ * `esm_one_hot` package + torch hub; here the caller passes ESM-2's parameters (fp32, host), named as in
+ * facebookresearch/esm's ESM2: per-layer arrays have n_layers entries. Written for head width 32
+ * (esm2_t30_150M: dim 640, 20 heads, ffn 2560), dim and ffn multiples of 128, L <= 128. Also evaluates the wild
+ * type's score. */
+typedef struct {
+    const float* embed;                 /* embed_tokens.weight [33][dim] (also the tied LM-head projection) */
+    const float* const* q_w; const float* const* q_b;       /* layers.i.self_attn.{q,k,v,out}_proj.{weight [dim][dim], bias} */
+    const float* const* k_w; const float* const* k_b;
+    const float* const* v_w; const float* const* v_b;
+    const float* const* o_w; const float* const* o_b;
+    const float* const* ln1_w; const float* const* ln1_b;   /* layers.i.self_attn_layer_norm */
+    const float* const* ln2_w; const float* const* ln2_b;   /* layers.i.final_layer_norm */
+    const float* const* fc1_w; const float* const* fc1_b;   /* [ffn][dim], [ffn] */
+    const float* const* fc2_w; const float* const* fc2_b;   /* [dim][ffn], [dim] */
+    const float* final_ln_w; const float* final_ln_b;       /* emb_layer_norm_after */
+    const float* head_dense_w; const float* head_dense_b;   /* lm_head.dense */
+    const float* head_ln_w; const float* head_ln_b;         /* lm_head.layer_norm */
+    const float* head_bias;                                 /* lm_head.bias [33] */
+} ppde_tf_weights;
+int ppde_model_set_transformer(ppde_model* m, int n_layers, int dim, int heads, int ffn, const ppde_tf_weights* w);
+/* local score of the wild type (nets.py:188 `wt_score`) for inspection. */
+int ppde_model_get_transformer_wt_score(ppde_model* m, float* out_host);
+
+/* Timing hook for bench.py: average duration (microseconds) of the transformer's GEMM kernel, C[M,N] = A[M,K] B[N,K]^T
+ * with the bias + GELU epilogue (the fc1 form), fp16 operands filled with pseudo-random values, `reps` launches
+ * between one HIP event pair. M, N multiples of 128, K of 64. */
+int ppde_transformer_time_gemm(int device, int M, int N, int K, int reps, float* avg_us);
+
+/* Diagnostics for the parity tests: an fp16 activation of the last stateless evaluation that used the transformer
+ * expert, converted to fp32. what: 0 layer input, 1 q|k|v, 2 attention probabilities, 3 post-attention stream,
+ * 4 fc1 pre-activation (all of `layer`), 5 final stream, 6 logits, 7 d logits, 8 d embedding, 9 d tokens,
+ * 10 / 11 attention output / d q|k|v of the layer evaluated last. */
+int ppde_debug_transformer_read(ppde_model* m, int what, int layer, float* out_host, int64_t count);
+
 /* lamda of e = dH + lamda * fit (energy.py:74, :99-100). */
 int ppde_model_set_lamda(ppde_model* m, float lamda);
 
@@ -99,10 +137,11 @@ int ppde_onehot_to_idx(ppde_model* m, const float* x_dev, int n, uint8_t* idx_de
 /* idx_dev [n, L] -> fp32 one-hot x_dev [n, L, 20]. */
 int ppde_idx_to_onehot(ppde_model* m, const uint8_t* idx_dev, int n, float* x_dev, void* stream);
 
-/* get_energy / get_energy_and_grads (energy.py:97-108,132): e_dev [n], fit_dev [n], and, when grad_dev
- * is not NULL, grad_dev [n, L, 20] = d e.sum() / d x. which: bit 0 = unsupervised (Potts) expert,
- * bit 1 = supervised expert; 3 = product of experts. With which == 2, e = fit and grad = d fit/dx
- * (ProteinSupervised, energy.py:153-160); with which == 1, e = dH, fit = 0. */
+/* get_energy / get_energy_and_grads (energy.py:97-132): e_dev [n], fit_dev [n], and, when grad_dev
+ * is not NULL, grad_dev [n, L, 20] = d e.sum() / d x. which: bit 0 = Potts expert, bit 1 = supervised expert,
+ * bit 2 = transformer expert; 3 = Potts product of experts, 6 = transformer product of experts
+ * (`--unsupervised_expert transformer`), 7 = `potts+transformer`. With which == 2, e = fit and grad = d fit/dx
+ * (ProteinSupervised, energy.py:153-160); without bit 1, fit = 0. */
 int ppde_energy_grad(ppde_model* m, const uint8_t* idx_dev, int n, int which,
                      float* e_dev, float* fit_dev, float* grad_dev, void* stream);
 

@@ -56,6 +56,7 @@ class EsmOracle:
         self.n_layers, self.dim, self.heads, self.hd = n_layers, dim, heads, dim // heads
         self.half = half_points
         self.perm = torch.as_tensor(potts_to_esm_index())
+        self.trace = None            # set to a dict to record intermediates of the next logits() call
 
     def _w(self, name):
         w = self.p[name]
@@ -86,27 +87,38 @@ class EsmOracle:
         x = _h(_h(x_esm, hp) @ self._w("embed_tokens.weight"), hp)
         x = _h(x * TOKEN_DROPOUT_SCALE, hp)
         H, hd = self.heads, self.hd
+        tr = self.trace
         for i in range(self.n_layers):
             pre = f"layers.{i}."
+            if tr is not None:
+                tr[f"xin{i}"] = x.detach()
             y = self._ln(x, pre + "self_attn_layer_norm")
             q = _h(self._lin(y, pre + "self_attn.q_proj") * (hd ** -0.5), hp)
             k = self._lin(y, pre + "self_attn.k_proj")
             v = self._lin(y, pre + "self_attn.v_proj")
             sp = lambda t: t.reshape(n, L, H, hd).transpose(1, 2)
+            if tr is not None:
+                tr[f"qkv{i}"] = torch.cat((q, k, v), -1).detach()
             q, k, v = self._rotary(sp(q)), self._rotary(sp(k)), sp(v)
             a = _h(q @ k.transpose(-1, -2), hp)
             a = _h(torch.softmax(a, -1), hp)
             ctx = _h(a @ v, hp).transpose(1, 2).reshape(n, L, H * hd)
             x = _h(x + self._lin(ctx, pre + "self_attn.out_proj"), hp)
+            if tr is not None:
+                tr[f"P{i}"], tr[f"ctx{i}"], tr[f"xmid{i}"] = a.detach(), ctx.detach(), x.detach()
             y = self._ln(x, pre + "final_layer_norm")
             hdn = self._lin(y, pre + "fc1")
             act = _h(hdn * 0.5 * (1.0 + torch.erf(hdn / math.sqrt(2.0))), hp)
             x = _h(x + self._lin(act, pre + "fc2"), hp)
+        if tr is not None:
+            tr["xlast"] = x.detach()
         x = self._ln(x, "emb_layer_norm_after")
         y = self._lin(x, "lm_head.dense")
         y = _h(y * 0.5 * (1.0 + torch.erf(y / math.sqrt(2.0))), hp)
         y = self._ln(y, "lm_head.layer_norm")
         lg = _h(_h(y, hp) @ self._w("embed_tokens.weight").t() + self.p["lm_head.bias"], hp)
+        if tr is not None:
+            tr["logits"] = lg.detach()
         return lg
 
     def score(self, x_potts):

@@ -24,6 +24,14 @@ class ChainConfig(C.Structure):
         [("seed", C.c_uint64), ("chain_offset", C.c_uint64)]
 
 
+class TfWeights(C.Structure):
+    """ppde_tf_weights (include/ppde_hip.h): host pointers to ESM-2's fp32 parameters."""
+    _PER_LAYER = ("q_w", "q_b", "k_w", "k_b", "v_w", "v_b", "o_w", "o_b", "ln1_w", "ln1_b", "ln2_w", "ln2_b",
+                  "fc1_w", "fc1_b", "fc2_w", "fc2_b")
+    _GLOBAL = ("final_ln_w", "final_ln_b", "head_dense_w", "head_dense_b", "head_ln_w", "head_ln_b", "head_bias")
+    _fields_ = [("embed", C.c_void_p)] + [(k, C.POINTER(C.c_void_p)) for k in _PER_LAYER] + [(k, C.c_void_p) for k in _GLOBAL]
+
+
 _p, _i, _f = C.c_void_p, C.c_int, C.c_float
 _pp = C.POINTER(C.c_void_p)
 
@@ -37,6 +45,10 @@ SIGNATURES = {
     "ppde_model_set_potts": (_i, [_p, _p, _p, _i, _i]),
     "ppde_model_set_cnn": (_i, [_p, _i, _i, _i, _i, _pp, _pp, _pp, _pp, _pp, _pp]),
     "ppde_model_set_lamda": (_i, [_p, _f]),
+    "ppde_model_set_transformer": (_i, [_p, _i, _i, _i, _i, C.POINTER(TfWeights)]),
+    "ppde_model_get_transformer_wt_score": (_i, [_p, C.POINTER(_f)]),
+    "ppde_debug_transformer_read": (_i, [_p, _i, _i, _p, C.c_int64]),
+    "ppde_transformer_time_gemm": (_i, [_i, _i, _i, _i, _i, C.POINTER(_f)]),
     "ppde_model_get_wt_hamiltonian": (_i, [_p, C.POINTER(_f)]),
     "ppde_onehot_to_idx": (_i, [_p, _p, _i, _p, _p]),
     "ppde_idx_to_onehot": (_i, [_p, _p, _i, _p, _p]),

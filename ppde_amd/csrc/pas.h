@@ -39,6 +39,9 @@ struct PasArgs {
     const float* gradC;         // [2][nets][n][N]  lamda * d fit_net/dx / nets   (NULL without the CNN expert)
     const float* fitC;          // [2][nets][n]     per-network predictions
     int n_nets;
+    const float* gradT;         // [2][n][N]  d (transformer score) / dx                  (NULL without the transformer expert)
+    const float* tfE;           // [2][n]     transformer local score
+    float tf_wt;                // the wild type's (nets.py:188)
     float* grad_cur;            // [n][N] combined gradient row of the CURRENT state (gradient-reuse mode)
     unsigned char* rec;         // [n] ChainRec records (+ the pending path), stride rec_stride bytes
     int rec_stride;
@@ -129,23 +132,29 @@ struct RowSrc {
     const float4* p;            // Potts (or combined) row
     const float4* c[4];         // CNN rows
     int nc;
+    const float4* t;            // transformer row (or NULL)
 };
 __device__ __forceinline__ float4 add4(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
 // (every index into c[] is a compile-time constant: a run-time index would send the struct to scratch memory)
 __device__ __forceinline__ float4 row_value(const RowSrc& r, int g4) {
-    if (r.nc == 0) return r.p[g4];
-    float4 v = r.c[0][g4];
-    if (r.nc > 1) v = add4(v, r.c[1][g4]);
-    if (r.nc > 2) v = add4(v, r.c[2][g4]);
-    if (r.nc > 3) v = add4(v, r.c[3][g4]);
-    return r.p ? add4(v, r.p[g4]) : v;
+    float4 v;
+    if (r.nc == 0) v = r.p ? r.p[g4] : make_float4(0.f, 0.f, 0.f, 0.f);
+    else {
+        v = r.c[0][g4];
+        if (r.nc > 1) v = add4(v, r.c[1][g4]);
+        if (r.nc > 2) v = add4(v, r.c[2][g4]);
+        if (r.nc > 3) v = add4(v, r.c[3][g4]);
+        if (r.p) v = add4(v, r.p[g4]);
+    }
+    return r.t ? add4(v, r.t[g4]) : v;
 }
 // The same in two halves for the kernels' prologues: row_parts_issue() only LOADS (a use of a loaded value in the
 // issuing basic block makes hipcc wait right there, before the loads that follow), row_parts_sum() adds later.
-struct RowParts { float4 v, e1, e2, e3, ep; };
+struct RowParts { float4 v, e1, e2, e3, ep, et; };
 __device__ __forceinline__ RowParts row_parts_issue(const RowSrc& r, int g4) {
     RowParts q;                                       // members stay unset where the component is absent
-    if (r.nc == 0) { q.v = r.p[g4]; return q; }
+    if (r.t) q.et = r.t[g4];
+    if (r.nc == 0) { if (r.p) q.v = r.p[g4]; return q; }
     q.v = r.c[0][g4];
     if (r.nc > 1) q.e1 = r.c[1][g4];
     if (r.nc > 2) q.e2 = r.c[2][g4];
@@ -153,13 +162,17 @@ __device__ __forceinline__ RowParts row_parts_issue(const RowSrc& r, int g4) {
     if (r.p) q.ep = r.p[g4];
     return q;
 }
-__device__ __forceinline__ float4 row_parts_sum(const RowParts& q, int nc, bool has_p) {
-    if (nc == 0) return q.v;
-    float4 v = q.v;
-    if (nc > 1) v = add4(v, q.e1);
-    if (nc > 2) v = add4(v, q.e2);
-    if (nc > 3) v = add4(v, q.e3);
-    return has_p ? add4(v, q.ep) : v;
+__device__ __forceinline__ float4 row_parts_sum(const RowParts& q, int nc, bool has_p, bool has_t) {
+    float4 v;
+    if (nc == 0) v = has_p ? q.v : make_float4(0.f, 0.f, 0.f, 0.f);
+    else {
+        v = q.v;
+        if (nc > 1) v = add4(v, q.e1);
+        if (nc > 2) v = add4(v, q.e2);
+        if (nc > 3) v = add4(v, q.e3);
+        if (has_p) v = add4(v, q.ep);
+    }
+    return has_t ? add4(v, q.et) : v;
 }
 
 __device__ __forceinline__ RowSrc slot_row(const PasArgs& a, int slot, int b) {
@@ -167,6 +180,7 @@ __device__ __forceinline__ RowSrc slot_row(const PasArgs& a, int slot, int b) {
     r.nc = 0;
     r.p = (a.which & 1) ? (const float4*)(a.grad + ((size_t)slot * a.n + b) * a.g.N) : nullptr;
     r.c[0] = r.c[1] = r.c[2] = r.c[3] = nullptr;
+    r.t = (a.which & 4) ? (const float4*)(a.gradT + ((size_t)slot * a.n + b) * a.g.N) : nullptr;
     if (a.which & 2) {
         r.nc = a.n_nets;
 #pragma unroll
@@ -180,6 +194,7 @@ __device__ __forceinline__ RowSrc plain_row(const float* row) {
     r.nc = 0;
     r.p = (const float4*)row;
     r.c[0] = r.c[1] = r.c[2] = r.c[3] = nullptr;
+    r.t = nullptr;
     return r;
 }
 // gradient at the current state: carried over in grad_cur (reuse) or freshly evaluated into slot 0
@@ -223,7 +238,7 @@ struct RowRegs {
 template <int GPT>
 struct RowLetters {
     uint8_t st, wt;
-    int nc; bool has_p;
+    int nc; bool has_p, has_t;
     RowParts parts[GPT];
 };
 template <int GPT>
@@ -231,7 +246,7 @@ __device__ __forceinline__ RowLetters<GPT> row_issue(const Geom& g, const RowSrc
                                                      const uint8_t* wt_row, RowRegs<GPT>& R) {
     const int tid = threadIdx.x, n4 = g.N / 4;
     RowLetters<GPT> q;
-    q.nc = src.nc; q.has_p = src.p != nullptr;
+    q.nc = src.nc; q.has_p = src.p != nullptr; q.has_t = src.t != nullptr;
 #pragma unroll
     for (int r = 0; r < GPT; ++r) {
         const int g4 = tid + r * PPDE_BLOCK;
@@ -249,7 +264,7 @@ __device__ __forceinline__ void row_commit(const RowLds& lds, const Geom& g, con
     const int tid = threadIdx.x;
 #pragma unroll
     for (int r = 0; r < GPT; ++r) {
-        R.gv[r] = R.valid[r] ? row_parts_sum(q.parts[r], q.nc, q.has_p) : make_float4(0.f, 0.f, 0.f, 0.f);
+        R.gv[r] = R.valid[r] ? row_parts_sum(q.parts[r], q.nc, q.has_p, q.has_t) : make_float4(0.f, 0.f, 0.f, 0.f);
         if (R.valid[r]) lds.G[tid + r * PPDE_BLOCK] = R.gv[r];
     }
     if (tid < g.L) { lds.St[tid] = q.st; lds.Wt[tid] = q.wt; }
@@ -625,6 +640,7 @@ __global__ __launch_bounds__(PPDE_BLOCK) void k_propose(PasArgs a) {
 __device__ __forceinline__ void slot_energy(const PasArgs& a, int slot, int b, float& e, float& f) {
     float dH = 0.f;
     if (a.which & 1) dH = potts_hamiltonian_from_parts(a.epart + ((size_t)slot * a.n + b) * a.g.Lp, a.g.Lp) - a.wt_H;
+    if (a.which & 4) dH += a.tfE[(size_t)slot * a.n + b] - a.tf_wt;   // PottsTransformer: potts + transformer (nets.py:311-312)
     f = 0.f;
     if (a.which & 2) {                               // EnsembleProtein: mean of the networks' outputs
         for (int k = 0; k < a.n_nets; ++k) f += a.fitC[((size_t)slot * a.n_nets + k) * a.n + b];
@@ -635,12 +651,13 @@ __device__ __forceinline__ void slot_energy(const PasArgs& a, int slot, int b, f
 
 // Early-issued loads of a slot's energy terms (two per lane cover L' <= 128; longer windows take the loop).
 struct EnergyPrefetch {
-    float e0, e1, f0, f1, f2, f3;   // scalars, not an array: the struct must stay in registers
+    float e0, e1, f0, f1, f2, f3, t0;   // scalars, not an array: the struct must stay in registers
 };
 __device__ __forceinline__ EnergyPrefetch prefetch_energy(const PasArgs& a, int slot, int b) {
     EnergyPrefetch p;
     p.e0 = p.e1 = 0.f;
-    p.f0 = p.f1 = p.f2 = p.f3 = 0.f;
+    p.f0 = p.f1 = p.f2 = p.f3 = p.t0 = 0.f;
+    if (a.which & 4) p.t0 = a.tfE[(size_t)slot * a.n + b];
     const int lane = threadIdx.x & 63;
     if (a.which & 1) {                               // clamped addresses + selects: no branch, so no wait between the loads
         const float* ep = a.epart + ((size_t)slot * a.n + b) * a.g.Lp;
@@ -658,7 +675,7 @@ __device__ __forceinline__ EnergyPrefetch prefetch_energy(const PasArgs& a, int 
 }
 __device__ __forceinline__ void finish_energy(const PasArgs& a, int slot, int b, EnergyPrefetch p, float& e, float& f) {
     float dH = 0.f;
-    use_here(p.e0); use_here(p.e1); use_here(p.f0); use_here(p.f1); use_here(p.f2); use_here(p.f3);
+    use_here(p.e0); use_here(p.e1); use_here(p.f0); use_here(p.f1); use_here(p.f2); use_here(p.f3); use_here(p.t0);
     if (a.which & 1) {
         const int lane = threadIdx.x & 63;
         // lane partial in index order, as potts_hamiltonian_from_parts
@@ -669,6 +686,7 @@ __device__ __forceinline__ void finish_energy(const PasArgs& a, int slot, int b,
         }
         dH = (float)wave_sum_d(sacc) - a.wt_H;
     }
+    if (a.which & 4) dH += p.t0 - a.tf_wt;
     f = 0.f;
     if (a.which & 2) {
         f = 0.f + p.f0;                               // same order as slot_energy: ((0 + f0) + f1) + ...
@@ -696,7 +714,7 @@ struct AcceptPrefetch {
 };
 __device__ __forceinline__ AcceptPrefetch accept_prefetch(const PasArgs& a, const RowLds& lds, int b0, int it) {
     AcceptPrefetch q;
-    q.px.e0 = q.px.e1 = q.px.f0 = q.px.f1 = q.px.f2 = q.px.f3 = 0.f;
+    q.px.e0 = q.px.e1 = q.px.f0 = q.px.f1 = q.px.f2 = q.px.f3 = q.px.t0 = 0.f;
     q.cur_e = q.cur_f = q.u = q.lpf_v = 0.f;
     q.flat_v = 0;
     const int b = b0 + opaque_zero();               // keep these loads independent vector loads (see opaque_zero)

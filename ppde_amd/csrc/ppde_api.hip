@@ -39,6 +39,8 @@ static hipError_t dalloc(T** p, size_t count) {
     return hipMalloc((void**)p, count * sizeof(T));
 }
 
+#include "tf_host.h"
+
 // Scope guards for the temporaries of the host layer: every early return (HIPCHK / ARGCHK) releases them.
 struct DevTmp {
     void* p = nullptr;
@@ -79,6 +81,10 @@ struct ppde_model {
     uint32_t* s_stateT = nullptr;
     float *s_grad = nullptr, *s_epart = nullptr, *s_gradC = nullptr, *s_fitC = nullptr;
     int* s_flag = nullptr;
+    // transformer expert (tf_host.h) and the stateless API's workspace for it
+    TfModel* tf = nullptr;
+    TfWork* s_tfw = nullptr;
+    float *s_gradT = nullptr, *s_tfE = nullptr;
     // chunk maxima of the long-sequence CNN path, sized for `cnn_scratch_n` chains
     float* cnn_cmax = nullptr;
     int* cnn_carg = nullptr;
@@ -153,6 +159,10 @@ struct EvalTargets {
     int* carg = nullptr;
     uint32_t* cgate = nullptr;
     int cnn_cap = 0;          // chains the chunk scratch is sized for
+    // transformer expert: gradient rows [slots][n][N], scores [slots][n], and the owner's activation workspace
+    float* gradT = nullptr;
+    float* tfE = nullptr;
+    TfWork* tfw = nullptr;
 };
 
 // chain groups (of 64) per Potts workgroup. Measured at 256 / 512 / 1024 chains: 4 groups 7.1 / 11.3 / 18.7 us,
@@ -359,10 +369,11 @@ static int launch_experts_fused(const ppde_model* m, const States& st, int n, co
 
 static int eval_experts(const ppde_model* m, int which, const States& states, int n, const EvalTargets& t,
                         int want_grad, hipStream_t s, int b_off = 0, int n_sub = -1) {
-    if ((which & 3) == 3 && want_grad && m->has_potts && m->has_cnn) {
+    if ((which & 3) == 3 && want_grad && m->has_potts && m->has_cnn) {   // (Potts + CNN in one launch; the transformer follows)
         bool done = false;
         int rc = launch_experts_fused(m, states, n, t, m->lamda / (float)m->n_nets, s, b_off, n_sub < 0 ? n : n_sub, &done);
-        if (rc || done) return rc;
+        if (rc) return rc;
+        if (done) which &= ~3;
     }
     if (which & 1) {
         ARGCHK(m->has_potts, "the energy uses the Potts expert but ppde_model_set_potts was not called");
@@ -375,6 +386,14 @@ static int eval_experts(const ppde_model* m, int which, const States& states, in
         int rc = launch_cnn(m, states, n, t, want_grad, scale, s, b_off, n_sub);
         if (rc) return rc;
     }
+    if (which & 4) {
+        ARGCHK(m->tf, "the energy uses the transformer expert but ppde_model_set_transformer was not called");
+        ARGCHK(t.tfw && t.tfE && (t.gradT || !want_grad), "no transformer workspace for this evaluation");
+        const int ns = n_sub < 0 ? n : n_sub;
+        int rc = tf_eval(m->tf, t.tfw, states.rows + (size_t)b_off * m->g.Ls, m->g.Ls, m->g.sh, ns, t.tfE + (size_t)t.slot * n + b_off,
+                         want_grad ? t.gradT + ((size_t)t.slot * n + b_off) * m->g.N : nullptr, s);
+        if (rc) return rc;
+    }
     return PPDE_OK;
 }
 
@@ -382,6 +401,7 @@ static PasArgs base_pas_args(const ppde_model* m, int which, int n) {
     PasArgs a{};
     a.g = m->g; a.n = n; a.wt = m->d_wt; a.wt_H = m->wt_H; a.lamda = m->lamda; a.which = which;
     a.n_nets = m->n_nets;
+    a.tf_wt = m->tf ? m->tf->wt_score : 0.f;
     return a;
 }
 
@@ -420,6 +440,9 @@ int ppde_model_destroy(ppde_model* m) {
     hipFree(m->s_flag);
     hipFree(m->d_wt); hipFree(m->d_wtT); hipFree(m->d_Jt); hipFree(m->d_h); hipFree(m->cnn_cmax); hipFree(m->cnn_carg); hipFree(m->cnn_cgate);
     for (void* p : m->cnn_allocs) hipFree(p);
+    hipFree(m->s_gradT); hipFree(m->s_tfE);
+    delete m->s_tfw;
+    delete m->tf;
     delete m;
     return PPDE_OK;
 }
@@ -427,6 +450,101 @@ int ppde_model_destroy(ppde_model* m) {
 int ppde_model_set_lamda(ppde_model* m, float lamda) {
     ARGCHK(m, "null model");
     m->lamda = lamda;
+    return PPDE_OK;
+}
+
+int ppde_model_set_transformer(ppde_model* m, int n_layers, int dim, int heads, int ffn, const ppde_tf_weights* w) {
+    ARGCHK(m && w, "null argument");
+    ARGCHK(n_layers >= 1 && n_layers <= 64, "1..64 transformer layers");
+    ARGCHK(heads >= 1 && dim == heads * TF_HD, "the attention kernels are written for head width 32 (ESM-2 150M: 640 / 20)");
+    ARGCHK(heads % TF_ATT_WAVES == 0, "head count must be even");
+    ARGCHK(dim % 128 == 0 && ffn % 128 == 0 && dim <= 2 * 64 * TF_LN_MAXP, "dim and ffn must be multiples of 128, dim <= 1024");
+    ARGCHK(m->L <= TF_TP, "the transformer expert handles sequences of up to 128 residues");
+    HIPCHK(hipSetDevice(m->device));
+    delete m->tf; m->tf = nullptr;
+    delete m->s_tfw; m->s_tfw = nullptr;
+    TfModel* t = new TfModel();
+    t->layers = n_layers; t->D = dim; t->H = heads; t->F = ffn;
+    int rc = tf_build_model(t, m->L, w);
+    if (rc) { delete t; return rc; }
+    // wild type's local score (nets.py:188) with the kernels that evaluate every other state
+    TfWork wk;
+    DevTmp sc;
+    if ((rc = tf_alloc_work(t, &wk, 1)) == PPDE_OK && sc.alloc<float>(1) != hipSuccess) rc = fail(PPDE_ERR_HIP, "allocation failed");
+    if (rc == PPDE_OK) rc = tf_eval(t, &wk, m->d_wt, m->g.Ls, m->g.sh, 1, sc.as<float>(), nullptr, 0);
+    if (rc == PPDE_OK && hipMemcpy(&t->wt_score, sc.p, sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) rc = fail(PPDE_ERR_HIP, "copy failed");
+    if (rc) { delete t; return rc; }
+    m->tf = t;
+    return PPDE_OK;
+}
+
+// Timing hook for bench.py: the transformer's GEMM kernel (fc1 form: bias + GELU epilogue) on pseudo-random fp16
+// operands of the given shape, `reps` launches between one HIP event pair on a stream of its own.
+int ppde_transformer_time_gemm(int device, int M, int N, int K, int reps, float* avg_us) {
+    ARGCHK(avg_us && reps >= 1 && M > 0 && N > 0 && K > 0, "bad argument");
+    HIPCHK(hipSetDevice(device));
+    DevTmp A, B, C, C2, bias;
+    HIPCHK(A.alloc<half_t>((size_t)M * K)); HIPCHK(B.alloc<half_t>((size_t)N * K));
+    HIPCHK(C.alloc<half_t>((size_t)M * N)); HIPCHK(C2.alloc<half_t>((size_t)M * N)); HIPCHK(bias.alloc<float>((size_t)N));
+    HIPCHK(hipMemset(bias.p, 0, (size_t)N * sizeof(float)));
+    hipStream_t s;
+    HIPCHK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    struct SG { hipStream_t s; ~SG() { hipStreamDestroy(s); } } sg{s};
+    hipLaunchKernelGGL(tf_fill_random, dim3((unsigned)(((size_t)M * K + 255) / 256)), dim3(256), 0, s, A.as<half_t>(), (size_t)M * K, 1u);
+    hipLaunchKernelGGL(tf_fill_random, dim3((unsigned)(((size_t)N * K + 255) / 256)), dim3(256), 0, s, B.as<half_t>(), (size_t)N * K, 2u);
+    HIPCHK(hipGetLastError());
+    EventPair ev;
+    HIPCHK(hipEventCreate(&ev.a)); HIPCHK(hipEventCreate(&ev.b));
+    int rc = PPDE_OK;
+    for (int i = 0; i < 3 && rc == PPDE_OK; ++i)
+        rc = tf_gemm<TF_EPI_BIAS_GELU>(s, A.as<half_t>(), B.as<half_t>(), C.as<half_t>(), M, N, K, bias.as<float>(), nullptr, C2.as<half_t>());
+    if (rc) return rc;
+    HIPCHK(hipEventRecord(ev.a, s));
+    for (int i = 0; i < reps && rc == PPDE_OK; ++i)
+        rc = tf_gemm<TF_EPI_BIAS_GELU>(s, A.as<half_t>(), B.as<half_t>(), C.as<half_t>(), M, N, K, bias.as<float>(), nullptr, C2.as<half_t>());
+    if (rc) return rc;
+    HIPCHK(hipEventRecord(ev.b, s));
+    HIPCHK(hipEventSynchronize(ev.b));
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, ev.a, ev.b));
+    *avg_us = ms * 1000.f / reps;
+    return PPDE_OK;
+}
+
+// Diagnostics: an activation of the LAST stateless transformer evaluation (ppde_energy_grad with bit 2) as fp32.
+int ppde_debug_transformer_read(ppde_model* m, int what, int layer, float* out_host, int64_t count) {
+    ARGCHK(m && m->tf && m->s_tfw && out_host && count >= 0, "no transformer evaluation to read from");
+    ARGCHK(layer >= 0 && layer < m->tf->layers, "layer out of range");
+    HIPCHK(hipSetDevice(m->device));
+    HIPCHK(hipDeviceSynchronize());
+    const TfWork* w = m->s_tfw;
+    const TfLayerAct& a = w->act[layer];
+    const half_t* src = nullptr;
+    switch (what) {
+        case 0: src = a.xin; break;
+        case 1: src = a.qkv; break;
+        case 2: src = a.P; break;
+        case 3: src = a.xmid; break;
+        case 4: src = a.hpre; break;
+        case 5: src = w->xlast; break;
+        case 6: src = w->logits; break;
+        case 7: src = w->dlogits; break;
+        case 8: src = w->gA; break;
+        case 9: src = w->G33; break;
+        case 10: src = w->ctx; break;
+        case 11: src = w->dqkv; break;
+        default: return fail(PPDE_ERR_INVALID, "unknown buffer id");
+    }
+    std::vector<half_t> h((size_t)count);
+    HIPCHK(hipMemcpy(h.data(), src, (size_t)count * sizeof(half_t), hipMemcpyDeviceToHost));
+    for (int64_t i = 0; i < count; ++i) out_host[i] = (float)h[(size_t)i];
+    return PPDE_OK;
+}
+
+int ppde_model_get_transformer_wt_score(ppde_model* m, float* out_host) {
+    ARGCHK(m && out_host, "null argument");
+    ARGCHK(m->tf, "no transformer expert");
+    *out_host = m->tf->wt_score;
     return PPDE_OK;
 }
 
@@ -597,7 +715,7 @@ int ppde_idx_to_onehot(ppde_model* m, const uint8_t* idx_dev, int n, float* x_de
 int ppde_energy_grad(ppde_model* m, const uint8_t* idx_dev, int n, int which, float* e_dev, float* fit_dev,
                      float* grad_dev, void* stream) {
     ARGCHK(m && idx_dev && n >= 0, "bad argument");
-    ARGCHK(which >= 1 && which <= 3, "which must be 1 (Potts), 2 (supervised) or 3 (product of experts)");
+    ARGCHK(which >= 1 && which <= 7, "which: bit 0 Potts, bit 1 supervised, bit 2 transformer expert");
     if (n == 0) return PPDE_OK;
     HIPCHK(hipSetDevice(m->device));
     hipStream_t s = (hipStream_t)stream;
@@ -610,12 +728,25 @@ int ppde_energy_grad(ppde_model* m, const uint8_t* idx_dev, int n, int which, fl
     const States st{m->s_state, m->s_stateT, potts_t4_pad(m->scratch_n)};
     if ((which & 1) && (rc = state_rows_to_t4(m, m->s_state, m->s_stateT, n, st.n_pad, s))) return rc;
     EvalTargets t{m->s_grad, m->s_epart, m->s_gradC, m->s_fitC, 0};
+    if (which & 4) {
+        ARGCHK(m->tf, "no transformer expert");
+        if (!m->s_tfw || m->s_tfw->n_cap < n) {
+            delete m->s_tfw; m->s_tfw = nullptr;
+            hipFree(m->s_gradT); hipFree(m->s_tfE); m->s_gradT = m->s_tfE = nullptr;
+            m->s_tfw = new TfWork();
+            if ((rc = tf_alloc_work(m->tf, m->s_tfw, n))) return rc;
+            HIPCHK(dalloc(&m->s_gradT, (size_t)n * g.N));
+            HIPCHK(dalloc(&m->s_tfE, (size_t)n));
+        }
+        t.gradT = m->s_gradT; t.tfE = m->s_tfE; t.tfw = m->s_tfw;
+    }
     t.cmax = m->cnn_cmax; t.carg = m->cnn_carg; t.cgate = m->cnn_cgate; t.cnn_cap = m->cnn_scratch_n;
     // the scratch is laid out for scratch_n chains; kernels index slot 0 with stride n, which is fine for slot 0
     rc = eval_experts(m, which, st, n, t, grad_dev != nullptr, s);
     if (rc) return rc;
     PasArgs a = base_pas_args(m, which, n);
     a.grad = m->s_grad; a.epart = m->s_epart; a.gradC = m->s_gradC; a.fitC = m->s_fitC;
+    a.gradT = m->s_gradT; a.tfE = m->s_tfE;
     if (e_dev || fit_dev) {
         hipLaunchKernelGGL(k_slot_energy, dim3((n + 3) / 4), dim3(256), 0, s, a, e_dev, fit_dev);
         HIPCHK(hipGetLastError());
@@ -656,6 +787,9 @@ struct ppde_chains {
     int *tmp_bt = nullptr, *tr_flat = nullptr, *tr_U = nullptr, *err_flag = nullptr,
         *d_it = nullptr, *tmp_dist = nullptr;
     unsigned long long* dbg = nullptr;           // stamps of the diagnostic build (64 x (cycles, 100 MHz ticks))
+    // transformer expert: this object's activation workspace, gradient rows [2][n][N] and scores [2][n]
+    TfWork* tfw = nullptr;
+    float *gradT = nullptr, *tfE = nullptr;
     // chunk scratch of the long-sequence CNN path (this object's own: its graphs hold these pointers)
     float* cnn_cmax = nullptr;
     int* cnn_carg = nullptr;
@@ -683,6 +817,7 @@ static PasArgs chain_args(const ppde_chains* c) {
     a.curT = (uint8_t*)c->curT; a.propT = (uint8_t*)c->propT; a.n_pad = c->n_pad;
     a.fb_state_stride = c->cfg.paper_results ? m->g.Ls : 0;
     a.grad = c->grad; a.epart = c->epart; a.gradC = c->gradC; a.fitC = c->fitC;
+    a.gradT = c->gradT; a.tfE = c->tfE;
     a.grad_cur = c->grad_cur; a.rec = c->rec; a.rec_stride = c->rec_stride; a.wt_e = c->wt_e; a.wt_f = c->wt_f;
     a.fb_grad = c->fb_grad; a.fb_grad_stride = c->cfg.paper_results ? (size_t)m->g.N : 0;
     a.e_hist = c->e_hist; a.f_hist = c->f_hist; a.best_state = c->best_state; a.rtraj = c->rtraj;
@@ -697,6 +832,7 @@ static States prop_states(const ppde_chains* c) { return States{c->prop, c->prop
 static EvalTargets chain_targets(const ppde_chains* c, int slot) {
     EvalTargets t{c->grad, c->epart, c->gradC, c->fitC, slot, c->dbg};
     t.cmax = c->cnn_cmax; t.carg = c->cnn_carg; t.cgate = c->cnn_cgate; t.cnn_cap = c->n;
+    t.gradT = c->gradT; t.tfE = c->tfE; t.tfw = c->tfw;
     return t;
 }
 
@@ -796,6 +932,7 @@ static int capture_segment(ppde_chains* c, int len, bool inside_run) {
 // it. Captured and instantiated here, from ppde_chains_init, so that no ppde_chains_run pays for it.
 static int capture_segments(ppde_chains* c) {
     if (!c->cfg.use_graph || c->cfg.rng_mode != 1 || !c->graphs.empty()) return PPDE_OK;
+    if (c->cfg.which & 4) return PPDE_OK;           // ~900 launches per iteration, tens of milliseconds each way: nothing to gain from replay
     static const int gl_env = []() { const char* e = getenv("PPDE_GRAPH_LEN"); const int v = e ? atoi(e) : 0; return v >= 1 && v <= 1000 ? v : 0; }();
     const int lens_default[2] = {100, 20};
     for (int k = 0; k < (gl_env ? 1 : 2); ++k) {
@@ -815,7 +952,9 @@ int ppde_chains_create(ppde_chains** out, ppde_model* m, const ppde_chain_config
     ARGCHK(cfg->max_steps >= 0, "negative max_steps");
     ARGCHK(cfg->pas_length >= 1 && cfg->pas_length <= 64, "ppde_pas_length out of range");
     ARGCHK(cfg->nmut_threshold >= 0, "negative nmut_threshold");
-    ARGCHK(cfg->which >= 1 && cfg->which <= 3, "which must be 1, 2 or 3");
+    ARGCHK(cfg->which >= 1 && cfg->which <= 7, "which: bit 0 Potts, bit 1 supervised, bit 2 transformer expert");
+    ARGCHK(!(cfg->which & 4) || m->tf, "transformer expert not set");
+    ARGCHK(!(cfg->which & 4) || cfg->n_streams <= 1, "the transformer expert runs on one stream");
     ARGCHK(cfg->min_pos >= 0 && cfg->max_pos < m->L && cfg->min_pos <= cfg->max_pos, "bad [min_pos, max_pos]");
     ARGCHK(cfg->rng_mode == 0 || cfg->rng_mode == 1, "rng_mode must be 0 or 1");
     ARGCHK(cfg->random_chain < cfg->n_chains, "random_chain out of range");
@@ -852,6 +991,13 @@ int ppde_chains_create(ppde_chains** out, ppde_model* m, const ppde_chain_config
             A(&c->cnn_cgate, cnn_chunk_gate_count(m, c->n), true);
         }
     }
+    if (cfg->which & 4) {
+        A(&c->gradT, 2 * n * g.N, true); A(&c->tfE, 2 * n, true);
+        if (ok) {
+            c->tfw = new TfWork();
+            if (tf_alloc_work(m->tf, c->tfw, c->n) != PPDE_OK) ok = false;
+        }
+    }
     A(&c->fb_grad, (cfg->paper_results ? n : 1) * g.N, true);
     A(&c->fb_e, cfg->paper_results ? n : 1, true); A(&c->fb_f, cfg->paper_results ? n : 1, true);
     A(&c->e_hist, T1 * n, true); A(&c->f_hist, T1 * n, true);
@@ -878,6 +1024,7 @@ int ppde_chains_create(ppde_chains** out, ppde_model* m, const ppde_chain_config
     }
     if (!ok) {
         for (void* p : c->allocs) hipFree(p);
+        delete c->tfw;
         if (c->h_err) hipHostFree(c->h_err);
         for (hipStream_t st : c->streams) if (st) hipStreamDestroy(st);
         for (hipEvent_t ev : c->events) if (ev) hipEventDestroy(ev);
@@ -898,6 +1045,7 @@ int ppde_chains_destroy(ppde_chains* c) {
         if (gs.graph) hipGraphDestroy(gs.graph);
     }
     for (void* p : c->allocs) hipFree(p);
+    delete c->tfw;
     if (c->h_err) hipHostFree(c->h_err);
     for (hipStream_t st : c->streams) if (st) hipStreamDestroy(st);
     for (hipEvent_t ev : c->events) if (ev) hipEventDestroy(ev);

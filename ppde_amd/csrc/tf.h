@@ -560,8 +560,8 @@ __global__ __launch_bounds__(64 * TF_ATT_WAVES) void tf_attn_bwd(TfAttnArgs a) {
 // gdirect[m][a] = logp[l][token of Potts letter a]  (the explicit x in sum x * log_softmax).
 // ------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void tf_score(const half_t* __restrict__ logits, const uint8_t* __restrict__ idx, int Ls, int sh,
-                                                int L, const int* __restrict__ perm, float* __restrict__ score,
-                                                half_t* __restrict__ dlogits, float* __restrict__ gdirect) {
+                                                int L, const int* __restrict__ perm, const int* __restrict__ pinv,
+                                                float* __restrict__ score, half_t* __restrict__ dlogits, float* __restrict__ gdirect) {
     __shared__ float red[8];
     const int b = blockIdx.x;
     float part = 0.f;
@@ -582,10 +582,8 @@ __global__ __launch_bounds__(256) void tf_score(const half_t* __restrict__ logit
             const float lp = v[k] - lse;
             if (k == tok) part += lp;
             if (dl) dl[k] = (half_t)((k == tok ? 1.0f : 0.0f) - expf(lp));
-        }
-        if (gdirect) {
-#pragma unroll
-            for (int aa = 0; aa < 20; ++aa) gdirect[m * 20 + aa] = v[perm[aa]] - lse;
+            const int aa = pinv[k];                            // Potts letter of token k, or -1 (static index into v: no scratch)
+            if (gdirect && aa >= 0) gdirect[m * 20 + aa] = lp;
         }
     }
     int phase = 0;

@@ -1,0 +1,243 @@
+// Host side of the transformer expert (tf.h): weight upload (fp16 copies in both orientations), activation
+// workspace of one owner (a ppde_chains or the stateless API), and the launch sequence of one evaluation
+// (forward over all layers, score, backward to the one-hot input). Included by ppde_api.hip.
+#pragma once
+#include "tf.h"
+
+struct TfLayerW {
+    half_t *Wqkv = nullptr, *WqkvT = nullptr, *Wo = nullptr, *WoT = nullptr, *W1 = nullptr, *W1T = nullptr, *W2 = nullptr, *W2T = nullptr;
+    float *bqkv = nullptr, *bo = nullptr, *b1 = nullptr, *b2 = nullptr, *ln1g = nullptr, *ln1b = nullptr, *ln2g = nullptr, *ln2b = nullptr;
+};
+struct TfModel {
+    int layers = 0, D = 0, H = 0, F = 0, L = 0;
+    std::vector<TfLayerW> lw;
+    half_t *E16 = nullptr, *E16T = nullptr, *Wd = nullptr, *WdT = nullptr;      // E16 [128][D] (rows >= 33 zero), E16T [D][128]
+    float *bd = nullptr, *lnf_g = nullptr, *lnf_b = nullptr, *lnh_g = nullptr, *lnh_b = nullptr, *blm = nullptr;
+    int* perm = nullptr;                  // ESM token of each Potts letter
+    int* pinv = nullptr;                  // Potts letter of each ESM token (-1: none)
+    float *rope_cos = nullptr, *rope_sin = nullptr;   // [L][16]
+    float wt_score = 0.f;
+    std::vector<void*> allocs;
+    ~TfModel() { for (void* p : allocs) hipFree(p); }
+};
+
+struct TfLayerAct {
+    half_t *xin = nullptr, *qkv = nullptr, *P = nullptr, *xmid = nullptr, *hpre = nullptr;
+    float *mean1 = nullptr, *rstd1 = nullptr, *mean2 = nullptr, *rstd2 = nullptr;
+};
+struct TfWork {
+    int n_cap = 0, M_pad = 0;
+    std::vector<TfLayerAct> act;
+    half_t *xlast = nullptr, *ln_out = nullptr, *ctx = nullptr, *actf = nullptr, *head_y = nullptr, *head_a = nullptr, *head_z = nullptr,
+           *logits = nullptr, *dlogits = nullptr, *G33 = nullptr, *gA = nullptr, *gB = nullptr, *dF = nullptr, *dqkv = nullptr, *tmpD = nullptr;
+    float *meanf = nullptr, *rstdf = nullptr, *meanh = nullptr, *rstdh = nullptr, *gdirect = nullptr;
+    std::vector<void*> allocs;
+    ~TfWork() { for (void* p : allocs) hipFree(p); }
+};
+
+static std::vector<half_t> tf_to_half(const float* w, size_t rows, size_t cols, size_t rows_pad, size_t cols_pad, bool transpose) {
+    // -> [rows_pad][cols_pad] (or its transpose [cols_pad][rows_pad]) fp16, zero padded
+    std::vector<half_t> o(rows_pad * cols_pad, (half_t)0.f);
+    for (size_t r = 0; r < rows; ++r)
+        for (size_t c = 0; c < cols; ++c) {
+            const half_t v = (half_t)w[r * cols + c];
+            if (!transpose) o[r * cols_pad + c] = v;
+            else o[c * rows_pad + r] = v;
+        }
+    return o;
+}
+
+template <typename T>
+static int tf_upload(std::vector<void*>& allocs, const std::vector<T>& h, T** out) {
+    T* d = nullptr;
+    HIPCHK(dalloc(&d, h.size()));
+    allocs.push_back(d);
+    HIPCHK(hipMemcpy(d, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
+    *out = d;
+    return PPDE_OK;
+}
+#define TFUP(vec, dst) do { int rc_ = tf_upload(t->allocs, vec, &(dst)); if (rc_) return rc_; } while (0)
+
+static int tf_build_model(TfModel* t, int L, const ppde_tf_weights* w) {
+    const int D = t->D, F = t->F;
+    t->L = L;
+    t->lw.resize(t->layers);
+    for (int l = 0; l < t->layers; ++l) {
+        TfLayerW& x = t->lw[l];
+        // q, k, v projections fused: rows [0, D) = q, [D, 2D) = k, [2D, 3D) = v
+        std::vector<float> wqkv((size_t)3 * D * D), bqkv((size_t)3 * D);
+        memcpy(wqkv.data(), w->q_w[l], sizeof(float) * D * D);
+        memcpy(wqkv.data() + (size_t)D * D, w->k_w[l], sizeof(float) * D * D);
+        memcpy(wqkv.data() + (size_t)2 * D * D, w->v_w[l], sizeof(float) * D * D);
+        memcpy(bqkv.data(), w->q_b[l], sizeof(float) * D);
+        memcpy(bqkv.data() + D, w->k_b[l], sizeof(float) * D);
+        memcpy(bqkv.data() + 2 * D, w->v_b[l], sizeof(float) * D);
+        TFUP(tf_to_half(wqkv.data(), 3 * D, D, 3 * D, D, false), x.Wqkv);
+        TFUP(tf_to_half(wqkv.data(), 3 * D, D, 3 * D, D, true), x.WqkvT);
+        TFUP(tf_to_half(w->o_w[l], D, D, D, D, false), x.Wo);
+        TFUP(tf_to_half(w->o_w[l], D, D, D, D, true), x.WoT);
+        TFUP(tf_to_half(w->fc1_w[l], F, D, F, D, false), x.W1);
+        TFUP(tf_to_half(w->fc1_w[l], F, D, F, D, true), x.W1T);
+        TFUP(tf_to_half(w->fc2_w[l], D, F, D, F, false), x.W2);
+        TFUP(tf_to_half(w->fc2_w[l], D, F, D, F, true), x.W2T);
+        TFUP(bqkv, x.bqkv);
+        TFUP(std::vector<float>(w->o_b[l], w->o_b[l] + D), x.bo);
+        TFUP(std::vector<float>(w->fc1_b[l], w->fc1_b[l] + F), x.b1);
+        TFUP(std::vector<float>(w->fc2_b[l], w->fc2_b[l] + D), x.b2);
+        TFUP(std::vector<float>(w->ln1_w[l], w->ln1_w[l] + D), x.ln1g);
+        TFUP(std::vector<float>(w->ln1_b[l], w->ln1_b[l] + D), x.ln1b);
+        TFUP(std::vector<float>(w->ln2_w[l], w->ln2_w[l] + D), x.ln2g);
+        TFUP(std::vector<float>(w->ln2_b[l], w->ln2_b[l] + D), x.ln2b);
+    }
+    TFUP(tf_to_half(w->embed, TF_VOCAB, D, TF_VOCAB_PAD, D, false), t->E16);
+    TFUP(tf_to_half(w->embed, TF_VOCAB, D, TF_VOCAB_PAD, D, true), t->E16T);
+    TFUP(tf_to_half(w->head_dense_w, D, D, D, D, false), t->Wd);
+    TFUP(tf_to_half(w->head_dense_w, D, D, D, D, true), t->WdT);
+    TFUP(std::vector<float>(w->head_dense_b, w->head_dense_b + D), t->bd);
+    TFUP(std::vector<float>(w->final_ln_w, w->final_ln_w + D), t->lnf_g);
+    TFUP(std::vector<float>(w->final_ln_b, w->final_ln_b + D), t->lnf_b);
+    TFUP(std::vector<float>(w->head_ln_w, w->head_ln_w + D), t->lnh_g);
+    TFUP(std::vector<float>(w->head_ln_b, w->head_ln_b + D), t->lnh_b);
+    std::vector<float> blm(TF_VOCAB_PAD, 0.f);
+    for (int k = 0; k < TF_VOCAB; ++k) blm[k] = w->head_bias[k];
+    TFUP(blm, t->blm);
+    // ESM-2 alphabet (facebookresearch/esm, `Alphabet.from_architecture("ESM-1b")`): <cls> <pad> <eos> <unk> L A G V S E R T
+    // I D P K Q N F Y M H W C X B U Z O . - <null_1> <mask>; Potts letters ACDEFGHIKLMNPQRSTVWY (hsu/data_utils.py:48-70)
+    static const char* esm = "....LAGVSERTIDPKQNFYMHWC";
+    static const char* potts = "ACDEFGHIKLMNPQRSTVWY";
+    std::vector<int> perm(20);
+    for (int a = 0; a < 20; ++a) perm[a] = (int)(strchr(esm + 4, potts[a]) - esm);
+    TFUP(perm, t->perm);
+    std::vector<int> pinv(TF_VOCAB, -1);
+    for (int a = 0; a < 20; ++a) pinv[perm[a]] = a;
+    TFUP(pinv, t->pinv);
+    std::vector<float> rc((size_t)L * 16), rs((size_t)L * 16);
+    for (int p = 0; p < L; ++p)
+        for (int d = 0; d < 16; ++d) {
+            const float inv = 1.0f / powf(10000.0f, (float)(2 * d) / (float)TF_HD);
+            const float ang = (float)p * inv;            // (fp32 product, as torch.outer of fp32 tensors)
+            rc[(size_t)p * 16 + d] = cosf(ang);
+            rs[(size_t)p * 16 + d] = sinf(ang);
+        }
+    TFUP(rc, t->rope_cos);
+    TFUP(rs, t->rope_sin);
+    return PPDE_OK;
+}
+
+static int tf_alloc_work(const TfModel* t, TfWork* wk, int n) {
+    const int D = t->D, F = t->F, L = t->L;
+    wk->n_cap = n;
+    const int M = n * L, Mp = (M + 127) & ~127;
+    wk->M_pad = Mp;
+    bool ok = true;
+    auto A = [&](auto** p, size_t count) {
+        if (!ok) return;
+        if (dalloc(p, count) != hipSuccess) { ok = false; return; }
+        wk->allocs.push_back((void*)*p);
+        if (hipMemset((void*)*p, 0, count * sizeof(**p)) != hipSuccess) ok = false;
+    };
+    wk->act.resize(t->layers);
+    for (auto& a : wk->act) {
+        A(&a.xin, (size_t)Mp * D); A(&a.qkv, (size_t)Mp * 3 * D); A(&a.P, (size_t)n * t->H * L * TF_TP);
+        A(&a.xmid, (size_t)Mp * D); A(&a.hpre, (size_t)Mp * F);
+        A(&a.mean1, (size_t)Mp); A(&a.rstd1, (size_t)Mp); A(&a.mean2, (size_t)Mp); A(&a.rstd2, (size_t)Mp);
+    }
+    A(&wk->xlast, (size_t)Mp * D); A(&wk->ln_out, (size_t)Mp * D); A(&wk->ctx, (size_t)Mp * D); A(&wk->actf, (size_t)Mp * F);
+    A(&wk->head_y, (size_t)Mp * D); A(&wk->head_a, (size_t)Mp * D); A(&wk->head_z, (size_t)Mp * D);
+    A(&wk->logits, (size_t)Mp * TF_VOCAB_PAD); A(&wk->dlogits, (size_t)Mp * TF_VOCAB_PAD); A(&wk->G33, (size_t)Mp * TF_VOCAB_PAD);
+    A(&wk->gA, (size_t)Mp * D); A(&wk->gB, (size_t)Mp * D); A(&wk->dF, (size_t)Mp * F); A(&wk->dqkv, (size_t)Mp * 3 * D); A(&wk->tmpD, (size_t)Mp * D);
+    A(&wk->meanf, (size_t)Mp); A(&wk->rstdf, (size_t)Mp); A(&wk->meanh, (size_t)Mp); A(&wk->rstdh, (size_t)Mp);
+    A(&wk->gdirect, (size_t)Mp * 20);
+    if (!ok) return fail(PPDE_ERR_HIP, "device allocation failed for the transformer workspace");
+    return PPDE_OK;
+}
+
+template <int EPI>
+static int tf_gemm(hipStream_t s, const half_t* A, const half_t* B, half_t* C, int M, int N, int K, const float* bias = nullptr,
+                   const half_t* R = nullptr, half_t* C2 = nullptr, float alpha = 1.f, int qcols = 0) {
+    ARGCHK(M % 128 == 0 && N % 128 == 0 && K % 64 == 0, "transformer GEMM shape is not a multiple of the 128 x 128 x 64 tile");
+    TfGemmArgs g{A, B, C, bias, R, C2, M, N, K, alpha, qcols};
+    hipLaunchKernelGGL(tf_gemm_nt<EPI>, dim3((M >> 7) * (N >> 7)), dim3(256), 4 * 128 * 64 * sizeof(half_t), s, g);
+    HIPCHK(hipGetLastError());
+    return PPDE_OK;
+}
+static int tf_ln(hipStream_t s, bool bwd, const half_t* x, half_t* y, const float* gamma, const float* beta, float* mean, float* rstd,
+                 int M, int D, const half_t* dy = nullptr, const half_t* gres = nullptr, float out_scale = 1.f) {
+    TfLnArgs a{x, y, gamma, beta, mean, rstd, dy, gres, M, D, out_scale};
+    if (bwd) hipLaunchKernelGGL(tf_ln_bwd, dim3((M + 3) / 4), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(tf_ln_fwd, dim3((M + 3) / 4), dim3(256), 0, s, a);
+    HIPCHK(hipGetLastError());
+    return PPDE_OK;
+}
+__global__ void tf_gelu_bwd_ew(const half_t* __restrict__ da, const half_t* __restrict__ y, half_t* __restrict__ dy, size_t count) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < count) dy[i] = (half_t)((float)da[i] * tf_gelu_grad((float)y[i]));
+}
+// pseudo-random fp16 operands for the GEMM timing hook (zero operands would flatter the clock)
+__global__ void tf_fill_random(half_t* p, size_t count, uint32_t seed) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    const U4 r = philox4x32_10(U4{(uint32_t)i, (uint32_t)(i >> 32), seed, 0u}, 0x1234u, 0x5678u);
+    p[i] = (half_t)(((float)(r.x >> 8) * 5.9604644775390625e-08f - 0.5f) * 0.25f);
+}
+#define TFRC(x) do { int rc_ = (x); if (rc_) return rc_; } while (0)
+
+// One evaluation: scores of n chains (state rows) into score_out [n], and, when grad_out is not NULL, the gradient of
+// the scores w.r.t. the Potts one-hot input into grad_out rows [n][L*20] (fp32).
+static int tf_eval(const TfModel* t, TfWork* wk, const uint8_t* rows, int Ls, int sh, int n, float* score_out, float* grad_out, hipStream_t s) {
+    ARGCHK(n <= wk->n_cap, "transformer workspace too small for this batch");
+    const int D = t->D, F = t->F, L = t->L, H = t->H, M = n * L, Mp = (M + 127) & ~127;
+    const float qs = 1.0f / sqrtf((float)TF_HD);
+    hipLaunchKernelGGL(tf_embed, dim3(M), dim3(128), 0, s, rows, Ls, sh, L, n, t->perm, t->E16, D, wk->act[0].xin);
+    HIPCHK(hipGetLastError());
+    for (int l = 0; l < t->layers; ++l) {
+        const TfLayerW& w = t->lw[l];
+        TfLayerAct& a = wk->act[l];
+        half_t* xnext = l + 1 < t->layers ? wk->act[l + 1].xin : wk->xlast;
+        TFRC(tf_ln(s, false, a.xin, wk->ln_out, w.ln1g, w.ln1b, a.mean1, a.rstd1, M, D));
+        TFRC(tf_gemm<TF_EPI_BIAS_QSCALE>(s, wk->ln_out, w.Wqkv, a.qkv, Mp, 3 * D, D, w.bqkv, nullptr, nullptr, qs, D));
+        TfAttnArgs at{a.qkv, wk->ctx, a.P, t->rope_cos, t->rope_sin, nullptr, nullptr, n, L, H, D, qs};
+        hipLaunchKernelGGL(tf_attn_fwd, dim3(n * (H / TF_ATT_WAVES)), dim3(64 * TF_ATT_WAVES), tf_attn_fwd_lds(), s, at);
+        HIPCHK(hipGetLastError());
+        TFRC(tf_gemm<TF_EPI_BIAS_RESID>(s, wk->ctx, w.Wo, a.xmid, Mp, D, D, w.bo, a.xin));
+        TFRC(tf_ln(s, false, a.xmid, wk->ln_out, w.ln2g, w.ln2b, a.mean2, a.rstd2, M, D));
+        TFRC(tf_gemm<TF_EPI_BIAS_GELU>(s, wk->ln_out, w.W1, wk->actf, Mp, F, D, w.b1, nullptr, a.hpre));
+        TFRC(tf_gemm<TF_EPI_BIAS_RESID>(s, wk->actf, w.W2, xnext, Mp, D, F, w.b2, a.xmid));
+    }
+    TFRC(tf_ln(s, false, wk->xlast, wk->ln_out, t->lnf_g, t->lnf_b, wk->meanf, wk->rstdf, M, D));
+    TFRC(tf_gemm<TF_EPI_BIAS_GELU>(s, wk->ln_out, t->Wd, wk->head_a, Mp, D, D, t->bd, nullptr, wk->head_y));
+    TFRC(tf_ln(s, false, wk->head_a, wk->head_z, t->lnh_g, t->lnh_b, wk->meanh, wk->rstdh, M, D));
+    TFRC(tf_gemm<TF_EPI_BIAS>(s, wk->head_z, t->E16, wk->logits, Mp, TF_VOCAB_PAD, D, t->blm));
+    hipLaunchKernelGGL(tf_score, dim3(n), dim3(256), 0, s, wk->logits, rows, Ls, sh, L, t->perm, t->pinv, score_out,
+                       grad_out ? wk->dlogits : (half_t*)nullptr, grad_out ? wk->gdirect : (float*)nullptr);
+    HIPCHK(hipGetLastError());
+    if (!grad_out) return PPDE_OK;
+
+    // ---- backward to the one-hot input
+    TFRC(tf_gemm<TF_EPI_PLAIN>(s, wk->dlogits, t->E16T, wk->tmpD, Mp, D, TF_VOCAB_PAD));
+    TFRC(tf_ln(s, true, wk->head_a, wk->gB, t->lnh_g, t->lnh_b, wk->meanh, wk->rstdh, M, D, wk->tmpD));
+    {
+        const size_t cnt = (size_t)M * D;
+        hipLaunchKernelGGL(tf_gelu_bwd_ew, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, s, wk->gB, wk->head_y, wk->gA, cnt);
+        HIPCHK(hipGetLastError());
+    }
+    TFRC(tf_gemm<TF_EPI_PLAIN>(s, wk->gA, t->WdT, wk->tmpD, Mp, D, D));
+    TFRC(tf_ln(s, true, wk->xlast, wk->gA, t->lnf_g, t->lnf_b, wk->meanf, wk->rstdf, M, D, wk->tmpD));
+    for (int l = t->layers - 1; l >= 0; --l) {
+        const TfLayerW& w = t->lw[l];
+        TfLayerAct& a = wk->act[l];
+        TFRC(tf_gemm<TF_EPI_GELU_BWD>(s, wk->gA, w.W2T, wk->dF, Mp, F, D, nullptr, a.hpre));
+        TFRC(tf_gemm<TF_EPI_PLAIN>(s, wk->dF, w.W1T, wk->tmpD, Mp, D, F));
+        TFRC(tf_ln(s, true, a.xmid, wk->gB, w.ln2g, w.ln2b, a.mean2, a.rstd2, M, D, wk->tmpD, wk->gA));
+        TFRC(tf_gemm<TF_EPI_PLAIN>(s, wk->gB, w.WoT, wk->tmpD, Mp, D, D));
+        TfAttnArgs at{a.qkv, nullptr, a.P, t->rope_cos, t->rope_sin, wk->tmpD, wk->dqkv, n, L, H, D, qs};
+        hipLaunchKernelGGL(tf_attn_bwd, dim3(n * (H / TF_ATT_WAVES)), dim3(64 * TF_ATT_WAVES), tf_attn_bwd_lds(), s, at);
+        HIPCHK(hipGetLastError());
+        TFRC(tf_gemm<TF_EPI_PLAIN>(s, wk->dqkv, w.WqkvT, wk->tmpD, Mp, D, 3 * D));
+        TFRC(tf_ln(s, true, a.xin, wk->gA, w.ln1g, w.ln1b, a.mean1, a.rstd1, M, D, wk->tmpD, wk->gB, l == 0 ? TF_TOKEN_DROPOUT_SCALE : 1.f));
+    }
+    TFRC(tf_gemm<TF_EPI_PLAIN>(s, wk->gA, t->E16, wk->G33, Mp, TF_VOCAB_PAD, D));
+    hipLaunchKernelGGL(tf_finish_grad, dim3((M * 20 + 255) / 256), dim3(256), 0, s, wk->G33, wk->gdirect, t->perm, M, grad_out, 0);
+    HIPCHK(hipGetLastError());
+    return PPDE_OK;
+}

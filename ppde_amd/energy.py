@@ -20,7 +20,7 @@ from . import _hip
 from .encoding import idx_to_onehot
 from .weights import PottsParams, load_cnn_states, load_wt
 
-WHICH_POTTS, WHICH_SUPERVISED, WHICH_POE = 1, 2, 3
+WHICH_POTTS, WHICH_SUPERVISED, WHICH_POE, WHICH_TRANSFORMER = 1, 2, 3, 4
 
 
 def _device_index(device):
@@ -85,6 +85,41 @@ class HipModel:
         _hip.check(self.lib.ppde_model_set_cnn(self.handle, len(nets), Cc, K, F, arr("cw"), arr("cb"), arr("lw"),
                                                arr("lb"), arr("dw"), arr("db")))
         self.has_cnn, self.n_nets = True, len(nets)
+
+    def set_transformer(self, state, heads):
+        """state: ESM-2 state dict (numpy / tensors, facebookresearch/esm parameter names); heads: attention heads."""
+        g = lambda k: np.ascontiguousarray(np.asarray(state[k].detach().cpu() if isinstance(state[k], torch.Tensor) else state[k],
+                                                      dtype=np.float32))
+        n_layers = 1 + max(int(k.split(".")[1]) for k in state if k.startswith("layers."))
+        dim = int(g("embed_tokens.weight").shape[1])
+        ffn = int(g("layers.0.fc1.weight").shape[0])
+        if g("embed_tokens.weight").shape[0] != 33:
+            raise ValueError("the transformer expert expects ESM-2's 33-token alphabet")
+        names = dict(q_w="self_attn.q_proj.weight", q_b="self_attn.q_proj.bias", k_w="self_attn.k_proj.weight",
+                     k_b="self_attn.k_proj.bias", v_w="self_attn.v_proj.weight", v_b="self_attn.v_proj.bias",
+                     o_w="self_attn.out_proj.weight", o_b="self_attn.out_proj.bias", ln1_w="self_attn_layer_norm.weight",
+                     ln1_b="self_attn_layer_norm.bias", ln2_w="final_layer_norm.weight", ln2_b="final_layer_norm.bias",
+                     fc1_w="fc1.weight", fc1_b="fc1.bias", fc2_w="fc2.weight", fc2_b="fc2.bias")
+        keep, w = [], _hip.TfWeights()
+        emb = g("embed_tokens.weight"); keep.append(emb); w.embed = emb.ctypes.data
+        for field, nm in names.items():
+            arrs = [g(f"layers.{i}.{nm}") for i in range(n_layers)]
+            keep.append(arrs)
+            ptrs = (C.c_void_p * n_layers)(*[a.ctypes.data for a in arrs]); keep.append(ptrs)
+            setattr(w, field, ptrs)
+        for field, nm in dict(final_ln_w="emb_layer_norm_after.weight", final_ln_b="emb_layer_norm_after.bias",
+                              head_dense_w="lm_head.dense.weight", head_dense_b="lm_head.dense.bias",
+                              head_ln_w="lm_head.layer_norm.weight", head_ln_b="lm_head.layer_norm.bias", head_bias="lm_head.bias").items():
+            a = g(nm); keep.append(a); setattr(w, field, a.ctypes.data)
+        with torch.cuda.device(self.device):
+            _hip.check(self.lib.ppde_model_set_transformer(self.handle, n_layers, dim, int(heads), ffn, C.byref(w)))
+        self.has_transformer, self.tf_shape = True, (n_layers, dim, int(heads), ffn)
+
+    @property
+    def transformer_wt_score(self):
+        v = C.c_float()
+        _hip.check(self.lib.ppde_model_get_transformer_wt_score(self.handle, C.byref(v)))
+        return v.value
 
     def set_lamda(self, lamda):
         _hip.check(self.lib.ppde_model_set_lamda(self.handle, float(lamda)))
@@ -203,8 +238,47 @@ def _advance_generator_like_reference(L):
         torch.nn.Linear(2 * L, 1)
 
 
+class TransformerScore:
+    """What callers read off the reference's Transformer / PottsTransformer (ppde/nets.py:172-240, :302-312): the
+    (Delta-)score of full-length one-hot sequences."""
+
+    def __init__(self, model, which):
+        self._model, self._which = model, which
+
+    @property
+    def wt_score(self):
+        return torch.tensor(self._model.transformer_wt_score)
+
+    def preprocess_onehot(self, x):
+        return x
+
+    def __call__(self, x_full, delta=True):
+        e, _, _ = self._model.energy_grad(self._model.onehot_to_idx(x_full), self._which, want_grad=False)
+        if delta:
+            return e
+        off = self._model.transformer_wt_score + (self._model.wt_hamiltonian if self._which & WHICH_POTTS else 0.0)
+        return e + off
+
+
+# ESM-2 checkpoints the reference's `--unsupervised_expert` names map to (nets.py:176-181) and their head counts
+ESM2_CHECKPOINTS = {"transformer-S": ("esm2_t12_35M_UR50D", 20), "transformer-M": ("esm2_t30_150M_UR50D", 20),
+                    "transformer": ("esm2_t30_150M_UR50D", 20), "transformer-L": ("esm2_t33_650M_UR50D", 20),
+                    "potts+transformer": ("esm2_t30_150M_UR50D", 20)}
+
+
 class _HipEnergy(torch.nn.Module):
     which = WHICH_POE
+
+    def _setup_transformer(self, args, dataset):
+        """The reference fetches the ESM-2 weights from torch hub at run time (nets.py:177-181, hub dir = --hub_dir); here the
+        checkpoint file must already be there: <hub_dir>/checkpoints/<name>.pt, or next to the protein's other weights."""
+        from .weights import load_esm2_state
+        name, heads = ESM2_CHECKPOINTS[args.unsupervised_expert]
+        cands = [os.path.join(getattr(args, "hub_dir", "."), "checkpoints", name + ".pt"), os.path.join(dataset, name + ".pt")]
+        path = next((c for c in cands if os.path.exists(c)), None)
+        if path is None:
+            raise FileNotFoundError(f"ESM-2 checkpoint {name}.pt not found (looked in {cands}); there is no network download here")
+        self.model.set_transformer(load_esm2_state(path), heads)
 
     def _setup(self, args, with_potts):
         dataset = os.path.join(args.protein_weights, args.protein)
@@ -248,15 +322,23 @@ class ProteinProductOfExperts(_HipEnergy):
         super().__init__()
         self.lamda = args.energy_lamda
         self.unsupervised_expert_type = args.unsupervised_expert
-        if args.unsupervised_expert != "potts":
-            raise NotImplementedError(
-                f"unsupervised_expert={args.unsupervised_expert!r}: only the Potts expert is on the HIP path "
-                "(the transformer experts are out of scope, see DESIGN.md)")
-        self._setup(args, with_potts=True)
+        ue = args.unsupervised_expert
+        if ue == "potts":
+            self._setup(args, with_potts=True)
+            self.unsup_which = WHICH_POTTS
+        elif ue in ESM2_CHECKPOINTS:                       # energy.py:84-90: 'potts+transformer' or any '*transformer*'
+            self.unsupervised_expert_type = "transformer"
+            self._setup(args, with_potts=(ue == "potts+transformer"))
+            self._setup_transformer(args, os.path.join(args.protein_weights, args.protein))
+            self.unsup_which = WHICH_TRANSFORMER | (WHICH_POTTS if ue == "potts+transformer" else 0)
+            self.unsupervised_expert = TransformerScore(self.model, self.unsup_which)
+        else:
+            raise ValueError(f"unknown unsupervised_expert {ue!r}")
+        self.which = self.unsup_which | WHICH_SUPERVISED
         self.model.set_lamda(self.lamda)
 
     def get_unsupervised_expert(self, x):
-        return self._eval(x, WHICH_POTTS, False)[0]
+        return self._eval(x, self.unsup_which, False)[0]
 
 
 class ProteinSupervised(_HipEnergy):

@@ -111,6 +111,20 @@ def make_esm2_state(n_layers, dim, heads, ffn, seed=0):
     return st
 
 
+def write_esm2_checkpoint(path, n_layers, dim, heads, ffn, seed=0):
+    """Synthetic ESM-2 checkpoint in the published file format (prefixed names, tied lm_head.weight included)."""
+    import torch
+    st = make_esm2_state(n_layers, dim, heads, ffn, seed)
+    sd = {}
+    for k, v in st.items():
+        pre = "encoder." if k.startswith("lm_head") else "encoder.sentence_encoder."
+        sd[pre + k] = torch.from_numpy(v)
+    sd["encoder.lm_head.weight"] = sd["encoder.sentence_encoder.embed_tokens.weight"]
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    torch.save({"model": sd}, path)
+    return st
+
+
 def make_linear(L, seed):
     rng = np.random.default_rng(20_000 + seed)
     return {

@@ -56,3 +56,21 @@ def load_linear(protein_dir, seeds=range(20)):
 def load_wt(protein_dir):
     seqs = read_fasta(os.path.join(protein_dir, "wt.fasta"), return_ids=False)
     return seqs, seqs_to_idx(seqs)
+
+
+def load_esm2_state(path):
+    """ESM-2 checkpoint -> state dict with the module's own parameter names (embed_tokens.weight, layers.i..., lm_head...).
+    Accepts the published files ({'model': {...}} with 'encoder.sentence_encoder.' / 'encoder.' prefixes, which
+    facebookresearch/esm strips on load) as well as already stripped dicts."""
+    ck = torch.load(path, map_location="cpu")
+    sd = ck["model"] if isinstance(ck, dict) and "model" in ck else ck
+    out = {}
+    for k, v in sd.items():
+        for pre in ("encoder.sentence_encoder.", "encoder."):
+            if k.startswith(pre):
+                k = k[len(pre):]
+                break
+        if k == "lm_head.weight" or k.endswith("inv_freq") or "contact_head" in k:
+            continue                                    # tied to embed_tokens / buffers / unused head
+        out[k] = v.detach().cpu().numpy().astype(np.float32)
+    return out

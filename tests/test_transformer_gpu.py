@@ -1,0 +1,136 @@
+"""GPU parity of the transformer unsupervised expert (BASELINE config 5) against oracle/esm_oracle.py.
+
+PARITY UNPINNED: the reference's model is the third-party esm_one_hot ESM-2 with hub weights, neither of which is in
+the mount; the oracle restates the published architecture on self-generated seeded weights (see its header).
+Tolerances (fp16 matmuls with fp32 accumulation on both sides, fp16 tensors at the same places): scores
+2e-3 * (1 + |s|) ... the observed ratios are appended to gpurun_out/parity_observed.json."""
+import os
+import tempfile
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import esm_oracle as eo
+from ppde_amd import _hip, synthetic
+from ppde_amd.encoding import seqs_to_idx
+from test_hip_parity import observed
+
+
+def _model(L, layers, dim, heads, ffn, seed=3, with_cnn=False, potts=None):
+    from ppde_amd.energy import HipModel
+    rng = np.random.default_rng(seed)
+    wt = rng.integers(0, 20, L).astype(np.uint8)
+    st = synthetic.make_esm2_state(layers, dim, heads, ffn, seed=seed)
+    m = HipModel(wt, "cuda:0")
+    if potts:
+        J, h = synthetic.make_potts(potts[1], seed=seed)
+        m.set_potts(J, h, potts[0])
+    cnn = None
+    if with_cnn:
+        cnn = [synthetic.make_cnn_state(L, s) for s in range(3)]
+        m.set_cnn(cnn)
+    m.set_transformer(st, heads)
+    return m, wt, st, cnn
+
+
+def _read(m, what, layer, shape):
+    out = np.empty(int(np.prod(shape)), np.float32)
+    _hip.check(m.lib.ppde_debug_transformer_read(m.handle, what, layer, _hip.ptr(out), out.size))
+    return out.reshape(shape)
+
+
+@pytest.mark.parametrize("L,layers,dim,heads,ffn,n", [(24, 2, 128, 4, 256, 5),        # toy
+                                                       (104, 30, 640, 20, 2560, 3)])    # esm2_t30_150M shapes, UBE4B length
+def test_score_and_gradient_vs_oracle(L, layers, dim, heads, ffn, n):
+    m, wt, st, _ = _model(L, layers, dim, heads, ffn)
+    orc = eo.EsmOracle(st, layers, dim, heads, half_points=True)
+    rng = np.random.default_rng(L)
+    idx = np.tile(wt, (n, 1))
+    for b in range(1, n):
+        pos = rng.choice(L, size=min(L, 3 * b), replace=False)
+        idx[b, pos] = rng.integers(0, 20, len(pos))
+    orc.trace = {}
+    s_o, g_o = orc.score_grad(idx.astype(np.int64))
+    tr, orc.trace = orc.trace, None
+    wt_o = float(orc.score_grad(wt.astype(np.int64)[None])[0][0])
+    e, fit, g = m.energy_grad(torch.as_tensor(idx).cuda(), 4)
+    # intermediates first: they localise a failure
+    M = n * L
+    for name, what, layer, shape, ref in [("x0", 0, 0, (M, dim), tr["xin0"].reshape(M, dim)),
+                                          ("qkv0", 1, 0, (M, 3 * dim), tr["qkv0"].reshape(M, 3 * dim)),
+                                          ("xmid0", 3, 0, (M, dim), tr["xmid0"].reshape(M, dim)),
+                                          ("xlast", 5, 0, (M, dim), tr["xlast"].reshape(M, dim))]:
+        got = _read(m, what, layer, shape)
+        err = np.abs(got - ref.numpy())
+        assert observed(f"tf{layers}:{name}", err.max(), 2e-2 * (1 + np.abs(ref.numpy()).max())) <= 1.0, name
+    lg = _read(m, 6, 0, (M, 128))[:, :33]
+    assert observed(f"tf{layers}:logits", np.abs(lg - tr["logits"].reshape(M, 33).numpy()).max(), 3e-2 * (1 + tr["logits"].abs().max().item())) <= 1.0
+    assert observed(f"tf{layers}:wt_score", abs(m.transformer_wt_score - wt_o), 2e-3 * (1 + abs(wt_o))) <= 1.0
+    s_dev = e.cpu().numpy() + m.transformer_wt_score
+    assert observed(f"tf{layers}:score", np.abs(s_dev - s_o.numpy()), 2e-3 * (1 + np.abs(s_o.numpy()))) <= 1.0
+    assert float(e[0]) == 0.0                                   # the wild type's Delta is exactly zero
+    assert float(fit.abs().max()) == 0.0
+    gd, go = g.cpu().numpy(), g_o.numpy()
+    assert observed(f"tf{layers}:grad", np.abs(gd - go).max(), 3e-2 * np.abs(go).max()) <= 1.0
+    # a chain's numbers do not depend on the batch it sits in
+    e1, _, g1 = m.energy_grad(torch.as_tensor(idx[1:2]).cuda(), 4)
+    assert torch.equal(e1, e[1:2]) and torch.equal(g1, g[1:2])
+
+
+def test_product_of_experts_with_transformer_and_sampler():
+    """which = 6 (transformer + supervised CNN) and 7 (potts + transformer + CNN): energies / gradients are the sums of
+    the experts', and a sampler run on the device RNG replays against the oracle fed the device's noise."""
+    import ppde_oracle as porc
+    from helpers import oracle_energy
+    from ppde_amd.sampler import Chains
+    L, layers, dim, heads, ffn, lam = 24, 2, 128, 4, 256, 2.0
+    m, wt, st, cnn = _model(L, layers, dim, heads, ffn, with_cnn=True, potts=(4, 16))
+    m.set_lamda(lam)
+    idx = np.random.default_rng(1).integers(0, 20, (6, L)).astype(np.uint8)
+    x = torch.as_tensor(idx).cuda()
+    e4, _, g4 = m.energy_grad(x, 4)
+    e2, f2, g2 = m.energy_grad(x, 2)
+    e1, _, g1 = m.energy_grad(x, 1)
+    e6, f6, g6 = m.energy_grad(x, 6)
+    e7, f7, g7 = m.energy_grad(x, 7)
+    assert torch.allclose(e6, e4 + lam * f2, atol=1e-5) and torch.allclose(f6, f2, atol=0)
+    assert torch.allclose(g6, g4 + lam * g2, atol=1e-5)
+    assert torch.allclose(e7, e4 + e1 + lam * f2, atol=2e-5) and torch.allclose(g7, g4 + g1 + lam * g2, atol=2e-5)
+    # sampler, device RNG, 10 iterations, both evaluation policies give the same trajectory
+    n, T = 6, 10
+    res = []
+    for reuse in (False, True):
+        ch = Chains(m, n, T, 2, 3, False, 0, L - 1, 6, 1, reuse_grad=reuse, random_chain=0, seed=5)
+        ch.init(torch.as_tensor(np.tile(wt, (n, 1))).cuda())
+        ch.run(T)
+        res.append(ch.collect())
+    assert np.array_equal(res[0]["energy_history"], res[1]["energy_history"]) and np.array_equal(res[0]["best_idx"], res[1]["best_idx"])
+    e_wt, f_wt, _ = m.energy_grad(torch.as_tensor(wt[None]).cuda(), 6)
+    assert np.isfinite(res[0]["energy_history"]).all() and np.all(res[0]["energy_history"][0] == float(e_wt[0]))
+    assert abs(float(e_wt[0]) - lam * float(f_wt[0])) < 1e-6        # wild type: Delta score 0, e = lamda * fit
+    assert (res[0]["energy_history"][1:] != res[0]["energy_history"][0]).any()
+
+
+def test_reference_style_energy_object_with_a_checkpoint_file():
+    """ProteinProductOfExperts(args) with --unsupervised_expert transformer: weights from a checkpoint file in the
+    published format (the reference downloads it into --hub_dir)."""
+    import argparse
+    from ppde_amd.energy import ProteinProductOfExperts
+    with tempfile.TemporaryDirectory() as root:
+        synthetic.write_weights_dir(root, "TOY24", potts_seed=7)
+        synthetic.write_esm2_checkpoint(os.path.join(root, "hub", "checkpoints", "esm2_t30_150M_UR50D.pt"), 2, 128, 4, 256, seed=2)
+        # (a 2-layer stand-in under the 150M file name: dimensions are read from the tensors, heads must give width 32)
+        import ppde_amd.energy as en
+        en.ESM2_CHECKPOINTS = dict(en.ESM2_CHECKPOINTS, transformer=("esm2_t30_150M_UR50D", 4))
+        args = argparse.Namespace(energy_lamda=1.0, unsupervised_expert="transformer", protein_weights=root, protein="TOY24",
+                                  n_chains=4, device="cuda:0", ppde_rng="philox", hub_dir=os.path.join(root, "hub"))
+        ef = ProteinProductOfExperts(args)
+        x = ef.wt_onehot.repeat(3, 1, 1)
+        e, fit = ef.get_energy(x)
+        e2, fit2, g = ef.get_energy_and_grads(x)
+        assert torch.equal(e, e2) and g.shape == (3, 24, 20) and torch.isfinite(g).all()
+        assert torch.allclose(e, fit, atol=1e-6)            # wild type: Delta score is 0, so e = lamda * fit
+        assert float(ef.get_unsupervised_expert(x).abs().max()) == 0.0
