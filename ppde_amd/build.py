@@ -5,7 +5,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "csrc", "ppde_api.hip")
-DEPS = [os.path.join(HERE, "csrc", f) for f in ("ppde_api.hip", "common.h", "potts.h", "cnn.h", "pas.h")] + \
+DEPS = sorted(os.path.join(HERE, "csrc", f) for f in os.listdir(os.path.join(HERE, "csrc")) if f.endswith((".hip", ".h"))) + \
        [os.path.join(os.path.dirname(HERE), "include", "ppde_hip.h")]
 OUT = os.path.join(HERE, "libppde_hip.so")
 

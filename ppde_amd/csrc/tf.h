@@ -15,6 +15,7 @@
 // matrix cores), tf_ln_fwd / tf_ln_bwd, tf_embed, tf_score (log-softmax, score, gradient seeds), tf_finish_grad.
 #pragma once
 #include "common.h"
+#include "potts.h"      // wait_vmcnt, xcd_contiguous
 
 typedef _Float16 half_t;
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
@@ -29,9 +30,19 @@ typedef float tf_f32x4 __attribute__((ext_vector_type(4)));
 #define TF_VOCAB_PAD 128         // logits / token-gradient GEMMs run on a 128-wide padded vocabulary
 #define TF_TOKEN_DROPOUT_SCALE 0.88f
 
-__device__ __forceinline__ float tf_gelu(float x) { return x * 0.5f * (1.0f + erff(x * 0.70710678118654752f)); }
+// erf by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7, far below the fp16 rounding of every value it feeds): one exp,
+// one reciprocal and a degree-5 polynomial instead of the library's ~40-instruction erff. The GELU epilogues evaluate it
+// 64 times per lane and tile, which made them a quarter of the fc1 GEMM with the library call.
+__device__ __forceinline__ float tf_erf(float x) {
+    const float ax = fabsf(x);
+    const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * ax);
+    const float poly = ((((1.061405429f * t - 1.453152027f) * t + 1.421413741f) * t - 0.284496736f) * t + 0.254829592f) * t;
+    const float r = 1.0f - poly * __expf(-ax * ax);
+    return copysignf(r, x);
+}
+__device__ __forceinline__ float tf_gelu(float x) { return x * 0.5f * (1.0f + tf_erf(x * 0.70710678118654752f)); }
 __device__ __forceinline__ float tf_gelu_grad(float x) {
-    return 0.5f * (1.0f + erff(x * 0.70710678118654752f)) + x * 0.3989422804014327f * __expf(-0.5f * x * x);
+    return 0.5f * (1.0f + tf_erf(x * 0.70710678118654752f)) + x * 0.3989422804014327f * __expf(-0.5f * x * x);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -55,32 +66,59 @@ struct TfGemmArgs {
     int qcols;
 };
 
-__device__ __forceinline__ void tf_glds16(const void* gsrc, uint32_t lds_base) {
-    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(gsrc), "s"(lds_base) : "memory");
+// LDS-DMA of 16 bytes per lane, source = 64-bit scalar base + 32-bit per-lane offset (saddr form: the per-iteration
+// k advance is ONE scalar add on the base, no per-lane address arithmetic). hipcc does not count it: the loop's waits
+// are hand-counted vmcnt.
+__device__ __forceinline__ void tf_glds16(const void* sbase, uint32_t voff, uint32_t lds_base) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff), "s"(sbase), "s"(lds_base) : "memory");
 }
 
-template <int EPI>
+// BK = k depth of one staged tile (32 or 64 halfs), STAGES = LDS buffers (prefetch distance STAGES - 1).
+template <int BK, int STAGES>
+__host__ __device__ constexpr size_t tf_gemm_lds() { return (size_t)STAGES * 2 * 128 * BK * 2; }
+
+template <int EPI, int BK, int STAGES>
 __global__ __launch_bounds__(256, 2) void tf_gemm_nt(TfGemmArgs g) {
+    static_assert(BK == 32 || BK == 64, "k depth of a staged tile");
     extern __shared__ __attribute__((aligned(16))) unsigned char tf_smem[];
-    half_t* sA = (half_t*)tf_smem;                   // [2][128][64]
-    half_t* sB = sA + 2 * 128 * 64;                  // [2][128][64]
+    constexpr int TILE = 128 * BK;                   // halfs of one operand tile
+    constexpr int CH = BK / 8;                       // 16-byte chunks per row (4 or 8)
+    constexpr int RPP = 64 / CH;                     // rows per 1-KiB DMA piece (16 or 8)
+    constexpr int PPT = (128 / RPP) / 4;             // pieces per operand, tile and wave (2 or 4)
+    half_t* sA = (half_t*)tf_smem;                   // [STAGES][128][BK]
+    half_t* sB = sA + STAGES * TILE;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
-    // tiles in N-fastest order inside groups of 8 row tiles: the row panel of A stays in L2 while its column tiles run
+    // Workgroups with equal (id mod 8) share an XCD (potts.h: xcd_contiguous): each XCD takes a contiguous run of tiles
+    // in N-fastest order, so the column tiles of one 128-row panel of A meet in ONE L2 and the panel crosses the
+    // fabric once instead of once per XCD.
     const int tiles_n = g.N >> 7;
-    const int m0 = (blockIdx.x / tiles_n) << 7, n0 = (blockIdx.x % tiles_n) << 7;
-    const int K = g.K, nk = K >> 6;
-    const int lr = lane >> 3, lc = lane & 7;         // row within an 8-row DMA piece, 16-byte chunk of the 128-byte row
-    auto stage = [&](int buf, int kt) {
-        const int k0 = kt << 6;
+    const int v = xcd_contiguous(blockIdx.x, gridDim.x);
+    const int m0 = (v / tiles_n) << 7, n0 = (v % tiles_n) << 7;
+    const int K = g.K, nk = K / BK;
+    const int lr = lane / CH, lc = lane % CH;        // row within a DMA piece, 16-byte chunk of the row
+    // XOR swizzle of the 16-byte chunk index by the row, applied to the DMA's SOURCE chunk and to the reads: 128-byte rows
+    // (BK 64) spread 8 consecutive rows over the 8 chunks; 64-byte rows (BK 32) put rows r, r+4, r+8, r+12 on one bank
+    // group, so those take different chunks
+    auto SW = [](int r) { return BK == 64 ? (r & 7) : ((r >> 2) & 3); };
+    // per-lane byte offsets of this wave's pieces (rows r = (wave*PPT + i)*RPP + lr), source chunk swizzled
+    uint32_t voff[PPT];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int p = wave * 4 + i, r = p * 8 + lr;               // piece p = rows 8p .. 8p+7 of the tile
-            const half_t* sa = g.A + (size_t)(m0 + r) * K + k0 + ((lc ^ (r & 7)) << 3);
-            tf_glds16(sa, (uint32_t)(uintptr_t)(sA + buf * 8192 + p * 512));
-            const half_t* sb = g.B + (size_t)(n0 + r) * K + k0 + ((lc ^ (r & 7)) << 3);
-            tf_glds16(sb, (uint32_t)(uintptr_t)(sB + buf * 8192 + p * 512));
+    for (int i = 0; i < PPT; ++i) {
+        const int r = (wave * PPT + i) * RPP + lr;
+        voff[i] = (uint32_t)r * (uint32_t)(K * 2) + (uint32_t)((lc ^ SW(r)) << 4);
+    }
+    const half_t* baseA = g.A + (size_t)m0 * K;
+    const half_t* baseB = g.B + (size_t)n0 * K;
+    auto stage = [&](int buf, int kt) {
+        const half_t* ka = baseA + (size_t)kt * BK;
+        const half_t* kb = baseB + (size_t)kt * BK;
+#pragma unroll
+        for (int i = 0; i < PPT; ++i) {
+            const int p = wave * PPT + i;
+            tf_glds16(ka, voff[i], (uint32_t)(uintptr_t)(sA + buf * TILE + p * 512));
+            tf_glds16(kb, voff[i], (uint32_t)(uintptr_t)(sB + buf * TILE + p * 512));
         }
     };
     tf_f32x4 acc[4][4];
@@ -90,15 +128,15 @@ __global__ __launch_bounds__(256, 2) void tf_gemm_nt(TfGemmArgs g) {
         for (int j = 0; j < 4; ++j) acc[i][j] = (tf_f32x4){0.f, 0.f, 0.f, 0.f};
     const int fr = lane & 15, fg = lane >> 4;
     auto compute = [&](int buf) {
-        const half_t* a = sA + buf * 8192 + (wm * 64 + fr) * 64;
-        const half_t* b = sB + buf * 8192 + (wn * 64 + fr) * 64;
+        const half_t* a = sA + buf * TILE + (wm * 64 + fr) * BK;
+        const half_t* b = sB + buf * TILE + (wn * 64 + fr) * BK;
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
+        for (int s = 0; s < BK / 32; ++s) {
             f16x8 af[4], bf[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {                             // rows fr + 16 i: (row & 7) == (fr & 7)
-                af[i] = *(const f16x8*)(a + i * 16 * 64 + (((s * 4 + fg) ^ (fr & 7)) << 3));
-                bf[i] = *(const f16x8*)(b + i * 16 * 64 + (((s * 4 + fg) ^ (fr & 7)) << 3));
+            for (int i = 0; i < 4; ++i) {                             // rows fr + 16 i (+ multiples of 64): SW(row) == SW(fr)
+                af[i] = *(const f16x8*)(a + i * 16 * BK + (((s * 4 + fg) ^ SW(fr)) << 3));
+                bf[i] = *(const f16x8*)(b + i * 16 * BK + (((s * 4 + fg) ^ SW(fr)) << 3));
             }
 #pragma unroll
             for (int i = 0; i < 4; ++i)
@@ -106,19 +144,19 @@ __global__ __launch_bounds__(256, 2) void tf_gemm_nt(TfGemmArgs g) {
                 for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j], af[i], acc[i][j], 0, 0, 0);
         }
     };
-    stage(0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    int cur = 0;
-    for (int kt = 0; kt + 1 < nk; ++kt) {
-        stage(cur ^ 1, kt + 1);
-        compute(cur);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        cur ^= 1;
+    // ring of STAGES buffers, tiles kt+1 .. kt+STAGES-2 stay in flight across the barrier of iteration kt
+#pragma unroll
+    for (int t = 0; t < STAGES - 1; ++t)
+        if (t < nk) stage(t, t);
+    for (int kt = 0; kt < nk; ++kt) {
+        const int ahead = min(nk - 1, kt + STAGES - 2) - kt;          // tiles issued after tile kt
+        wait_vmcnt<(STAGES - 2) * 2 * PPT + 1>(ahead * 2 * PPT);
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_s_barrier();                                 // tile kt has landed for every wave; buffer (kt-1) is free
+        asm volatile("" ::: "memory");
+        if (kt + STAGES - 1 < nk) stage((kt + STAGES - 1) % STAGES, kt + STAGES - 1);
+        compute(kt % STAGES);
     }
-    compute(cur);
-
     // ---- epilogue: lane = row fr of each 16-row tile, columns 4 fg .. 4 fg + 3 of each 16-column tile
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -164,7 +202,8 @@ __global__ __launch_bounds__(256, 2) void tf_gemm_nt(TfGemmArgs g) {
 // ------------------------------------------------------------------------------------------------------------
 // Layer norm over rows of D halfs (D even), one wavefront per row, statistics in fp32.
 // ------------------------------------------------------------------------------------------------------------
-#define TF_LN_MAXP 8              // pairs per lane: D <= 1024
+#define TF_LN_MAXP 8              // (D <= 2 * 64 * TF_LN_MAXP = 1024)
+#define TF_LN_MAXC 2              // 16-byte chunks (8 halfs) per lane
 struct TfLnArgs {
     const half_t* x;        // [M][D]
     half_t* y;              // forward output / backward: gradient written here
@@ -177,37 +216,51 @@ struct TfLnArgs {
     int M, D;
     float out_scale;        // backward: the sum is rounded to fp16, then multiplied by this (1 = no-op) and rounded again
 };
+__device__ __forceinline__ void tf_load8(const float* p, float (&v)[8]) {
+    const float4 a = *(const float4*)p, b = *(const float4*)(p + 4);
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+}
 
+// one wavefront per row; a lane holds up to TF_LN_MAXC chunks of 8 halfs (16-byte loads and stores)
 __global__ __launch_bounds__(256) void tf_ln_fwd(TfLnArgs a) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (row >= a.M) return;
-    const int np = a.D >> 1;
-    const f16x2* xr = (const f16x2*)(a.x + (size_t)row * a.D);
-    float v0[TF_LN_MAXP], v1[TF_LN_MAXP];
+    const int nc = a.D >> 3;
+    const f16x8* xr = (const f16x8*)(a.x + (size_t)row * a.D);
+    float v[TF_LN_MAXC][8];
     float s = 0.f;
 #pragma unroll
-    for (int i = 0; i < TF_LN_MAXP; ++i) {
-        const int p = lane + 64 * i;
-        v0[i] = v1[i] = 0.f;
-        if (p < np) { const f16x2 t = xr[p]; v0[i] = (float)t[0]; v1[i] = (float)t[1]; s += v0[i] + v1[i]; }
+    for (int i = 0; i < TF_LN_MAXC; ++i) {
+        const int c = lane + 64 * i;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[i][e] = 0.f;
+        if (c < nc) {
+            const f16x8 t = xr[c];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { v[i][e] = (float)t[e]; s += v[i][e]; }
+        }
     }
     const float mean = wave_sum(s) / (float)a.D;
     float q = 0.f;
 #pragma unroll
-    for (int i = 0; i < TF_LN_MAXP; ++i) {
-        const int p = lane + 64 * i;
-        if (p < np) { const float d0 = v0[i] - mean, d1 = v1[i] - mean; q += d0 * d0 + d1 * d1; }
-    }
-    const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)a.D + 1e-5f);
-    f16x2* yr = (f16x2*)(a.y + (size_t)row * a.D);
+    for (int i = 0; i < TF_LN_MAXC; ++i)
+        if (lane + 64 * i < nc) {
 #pragma unroll
-    for (int i = 0; i < TF_LN_MAXP; ++i) {
-        const int p = lane + 64 * i;
-        if (p < np) {
-            f16x2 o;
-            o[0] = (half_t)((v0[i] - mean) * rstd * a.gamma[2 * p] + a.beta[2 * p]);
-            o[1] = (half_t)((v1[i] - mean) * rstd * a.gamma[2 * p + 1] + a.beta[2 * p + 1]);
-            yr[p] = o;
+            for (int e = 0; e < 8; ++e) { const float d = v[i][e] - mean; q += d * d; }
+        }
+    const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)a.D + 1e-5f);
+    f16x8* yr = (f16x8*)(a.y + (size_t)row * a.D);
+#pragma unroll
+    for (int i = 0; i < TF_LN_MAXC; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nc) {
+            float ga[8], be[8];
+            tf_load8(a.gamma + 8 * c, ga);
+            tf_load8(a.beta + 8 * c, be);
+            f16x8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = (half_t)((v[i][e] - mean) * rstd * ga[e] + be[e]);
+            yr[c] = o;
         }
     }
     if (lane == 0) { a.mean[row] = mean; a.rstd[row] = rstd; }
@@ -217,37 +270,47 @@ __global__ __launch_bounds__(256) void tf_ln_fwd(TfLnArgs a) {
 __global__ __launch_bounds__(256) void tf_ln_bwd(TfLnArgs a) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (row >= a.M) return;
-    const int np = a.D >> 1;
-    const f16x2* xr = (const f16x2*)(a.x + (size_t)row * a.D);
-    const f16x2* dr = (const f16x2*)(a.dy + (size_t)row * a.D);
+    const int nc = a.D >> 3;
+    const f16x8* xr = (const f16x8*)(a.x + (size_t)row * a.D);
+    const f16x8* dr = (const f16x8*)(a.dy + (size_t)row * a.D);
+    const f16x8* rr = a.gres ? (const f16x8*)(a.gres + (size_t)row * a.D) : nullptr;
     const float mean = a.mean[row], rstd = a.rstd[row];
-    float xh0[TF_LN_MAXP], xh1[TF_LN_MAXP], g0[TF_LN_MAXP], g1[TF_LN_MAXP];
+    float xh[TF_LN_MAXC][8], gg[TF_LN_MAXC][8], rs[TF_LN_MAXC][8];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-    for (int i = 0; i < TF_LN_MAXP; ++i) {
-        const int p = lane + 64 * i;
-        xh0[i] = xh1[i] = g0[i] = g1[i] = 0.f;
-        if (p < np) {
-            const f16x2 t = xr[p], d = dr[p];
-            xh0[i] = ((float)t[0] - mean) * rstd; xh1[i] = ((float)t[1] - mean) * rstd;
-            g0[i] = (float)d[0] * a.gamma[2 * p]; g1[i] = (float)d[1] * a.gamma[2 * p + 1];
-            s1 += g0[i] + g1[i];
-            s2 += g0[i] * xh0[i] + g1[i] * xh1[i];
+    for (int i = 0; i < TF_LN_MAXC; ++i) {
+        const int c = lane + 64 * i;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) xh[i][e] = gg[i][e] = rs[i][e] = 0.f;
+        if (c < nc) {
+            const f16x8 t = xr[c], d = dr[c];
+            float ga[8];
+            tf_load8(a.gamma + 8 * c, ga);
+            if (rr) { const f16x8 r = rr[c];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) rs[i][e] = (float)r[e]; }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                xh[i][e] = ((float)t[e] - mean) * rstd;
+                gg[i][e] = (float)d[e] * ga[e];
+                s1 += gg[i][e];
+                s2 += gg[i][e] * xh[i][e];
+            }
         }
     }
     const float m1 = wave_sum(s1) / (float)a.D, m2 = wave_sum(s2) / (float)a.D;
-    f16x2* yr = (f16x2*)(a.y + (size_t)row * a.D);
-    const f16x2* rr = a.gres ? (const f16x2*)(a.gres + (size_t)row * a.D) : nullptr;
+    f16x8* yr = (f16x8*)(a.y + (size_t)row * a.D);
 #pragma unroll
-    for (int i = 0; i < TF_LN_MAXP; ++i) {
-        const int p = lane + 64 * i;
-        if (p < np) {
-            float d0 = rstd * (g0[i] - m1 - xh0[i] * m2), d1 = rstd * (g1[i] - m1 - xh1[i] * m2);
-            if (rr) { const f16x2 r = rr[p]; d0 += (float)r[0]; d1 += (float)r[1]; }
-            f16x2 o;
-            o[0] = (half_t)d0; o[1] = (half_t)d1;
-            if (a.out_scale != 1.0f) { o[0] = (half_t)((float)o[0] * a.out_scale); o[1] = (half_t)((float)o[1] * a.out_scale); }
-            yr[p] = o;
+    for (int i = 0; i < TF_LN_MAXC; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nc) {
+            f16x8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                o[e] = (half_t)(rstd * (gg[i][e] - m1 - xh[i][e] * m2) + rs[i][e]);
+                if (a.out_scale != 1.0f) o[e] = (half_t)((float)o[e] * a.out_scale);
+            }
+            yr[c] = o;
         }
     }
 }
@@ -267,15 +330,20 @@ __global__ void tf_embed(const uint8_t* __restrict__ idx, int Ls, int sh, int L,
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// Attention, one wavefront per (chain, head); a workgroup = TF_ATT_WAVES consecutive heads of a chain.
-// qkv [M][3D] as the projection wrote it (q already scaled); rotary embedding is applied while staging q and k.
-// Forward: S^T tiles = K Q^T (keys on the accumulator rows, so a lane holds 4 consecutive keys of one query: the
-// softmax reduces in-lane + two lane shuffles, and P leaves in 8-byte pieces), P^T V via V^T (LDS) x P.
+// Attention: one workgroup of TF_ATT_WAVES wavefronts per (chain, head); the waves share the head's staged q, k, v and
+// take the 16-query tiles in turn. qkv [M][3D] as the projection wrote it (q already scaled); the rotary embedding is
+// applied while staging q and k.
+// Orientation: every score tile is computed as S^T = K Q^T (v_mfma 16x16x32, k = head width), so a lane holds 4
+// consecutive KEYS of one query: the softmax reduces in-lane + two lane shuffles, P leaves in 8-byte pieces, and
+// the tile is already the B operand (k = key on the rows) of a v_mfma_f32_16x16x16_f16: P V and dS K need no LDS
+// round trip. Products that contract over the QUERY (dK, dV) take the tile through one 512-byte LDS tile and the
+// transposed read ds_read_b64_tr_b16 (lane maps of both instructions: scripts/probes/mfma_probe.hip).
 // ------------------------------------------------------------------------------------------------------------
 #define TF_ATT_WAVES 2
 #define TF_TP 128                 // padded sequence length the attention kernels are written for (L <= 128)
 #define TF_NKT 8                  // key tiles of 16
 #define TF_LDP (TF_TP + 8)        // padded row length (halfs) of the transposed LDS images
+typedef __fp16 tf_hfx4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
 
 struct TfAttnArgs {
     const half_t* qkv;      // [M][3D]
@@ -289,22 +357,22 @@ struct TfAttnArgs {
     float qscale;           // hd^-0.5 (backward: d q_lin = d q * qscale)
 };
 
-__host__ __device__ inline size_t tf_attn_fwd_lds() { return (size_t)TF_ATT_WAVES * (2 * TF_TP * TF_HD + TF_HD * TF_LDP + 16 * TF_LDP) * 2; }
-
-// stage rows of q or k with the rotary embedding applied: lane item = (t, c in {0,1}) handles dims 8c..8c+7 and their
-// partners 16+8c..; dst row-major [TF_TP][32] (ROWMAJOR) or transposed [32][TF_LDP]
+// stage rows of q or k with the rotary embedding applied: item = (t, c in {0,1}) handles dims 8c..8c+7 and their
+// partners 16+8c..; dst row-major [TF_TP][32] or transposed [32][TF_LDP]; `tid` of `nthr` threads
 template <bool TRANSPOSED>
-__device__ __forceinline__ void tf_stage_rotary(const half_t* src, int ld, int L, const float* rc, const float* rs, half_t* dst, int lane) {
-    for (int it = lane; it < L * 2; it += 64) {
+__device__ __forceinline__ void tf_stage_rotary(const half_t* src, int ld, int L, const float* rc, const float* rs, half_t* dst, int tid, int nthr) {
+    for (int it = tid; it < L * 2; it += nthr) {
         const int t = it >> 1, c = it & 1;
         const f16x8 x1 = *(const f16x8*)(src + (size_t)t * ld + 8 * c);
         const f16x8 x2 = *(const f16x8*)(src + (size_t)t * ld + 16 + 8 * c);
+        float co[8], si[8];
+        tf_load8(rc + t * 16 + 8 * c, co);
+        tf_load8(rs + t * 16 + 8 * c, si);
         f16x8 y1, y2;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            const float co = rc[t * 16 + 8 * c + e], si = rs[t * 16 + 8 * c + e];
-            y1[e] = (half_t)((float)x1[e] * co - (float)x2[e] * si);
-            y2[e] = (half_t)((float)x2[e] * co + (float)x1[e] * si);
+            y1[e] = (half_t)((float)x1[e] * co[e] - (float)x2[e] * si[e]);
+            y2[e] = (half_t)((float)x2[e] * co[e] + (float)x1[e] * si[e]);
         }
         if constexpr (!TRANSPOSED) {
             *(f16x8*)(dst + t * TF_HD + 8 * c) = y1;
@@ -316,8 +384,8 @@ __device__ __forceinline__ void tf_stage_rotary(const half_t* src, int ld, int L
     }
 }
 template <bool TRANSPOSED>
-__device__ __forceinline__ void tf_stage_plain(const half_t* src, int ld, int L, half_t* dst, int lane) {
-    for (int it = lane; it < L * 4; it += 64) {
+__device__ __forceinline__ void tf_stage_plain(const half_t* src, int ld, int L, half_t* dst, int tid, int nthr) {
+    for (int it = tid; it < L * 4; it += nthr) {
         const int t = it >> 2, c = it & 3;
         const f16x8 x = *(const f16x8*)(src + (size_t)t * ld + 8 * c);
         if constexpr (!TRANSPOSED) *(f16x8*)(dst + t * TF_HD + 8 * c) = x;
@@ -327,32 +395,34 @@ __device__ __forceinline__ void tf_stage_plain(const half_t* src, int ld, int L,
         }
     }
 }
-__device__ __forceinline__ void tf_zero_lds(half_t* p, int halfs, int lane) {
-    for (int i = lane * 8; i < halfs; i += 64 * 8) *(f16x8*)(p + i) = (f16x8){0, 0, 0, 0, 0, 0, 0, 0};
+__device__ __forceinline__ void tf_zero_lds(half_t* p, int halfs, int tid, int nthr) {
+    for (int i = tid * 8; i < halfs; i += nthr * 8) *(f16x8*)(p + i) = (f16x8){0, 0, 0, 0, 0, 0, 0, 0};
 }
 __device__ __forceinline__ float tf_quad_rows_max(float v) { return fmaxf(fmaxf(v, __shfl_xor(v, 16)), fmaxf(__shfl_xor(v, 32), __shfl_xor(v, 48))); }
 __device__ __forceinline__ float tf_quad_rows_sum(float v) { v += __shfl_xor(v, 16); v += __shfl_xor(v, 32); return v; }
 
+// LDS: q rows [TP][32] | k rows [TP][32] | v transposed [32][LDP]
+__host__ __device__ inline size_t tf_attn_fwd_lds() { return (size_t)(2 * TF_TP * TF_HD + TF_HD * TF_LDP) * 2; }
+
 __global__ __launch_bounds__(64 * TF_ATT_WAVES) void tf_attn_fwd(TfAttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char tf_smem[];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int b = blockIdx.x / (a.H / TF_ATT_WAVES), h = (blockIdx.x % (a.H / TF_ATT_WAVES)) * TF_ATT_WAVES + wave;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.x / a.H, h = blockIdx.x % a.H;
     const int L = a.L, D = a.D, ld = 3 * D;
-    half_t* sQ = (half_t*)tf_smem + (size_t)wave * (2 * TF_TP * TF_HD + TF_HD * TF_LDP + 16 * TF_LDP);
+    half_t* sQ = (half_t*)tf_smem;
     half_t* sK = sQ + TF_TP * TF_HD;
     half_t* sVt = sK + TF_TP * TF_HD;                 // [32][TF_LDP]
-    half_t* sP = sVt + TF_HD * TF_LDP;                // [16][TF_LDP]
     const half_t* base = a.qkv + (size_t)b * L * ld + h * TF_HD;
-    tf_zero_lds(sQ, 2 * TF_TP * TF_HD + TF_HD * TF_LDP + 16 * TF_LDP, lane);
+    tf_zero_lds(sQ, 2 * TF_TP * TF_HD + TF_HD * TF_LDP, tid, 64 * TF_ATT_WAVES);
     __syncthreads();
-    tf_stage_rotary<false>(base, ld, L, a.rope_cos, a.rope_sin, sQ, lane);
-    tf_stage_rotary<false>(base + D, ld, L, a.rope_cos, a.rope_sin, sK, lane);
-    tf_stage_plain<true>(base + 2 * D, ld, L, sVt, lane);
+    tf_stage_rotary<false>(base, ld, L, a.rope_cos, a.rope_sin, sQ, tid, 64 * TF_ATT_WAVES);
+    tf_stage_rotary<false>(base + D, ld, L, a.rope_cos, a.rope_sin, sK, tid, 64 * TF_ATT_WAVES);
+    tf_stage_plain<true>(base + 2 * D, ld, L, sVt, tid, 64 * TF_ATT_WAVES);
     __syncthreads();
     const int fr = lane & 15, fg = lane >> 4;
     const int NQ = (L + 15) >> 4, NK = NQ;
     half_t* Pg = a.P + ((size_t)(b * a.H + h) * L) * TF_TP;
-    for (int qi = 0; qi < NQ; ++qi) {
+    for (int qi = wave; qi < NQ; qi += TF_ATT_WAVES) {
         const f16x8 qf = *(const f16x8*)(sQ + (qi * 16 + fr) * TF_HD + fg * 8);
         tf_f32x4 s[TF_NKT];
         float mx = -INFINITY;
@@ -381,69 +451,65 @@ __global__ __launch_bounds__(64 * TF_ATT_WAVES) void tf_attn_fwd(TfAttnArgs a) {
         sum = tf_quad_rows_sum(sum);
         const float inv = 1.0f / sum;
         const int q = qi * 16 + fr;
+        tf_f32x4 o[2] = {(tf_f32x4){0.f, 0.f, 0.f, 0.f}, (tf_f32x4){0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
         for (int j = 0; j < TF_NKT; ++j)
             if (j < NK) {
                 f16x4 p;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) p[r] = (half_t)(s[j][r] * inv);
-                *(f16x4*)(sP + fr * TF_LDP + j * 16 + 4 * fg) = p;
                 if (q < L) *(f16x4*)(Pg + (size_t)q * TF_TP + j * 16 + 4 * fg) = p;
-            }
-        __syncthreads();
-        // ctx^T tile [d][query] = V^T (rows d, k = key) x P (rows query, k = key)
+                // ctx^T [d][query] += V^T (rows d, k = these 16 keys) x P^T (k = key on the rows: the tile as it stands)
 #pragma unroll
-        for (int dj = 0; dj < 2; ++dj) {
-            tf_f32x4 o = (tf_f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int kc = 0; kc < TF_TP / 32; ++kc) {
-                const f16x8 vf = *(const f16x8*)(sVt + (dj * 16 + fr) * TF_LDP + kc * 32 + fg * 8);
-                const f16x8 pf = *(const f16x8*)(sP + fr * TF_LDP + kc * 32 + fg * 8);
-                o = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf, o, 0, 0, 0);
+                for (int dj = 0; dj < 2; ++dj) {
+                    const f16x4 vf = *(const f16x4*)(sVt + (dj * 16 + fr) * TF_LDP + j * 16 + 4 * fg);
+                    o[dj] = __builtin_amdgcn_mfma_f32_16x16x16f16(vf, p, o[dj], 0, 0, 0);
+                }
             }
-            if (q < L) {
+        if (q < L) {
+#pragma unroll
+            for (int dj = 0; dj < 2; ++dj) {
                 f16x4 ov;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) ov[r] = (half_t)o[r];
+                for (int r = 0; r < 4; ++r) ov[r] = (half_t)o[dj][r];
                 *(f16x4*)(a.ctx + (size_t)(b * L + q) * D + h * TF_HD + dj * 16 + 4 * fg) = ov;
             }
         }
-        __syncthreads();
     }
 }
 
 // Backward of the same: dqkv from dctx, P and re-staged q, k, v.
 //   dP^T = V dO^T, dS = P o (dP - rowsum(dP o P)), dQ = dS K, dK = dS^T Q, dV = P^T dO; then the rotary transpose on
-//   dQ, dK and the q scaling. Queries are processed 32 at a time (the k depth of one MFMA).
-__host__ __device__ inline size_t tf_attn_bwd_lds() {
-    return (size_t)TF_ATT_WAVES * (2 * TF_TP * TF_HD + 3 * TF_HD * TF_LDP + 32 * TF_LDP + 2 * TF_TP * 40) * 2;
-}
+//   dQ, dK and the q scaling. The waves of a head take the query tiles in turn; dK and dV are summed over the waves in
+//   a fixed order at the end (wave 1's partial sums go through LDS to wave 0).
+// LDS: v rows | dO rows | dO^T | k^T (rotated) | q^T (rotated) | per wave two 16 x 16 transpose tiles
+#define TF_ATT_STAGE (2 * TF_TP * TF_HD + 3 * TF_HD * TF_LDP)
+__host__ __device__ inline size_t tf_attn_bwd_lds() { return (size_t)(TF_ATT_STAGE + TF_ATT_WAVES * 512) * 2; }
+static_assert((size_t)TF_ATT_STAGE * 2 >= (size_t)(TF_ATT_WAVES - 1) * 4 * TF_NKT * 64 * 16, "the staging area also carries the partial sums");
+
 __global__ __launch_bounds__(64 * TF_ATT_WAVES) void tf_attn_bwd(TfAttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char tf_smem[];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int b = blockIdx.x / (a.H / TF_ATT_WAVES), h = (blockIdx.x % (a.H / TF_ATT_WAVES)) * TF_ATT_WAVES + wave;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.x / a.H, h = blockIdx.x % a.H;
     const int L = a.L, D = a.D, ld = 3 * D;
-    constexpr int PER_WAVE = 2 * TF_TP * TF_HD + 3 * TF_HD * TF_LDP + 32 * TF_LDP + 2 * TF_TP * 40;
-    half_t* sV = (half_t*)tf_smem + (size_t)wave * PER_WAVE;   // [TP][32]
+    half_t* sV = (half_t*)tf_smem;                             // [TP][32]
     half_t* sdO = sV + TF_TP * TF_HD;                          // [TP][32]
     half_t* sdOt = sdO + TF_TP * TF_HD;                        // [32][LDP]
     half_t* sKt = sdOt + TF_HD * TF_LDP;                       // [32][LDP] rotated k, transposed
     half_t* sQt = sKt + TF_HD * TF_LDP;                        // [32][LDP] rotated q, transposed
-    half_t* sdS = sQt + TF_HD * TF_LDP;                        // [32 queries][LDP keys]
-    half_t* sdSt = sdS + 32 * TF_LDP;                          // [TP keys][40]  (32 queries + pad)
-    half_t* sPt = sdSt + TF_TP * 40;                           // [TP keys][40]
+    half_t* sT = sQt + TF_HD * TF_LDP + wave * 512;            // this wave's two 16 x 16 tiles
     const half_t* base = a.qkv + (size_t)b * L * ld + h * TF_HD;
     const half_t* dob = a.dctx + (size_t)b * L * D + h * TF_HD;
-    tf_zero_lds(sV, PER_WAVE, lane);
+    tf_zero_lds(sV, TF_ATT_STAGE, tid, 64 * TF_ATT_WAVES);
     __syncthreads();
-    tf_stage_plain<false>(base + 2 * D, ld, L, sV, lane);
-    tf_stage_plain<false>(dob, D, L, sdO, lane);
-    tf_stage_plain<true>(dob, D, L, sdOt, lane);
-    tf_stage_rotary<true>(base + D, ld, L, a.rope_cos, a.rope_sin, sKt, lane);
-    tf_stage_rotary<true>(base, ld, L, a.rope_cos, a.rope_sin, sQt, lane);
+    tf_stage_plain<false>(base + 2 * D, ld, L, sV, tid, 64 * TF_ATT_WAVES);
+    tf_stage_plain<false>(dob, D, L, sdO, tid, 64 * TF_ATT_WAVES);
+    tf_stage_plain<true>(dob, D, L, sdOt, tid, 64 * TF_ATT_WAVES);
+    tf_stage_rotary<true>(base + D, ld, L, a.rope_cos, a.rope_sin, sKt, tid, 64 * TF_ATT_WAVES);
+    tf_stage_rotary<true>(base, ld, L, a.rope_cos, a.rope_sin, sQt, tid, 64 * TF_ATT_WAVES);
     __syncthreads();
     const int fr = lane & 15, fg = lane >> 4;
-    const int NK = (L + 15) >> 4;
+    const int NQ = (L + 15) >> 4, NK = NQ;
     const half_t* Pg = a.P + ((size_t)(b * a.H + h) * L) * TF_TP;
     tf_f32x4 accK[2][TF_NKT], accV[2][TF_NKT];
 #pragma unroll
@@ -451,86 +517,100 @@ __global__ __launch_bounds__(64 * TF_ATT_WAVES) void tf_attn_bwd(TfAttnArgs a) {
 #pragma unroll
         for (int j = 0; j < TF_NKT; ++j) { accK[dj][j] = (tf_f32x4){0.f, 0.f, 0.f, 0.f}; accV[dj][j] = (tf_f32x4){0.f, 0.f, 0.f, 0.f}; }
     half_t* dq_out = a.dqkv + (size_t)b * L * ld + h * TF_HD;
-    for (int q0 = 0; q0 < L; q0 += 32) {
+    // the transposed read: lane (fr, fg) supplies row 4 fg + (fr >> 2), columns 4 (fr & 3) .. of the tile and receives
+    // column fr of rows 4 fg .. 4 fg + 3
+    typedef __attribute__((address_space(3))) tf_hfx4* lds_tr_ptr;
+    const int tr_off = (4 * fg + (fr >> 2)) * 16 + 4 * (fr & 3);
+    for (int qi = wave; qi < NQ; qi += TF_ATT_WAVES) {
+        const int q = qi * 16 + fr;
+        const f16x8 dof = *(const f16x8*)(sdO + (qi * 16 + fr) * TF_HD + fg * 8);
+        tf_f32x4 dp[TF_NKT];
+        f16x4 pt[TF_NKT], ds[TF_NKT];
+        float delta = 0.f;
 #pragma unroll
-        for (int qi = 0; qi < 2; ++qi) {
-            const int q = q0 + qi * 16 + fr;
-            const f16x8 dof = *(const f16x8*)(sdO + min(q, TF_TP - 1) * TF_HD + fg * 8);
-            tf_f32x4 dp[TF_NKT];
-            f16x4 pt[TF_NKT];
-            float delta = 0.f;
+        for (int j = 0; j < TF_NKT; ++j) {
+            dp[j] = (tf_f32x4){0.f, 0.f, 0.f, 0.f};
+            pt[j] = (f16x4){0, 0, 0, 0};
+            if (j < NK) {
+                const f16x8 vf = *(const f16x8*)(sV + (j * 16 + fr) * TF_HD + fg * 8);
+                dp[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, dof, dp[j], 0, 0, 0);   // [key][query]
+                if (q < L) pt[j] = *(const f16x4*)(Pg + (size_t)q * TF_TP + j * 16 + 4 * fg);
 #pragma unroll
-            for (int j = 0; j < TF_NKT; ++j) {
-                dp[j] = (tf_f32x4){0.f, 0.f, 0.f, 0.f};
-                pt[j] = (f16x4){0, 0, 0, 0};
-                if (j < NK) {
-                    const f16x8 vf = *(const f16x8*)(sV + (j * 16 + fr) * TF_HD + fg * 8);
-                    dp[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, dof, dp[j], 0, 0, 0);   // [key][query]
-                    if (q < L) pt[j] = *(const f16x4*)(Pg + (size_t)q * TF_TP + j * 16 + 4 * fg);
+                for (int r = 0; r < 4; ++r) { dp[j][r] = (float)(half_t)dp[j][r]; delta += dp[j][r] * (float)pt[j][r]; }
+            }
+        }
+        delta = tf_quad_rows_sum(delta);
+        tf_f32x4 o[2] = {(tf_f32x4){0.f, 0.f, 0.f, 0.f}, (tf_f32x4){0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) { dp[j][r] = (float)(half_t)dp[j][r]; delta += dp[j][r] * (float)pt[j][r]; }
+        for (int j = 0; j < TF_NKT; ++j)
+            if (j < NK) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) ds[j][r] = (half_t)((float)pt[j][r] * (dp[j][r] - delta));
+                // dQ^T [d][query] += Kr^T (rows d, k = these keys) x dS^T (k = key on the rows: the tile as it stands)
+#pragma unroll
+                for (int dj = 0; dj < 2; ++dj) {
+                    const f16x4 kf = *(const f16x4*)(sKt + (dj * 16 + fr) * TF_LDP + j * 16 + 4 * fg);
+                    o[dj] = __builtin_amdgcn_mfma_f32_16x16x16f16(kf, ds[j], o[dj], 0, 0, 0);
                 }
             }
-            delta = tf_quad_rows_sum(delta);
+        if (q < L) {
+            f16x4 o1, o2;         // rotary transpose on (d, d + 16) = (o[0][r], o[1][r]), d = 4 fg + r, then the q scaling
 #pragma unroll
-            for (int j = 0; j < TF_NKT; ++j)
-                if (j < NK) {
-                    f16x4 ds;
+            for (int r = 0; r < 4; ++r) {
+                const float co = a.rope_cos[q * 16 + 4 * fg + r], si = a.rope_sin[q * 16 + 4 * fg + r];
+                const float y1 = (float)(half_t)o[0][r], y2 = (float)(half_t)o[1][r];
+                o1[r] = (half_t)((float)(half_t)(y1 * co + y2 * si) * a.qscale);
+                o2[r] = (half_t)((float)(half_t)(y2 * co - y1 * si) * a.qscale);
+            }
+            *(f16x4*)(dq_out + (size_t)q * ld + 4 * fg) = o1;
+            *(f16x4*)(dq_out + (size_t)q * ld + 16 + 4 * fg) = o2;
+        }
+        // dK^T [d][key] += Qr^T (rows d, k = these queries) x dS (k = query on the rows);  dV^T += dO^T x P: the tiles
+        // turned query-major through LDS
+        const f16x4 qf0 = *(const f16x4*)(sQt + (fr) * TF_LDP + qi * 16 + 4 * fg), qf1 = *(const f16x4*)(sQt + (16 + fr) * TF_LDP + qi * 16 + 4 * fg);
+        const f16x4 of0 = *(const f16x4*)(sdOt + (fr) * TF_LDP + qi * 16 + 4 * fg), of1 = *(const f16x4*)(sdOt + (16 + fr) * TF_LDP + qi * 16 + 4 * fg);
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) ds[r] = (half_t)((float)pt[j][r] * (dp[j][r] - delta));
-                    *(f16x4*)(sdS + (qi * 16 + fr) * TF_LDP + j * 16 + 4 * fg) = ds;
+        for (int j = 0; j < TF_NKT; ++j)
+            if (j < NK) {
+                *(f16x4*)(sT + fr * 16 + 4 * fg) = ds[j];
+                *(f16x4*)(sT + 256 + fr * 16 + 4 * fg) = pt[j];
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                const tf_hfx4 dsq_ = __builtin_amdgcn_ds_read_tr16_b64_v4f16((lds_tr_ptr)(sT + tr_off));
+                const tf_hfx4 pq_ = __builtin_amdgcn_ds_read_tr16_b64_v4f16((lds_tr_ptr)(sT + 256 + tr_off));
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                f16x4 dsq, pq;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        sdSt[(j * 16 + 4 * fg + r) * 40 + qi * 16 + fr] = ds[r];
-                        sPt[(j * 16 + 4 * fg + r) * 40 + qi * 16 + fr] = pt[j][r];
-                    }
-                }
+                for (int r = 0; r < 4; ++r) { dsq[r] = (half_t)dsq_[r]; pq[r] = (half_t)pq_[r]; }
+                accK[0][j] = __builtin_amdgcn_mfma_f32_16x16x16f16(qf0, dsq, accK[0][j], 0, 0, 0);
+                accK[1][j] = __builtin_amdgcn_mfma_f32_16x16x16f16(qf1, dsq, accK[1][j], 0, 0, 0);
+                accV[0][j] = __builtin_amdgcn_mfma_f32_16x16x16f16(of0, pq, accV[0][j], 0, 0, 0);
+                accV[1][j] = __builtin_amdgcn_mfma_f32_16x16x16f16(of1, pq, accV[1][j], 0, 0, 0);
+            }
+    }
+    // ---- sum the waves' partial dK^T, dV^T in wave order (wave 0 + wave 1 + ...), through the staging area
+    __syncthreads();
+    tf_f32x4* red = (tf_f32x4*)tf_smem;
+    for (int w = 1; w < TF_ATT_WAVES; ++w) {
+        if (wave == w) {
+#pragma unroll
+            for (int dj = 0; dj < 2; ++dj)
+#pragma unroll
+                for (int j = 0; j < TF_NKT; ++j) { red[((dj * TF_NKT + j) * 2 + 0) * 64 + lane] = accK[dj][j]; red[((dj * TF_NKT + j) * 2 + 1) * 64 + lane] = accV[dj][j]; }
         }
         __syncthreads();
-        // dQ (these 32 queries, complete over the keys): [d][query] = Kr^T (rows d, k = key) x dS (rows query, k = key)
+        if (wave == 0) {
 #pragma unroll
-        for (int qi = 0; qi < 2; ++qi) {
-            tf_f32x4 o[2];
+            for (int dj = 0; dj < 2; ++dj)
 #pragma unroll
-            for (int dj = 0; dj < 2; ++dj) {
-                o[dj] = (tf_f32x4){0.f, 0.f, 0.f, 0.f};
+                for (int j = 0; j < TF_NKT; ++j) {
+                    const tf_f32x4 k = red[((dj * TF_NKT + j) * 2 + 0) * 64 + lane], v = red[((dj * TF_NKT + j) * 2 + 1) * 64 + lane];
 #pragma unroll
-                for (int kc = 0; kc < TF_TP / 32; ++kc) {
-                    const f16x8 kf = *(const f16x8*)(sKt + (dj * 16 + fr) * TF_LDP + kc * 32 + fg * 8);
-                    const f16x8 sf = *(const f16x8*)(sdS + (qi * 16 + fr) * TF_LDP + kc * 32 + fg * 8);
-                    o[dj] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, sf, o[dj], 0, 0, 0);
-                }
-            }
-            const int q = q0 + qi * 16 + fr;
-            if (q < L) {
-                f16x4 o1, o2;     // rotary transpose on (d, d + 16) = (o[0][r], o[1][r]), d = 4 fg + r, then the q scaling
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float co = a.rope_cos[q * 16 + 4 * fg + r], si = a.rope_sin[q * 16 + 4 * fg + r];
-                    const float y1 = (float)(half_t)o[0][r], y2 = (float)(half_t)o[1][r];
-                    o1[r] = (half_t)((float)(half_t)(y1 * co + y2 * si) * a.qscale);
-                    o2[r] = (half_t)((float)(half_t)(y2 * co - y1 * si) * a.qscale);
-                }
-                *(f16x4*)(dq_out + (size_t)q * ld + 4 * fg) = o1;
-                *(f16x4*)(dq_out + (size_t)q * ld + 16 + 4 * fg) = o2;
-            }
-        }
-        // dK^T += Qr^T (rows d, k = these queries) x dS^T (rows key, k = queries); dV^T += dO^T x P^T
-#pragma unroll
-        for (int dj = 0; dj < 2; ++dj) {
-            const f16x8 qf = *(const f16x8*)(sQt + (dj * 16 + fr) * TF_LDP + q0 + fg * 8);
-            const f16x8 of = *(const f16x8*)(sdOt + (dj * 16 + fr) * TF_LDP + q0 + fg * 8);
-#pragma unroll
-            for (int j = 0; j < TF_NKT; ++j)
-                if (j < NK) {
-                    const f16x8 sf = *(const f16x8*)(sdSt + (j * 16 + fr) * 40 + fg * 8);
-                    const f16x8 pf = *(const f16x8*)(sPt + (j * 16 + fr) * 40 + fg * 8);
-                    accK[dj][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(qf, sf, accK[dj][j], 0, 0, 0);
-                    accV[dj][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(of, pf, accV[dj][j], 0, 0, 0);
+                    for (int r = 0; r < 4; ++r) { accK[dj][j][r] += k[r]; accV[dj][j][r] += v[r]; }
                 }
         }
         __syncthreads();
     }
+    if (wave != 0) return;
 #pragma unroll
     for (int j = 0; j < TF_NKT; ++j) {
         const int key = j * 16 + fr;

@@ -152,12 +152,30 @@ static int tf_alloc_work(const TfModel* t, TfWork* wk, int n) {
     return PPDE_OK;
 }
 
+#define TF_GEMM_DEFAULT 0
 template <int EPI>
 static int tf_gemm(hipStream_t s, const half_t* A, const half_t* B, half_t* C, int M, int N, int K, const float* bias = nullptr,
                    const half_t* R = nullptr, half_t* C2 = nullptr, float alpha = 1.f, int qcols = 0) {
     ARGCHK(M % 128 == 0 && N % 128 == 0 && K % 64 == 0, "transformer GEMM shape is not a multiple of the 128 x 128 x 64 tile");
     TfGemmArgs g{A, B, C, bias, R, C2, M, N, K, alpha, qcols};
-    hipLaunchKernelGGL(tf_gemm_nt<EPI>, dim3((M >> 7) * (N >> 7)), dim3(256), 4 * 128 * 64 * sizeof(half_t), s, g);
+    // staged k depth x LDS buffers (tuning knob PPDE_TF_GEMM=64x2|64x3|32x2|32x3|32x4; default: the measured optimum)
+    static const int variant = []() {
+        const char* e = getenv("PPDE_TF_GEMM");
+        if (!e) return TF_GEMM_DEFAULT;
+        if (!strcmp(e, "64x2")) return 0; if (!strcmp(e, "64x3")) return 1; if (!strcmp(e, "32x2")) return 2;
+        if (!strcmp(e, "32x3")) return 3; if (!strcmp(e, "32x4")) return 4;
+        return TF_GEMM_DEFAULT;
+    }();
+    const dim3 grid((M >> 7) * (N >> 7));
+#define TF_LAUNCH(BKV, STV) { constexpr size_t lds_ = (size_t)STV * 2 * 128 * BKV * 2; hipLaunchKernelGGL((tf_gemm_nt<EPI, BKV, STV>), grid, dim3(256), lds_, s, g); }
+    switch (variant) {
+        case 0: TF_LAUNCH(64, 2) break;
+        case 1: TF_LAUNCH(64, 3) break;
+        case 2: TF_LAUNCH(32, 2) break;
+        case 3: TF_LAUNCH(32, 3) break;
+        default: TF_LAUNCH(32, 4) break;
+    }
+#undef TF_LAUNCH
     HIPCHK(hipGetLastError());
     return PPDE_OK;
 }
@@ -197,7 +215,7 @@ static int tf_eval(const TfModel* t, TfWork* wk, const uint8_t* rows, int Ls, in
         TFRC(tf_ln(s, false, a.xin, wk->ln_out, w.ln1g, w.ln1b, a.mean1, a.rstd1, M, D));
         TFRC(tf_gemm<TF_EPI_BIAS_QSCALE>(s, wk->ln_out, w.Wqkv, a.qkv, Mp, 3 * D, D, w.bqkv, nullptr, nullptr, qs, D));
         TfAttnArgs at{a.qkv, wk->ctx, a.P, t->rope_cos, t->rope_sin, nullptr, nullptr, n, L, H, D, qs};
-        hipLaunchKernelGGL(tf_attn_fwd, dim3(n * (H / TF_ATT_WAVES)), dim3(64 * TF_ATT_WAVES), tf_attn_fwd_lds(), s, at);
+        hipLaunchKernelGGL(tf_attn_fwd, dim3(n * H), dim3(64 * TF_ATT_WAVES), tf_attn_fwd_lds(), s, at);
         HIPCHK(hipGetLastError());
         TFRC(tf_gemm<TF_EPI_BIAS_RESID>(s, wk->ctx, w.Wo, a.xmid, Mp, D, D, w.bo, a.xin));
         TFRC(tf_ln(s, false, a.xmid, wk->ln_out, w.ln2g, w.ln2b, a.mean2, a.rstd2, M, D));
@@ -231,7 +249,7 @@ static int tf_eval(const TfModel* t, TfWork* wk, const uint8_t* rows, int Ls, in
         TFRC(tf_ln(s, true, a.xmid, wk->gB, w.ln2g, w.ln2b, a.mean2, a.rstd2, M, D, wk->tmpD, wk->gA));
         TFRC(tf_gemm<TF_EPI_PLAIN>(s, wk->gB, w.WoT, wk->tmpD, Mp, D, D));
         TfAttnArgs at{a.qkv, nullptr, a.P, t->rope_cos, t->rope_sin, wk->tmpD, wk->dqkv, n, L, H, D, qs};
-        hipLaunchKernelGGL(tf_attn_bwd, dim3(n * (H / TF_ATT_WAVES)), dim3(64 * TF_ATT_WAVES), tf_attn_bwd_lds(), s, at);
+        hipLaunchKernelGGL(tf_attn_bwd, dim3(n * H), dim3(64 * TF_ATT_WAVES), tf_attn_bwd_lds(), s, at);
         HIPCHK(hipGetLastError());
         TFRC(tf_gemm<TF_EPI_PLAIN>(s, wk->dqkv, w.WqkvT, wk->tmpD, Mp, D, 3 * D));
         TFRC(tf_ln(s, true, a.xin, wk->gA, w.ln1g, w.ln1b, a.mean1, a.rstd1, M, D, wk->tmpD, wk->gB, l == 0 ? TF_TOKEN_DROPOUT_SCALE : 1.f));

@@ -1,0 +1,24 @@
+#!/usr/bin/env python3
+"""Timing sweep of the transformer GEMM kernel variants (staged k depth x LDS buffers) at the shapes of one layer
+(tuning aid; run on the GPU box): python scripts/tune_tf_gemm.py"""
+import ctypes as C
+import os
+import subprocess
+import sys
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+SHAPES = [(26624, 1920, 640), (26624, 640, 640), (26624, 2560, 640), (26624, 640, 2560), (26624, 640, 1920)]
+if os.environ.get("TF_TUNE_CHILD"):
+    from ppde_amd import _hip
+    lib = _hip.load()
+    for M, N, K in SHAPES:
+        us = C.c_float()
+        _hip.check(lib.ppde_transformer_time_gemm(0, M, N, K, 30, C.byref(us)))
+        print(f"{os.environ.get('PPDE_TF_GEMM', 'default'):8s} M={M} N={N:5d} K={K:5d}: {us.value:8.1f} us  {2.0 * M * N * K / us.value / 1e6:7.1f} TFLOP/s", flush=True)
+    sys.exit(0)
+for v in ("64x2", "64x3", "32x2", "32x3", "32x4"):
+    r = subprocess.run([sys.executable, os.path.abspath(__file__)], env=dict(os.environ, TF_TUNE_CHILD="1", PPDE_TF_GEMM=v), capture_output=True, text=True)
+    sys.stdout.write(r.stdout)
+    if r.returncode:
+        sys.stdout.write(r.stderr[-1500:])
