@@ -78,7 +78,7 @@ def main(args, rank, world, local, backend):
     # dominant kernel: tf_gemm_nt at the fc1 shape
     M = (n * L + 127) // 128 * 128
     us = C.c_float()
-    _hip.check(_hip.load().ppde_transformer_time_gemm(local, M, F, D, 50, C.byref(us)))
+    _hip.check(_hip.load().ppde_transformer_time_gemm(local, M, F, D, 50, 3, C.byref(us)))
     gemm_tf = 2.0 * M * F * D / (us.value * 1e-6) / 1e12
     # one evaluation on its own
     x = torch.as_tensor(np.tile(wt, (n, 1))).to(device)

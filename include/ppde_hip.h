@@ -110,10 +110,11 @@ int ppde_model_set_transformer(ppde_model* m, int n_layers, int dim, int heads, 
 /* local score of the wild type (nets.py:188 `wt_score`) for inspection. */
 int ppde_model_get_transformer_wt_score(ppde_model* m, float* out_host);
 
-/* Timing hook for bench.py: average duration (microseconds) of the transformer's GEMM kernel, C[M,N] = A[M,K] B[N,K]^T
- * with the bias + GELU epilogue (the fc1 form), fp16 operands filled with pseudo-random values, `reps` launches
- * between one HIP event pair. M, N multiples of 128, K of 64. */
-int ppde_transformer_time_gemm(int device, int M, int N, int K, int reps, float* avg_us);
+/* Timing hook for bench.py: average duration (microseconds) of the transformer's GEMM kernel, C[M,N] = A[M,K] B[N,K]^T,
+ * fp16 operands filled with pseudo-random values, `reps` launches between one HIP event pair. epilogue: 0 bias,
+ * 2 bias + residual, 3 bias + GELU (the fc1 form), 4 GELU' (backward through fc2), 5 plain. M, N multiples of 128,
+ * K of 64. */
+int ppde_transformer_time_gemm(int device, int M, int N, int K, int reps, int epilogue, float* avg_us);
 
 /* Diagnostics for the parity tests: an fp16 activation of the last stateless evaluation that used the transformer
  * expert, converted to fp32. what: 0 layer input, 1 q|k|v, 2 attention probabilities, 3 post-attention stream,

@@ -480,7 +480,7 @@ int ppde_model_set_transformer(ppde_model* m, int n_layers, int dim, int heads, 
 
 // Timing hook for bench.py: the transformer's GEMM kernel (fc1 form: bias + GELU epilogue) on pseudo-random fp16
 // operands of the given shape, `reps` launches between one HIP event pair on a stream of its own.
-int ppde_transformer_time_gemm(int device, int M, int N, int K, int reps, float* avg_us) {
+int ppde_transformer_time_gemm(int device, int M, int N, int K, int reps, int epilogue, float* avg_us) {
     ARGCHK(avg_us && reps >= 1 && M > 0 && N > 0 && K > 0, "bad argument");
     HIPCHK(hipSetDevice(device));
     DevTmp A, B, C, C2, bias;
@@ -496,12 +496,20 @@ int ppde_transformer_time_gemm(int device, int M, int N, int K, int reps, float*
     EventPair ev;
     HIPCHK(hipEventCreate(&ev.a)); HIPCHK(hipEventCreate(&ev.b));
     int rc = PPDE_OK;
-    for (int i = 0; i < 3 && rc == PPDE_OK; ++i)
-        rc = tf_gemm<TF_EPI_BIAS_GELU>(s, A.as<half_t>(), B.as<half_t>(), C.as<half_t>(), M, N, K, bias.as<float>(), nullptr, C2.as<half_t>());
+    auto one = [&]() {
+        switch (epilogue) {
+            case TF_EPI_PLAIN: return tf_gemm<TF_EPI_PLAIN>(s, A.as<half_t>(), B.as<half_t>(), C.as<half_t>(), M, N, K);
+            case TF_EPI_BIAS: return tf_gemm<TF_EPI_BIAS>(s, A.as<half_t>(), B.as<half_t>(), C.as<half_t>(), M, N, K, bias.as<float>());
+            case TF_EPI_BIAS_RESID: return tf_gemm<TF_EPI_BIAS_RESID>(s, A.as<half_t>(), B.as<half_t>(), C.as<half_t>(), M, N, K, bias.as<float>(), C2.as<half_t>());
+            case TF_EPI_GELU_BWD: return tf_gemm<TF_EPI_GELU_BWD>(s, A.as<half_t>(), B.as<half_t>(), C.as<half_t>(), M, N, K, nullptr, C2.as<half_t>());
+            default: return tf_gemm<TF_EPI_BIAS_GELU>(s, A.as<half_t>(), B.as<half_t>(), C.as<half_t>(), M, N, K, bias.as<float>(), nullptr, C2.as<half_t>());
+        }
+    };
+    HIPCHK(hipMemsetAsync(C2.p, 0, (size_t)M * N * sizeof(half_t), s));
+    for (int i = 0; i < 3 && rc == PPDE_OK; ++i) rc = one();
     if (rc) return rc;
     HIPCHK(hipEventRecord(ev.a, s));
-    for (int i = 0; i < reps && rc == PPDE_OK; ++i)
-        rc = tf_gemm<TF_EPI_BIAS_GELU>(s, A.as<half_t>(), B.as<half_t>(), C.as<half_t>(), M, N, K, bias.as<float>(), nullptr, C2.as<half_t>());
+    for (int i = 0; i < reps && rc == PPDE_OK; ++i) rc = one();
     if (rc) return rc;
     HIPCHK(hipEventRecord(ev.b, s));
     HIPCHK(hipEventSynchronize(ev.b));

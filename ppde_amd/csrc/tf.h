@@ -75,16 +75,22 @@ __device__ __forceinline__ void tf_glds16(const void* sbase, uint32_t voff, uint
 
 // BK = k depth of one staged tile (32 or 64 halfs), STAGES = LDS buffers (prefetch distance STAGES - 1).
 template <int BK, int STAGES>
-__host__ __device__ constexpr size_t tf_gemm_lds() { return (size_t)STAGES * 2 * 128 * BK * 2; }
+__host__ __device__ constexpr size_t tf_gemm_lds() {
+    const size_t operands = (size_t)STAGES * 2 * 128 * BK * 2, out_tile = (size_t)128 * 136 * 2;   // (the epilogue stages the output tile)
+    return operands > out_tile ? operands : out_tile;
+}
 
-template <int EPI, int BK, int STAGES>
-__global__ __launch_bounds__(256, 2) void tf_gemm_nt(TfGemmArgs g) {
+// NWAVE = 4: waves 2 x 2, each 64 x 64; NWAVE = 8: waves 4 x 2, each 32 x 64 (twice the waves to hide the DMA latency with)
+template <int EPI, int BK, int STAGES, int NWAVE = 4>
+__global__ __launch_bounds__(64 * NWAVE, 2) void tf_gemm_nt(TfGemmArgs g) {
+    static_assert(NWAVE == 4 || NWAVE == 8, "waves per workgroup");
+    constexpr int MT = 16 / NWAVE;                   // 16-row tiles per wave
     static_assert(BK == 32 || BK == 64, "k depth of a staged tile");
     extern __shared__ __attribute__((aligned(16))) unsigned char tf_smem[];
     constexpr int TILE = 128 * BK;                   // halfs of one operand tile
     constexpr int CH = BK / 8;                       // 16-byte chunks per row (4 or 8)
     constexpr int RPP = 64 / CH;                     // rows per 1-KiB DMA piece (16 or 8)
-    constexpr int PPT = (128 / RPP) / 4;             // pieces per operand, tile and wave (2 or 4)
+    constexpr int PPT = (128 / RPP) / NWAVE;         // pieces per operand, tile and wave
     half_t* sA = (half_t*)tf_smem;                   // [STAGES][128][BK]
     half_t* sB = sA + STAGES * TILE;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -121,29 +127,39 @@ __global__ __launch_bounds__(256, 2) void tf_gemm_nt(TfGemmArgs g) {
             tf_glds16(kb, voff[i], (uint32_t)(uintptr_t)(sB + buf * TILE + p * 512));
         }
     };
-    tf_f32x4 acc[4][4];
+    tf_f32x4 acc[MT][4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < MT; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (tf_f32x4){0.f, 0.f, 0.f, 0.f};
     const int fr = lane & 15, fg = lane >> 4;
     auto compute = [&](int buf) {
-        const half_t* a = sA + buf * TILE + (wm * 64 + fr) * BK;
+        const half_t* a = sA + buf * TILE + (wm * 16 * MT + fr) * BK;
         const half_t* b = sB + buf * TILE + (wn * 64 + fr) * BK;
 #pragma unroll
         for (int s = 0; s < BK / 32; ++s) {
-            f16x8 af[4], bf[4];
+            f16x8 af[MT], bf[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {                             // rows fr + 16 i (+ multiples of 64): SW(row) == SW(fr)
-                af[i] = *(const f16x8*)(a + i * 16 * BK + (((s * 4 + fg) ^ SW(fr)) << 3));
+            for (int i = 0; i < 4; ++i) {                             // rows fr + 16 i (+ multiples of 32): SW(row) == SW(fr)
+                if (i < MT) af[i] = *(const f16x8*)(a + i * 16 * BK + (((s * 4 + fg) ^ SW(fr)) << 3));
                 bf[i] = *(const f16x8*)(b + i * 16 * BK + (((s * 4 + fg) ^ SW(fr)) << 3));
             }
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < MT; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j], af[i], acc[i][j], 0, 0, 0);
         }
     };
+    // the epilogue's second operand (residual / pre-activation) is requested now: fetched at the tile's end it was a
+    // dependent, scattered 8-byte load per 16 x 16 tile with nothing left to overlap (+50 % on the N = 2560 GEMMs)
+    f16x4 rpre[MT][4];
+    if constexpr (EPI == TF_EPI_BIAS_RESID || EPI == TF_EPI_GELU_BWD) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                rpre[i][j] = *(const f16x4*)(g.R + (size_t)(m0 + wm * 16 * MT + i * 16 + (lane & 15)) * g.N + n0 + wn * 64 + j * 16 + 4 * (lane >> 4));
+    }
     // ring of STAGES buffers, tiles kt+1 .. kt+STAGES-2 stay in flight across the barrier of iteration kt
 #pragma unroll
     for (int t = 0; t < STAGES - 1; ++t)
@@ -157,21 +173,36 @@ __global__ __launch_bounds__(256, 2) void tf_gemm_nt(TfGemmArgs g) {
         if (kt + STAGES - 1 < nk) stage((kt + STAGES - 1) % STAGES, kt + STAGES - 1);
         compute(kt % STAGES);
     }
-    // ---- epilogue: lane = row fr of each 16-row tile, columns 4 fg .. 4 fg + 3 of each 16-column tile
+    // ---- epilogue: lane = row fr of each 16-row tile, columns 4 fg .. 4 fg + 3 of each 16-column tile. The fp16 tile goes
+    //      through LDS (free now) so that it leaves as whole 256-byte rows, 16 bytes per lane: written straight from the
+    //      accumulator layout it was 32 scattered 8-byte stores per wave and output (a second output cost as much as
+    //      half of the k loop at K = 640).
+    constexpr int OLD = 136;                                          // padded row length (halfs) of the staged tile
+    half_t* sOut = (half_t*)tf_smem;
+    static_assert((size_t)128 * OLD * 2 <= tf_gemm_lds<BK, STAGES>(), "the output tile is staged in the operand buffers");
+    auto flush = [&](half_t* dst) {                                   // sOut -> dst tile, coalesced
+        __syncthreads();
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int m = m0 + wm * 64 + i * 16 + fr;
+        for (int c = tid; c < 128 * 16; c += 64 * NWAVE) {
+            const int row = c >> 4, ch = c & 15;
+            *(f16x8*)(dst + (size_t)(m0 + row) * g.N + n0 + ch * 8) = *(const f16x8*)(sOut + row * OLD + ch * 8);
+        }
+    };
+    __syncthreads();                                                  // every wave is done with the operand tiles
+    [[maybe_unused]] f16x4 second[MT][4];                             // BIAS_GELU: the activation, stored after the pre-activation
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        const int ml = wm * 16 * MT + i * 16 + fr;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const int n = n0 + wn * 64 + j * 16 + 4 * fg;
-            const size_t at = (size_t)m * g.N + n;
+            const int nl = wn * 64 + j * 16 + 4 * fg, n = n0 + nl;
             float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
             f16x4 out;
             if constexpr (EPI == TF_EPI_PLAIN) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) out[r] = (half_t)v[r];
             } else if constexpr (EPI == TF_EPI_GELU_BWD) {
-                const f16x4 h = *(const f16x4*)(g.R + at);
+                const f16x4 h = rpre[i][j];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) out[r] = (half_t)((float)(half_t)v[r] * tf_gelu_grad((float)h[r]));
             } else {
@@ -185,18 +216,26 @@ __global__ __launch_bounds__(256, 2) void tf_gemm_nt(TfGemmArgs g) {
                         for (int r = 0; r < 4; ++r) out[r] = (half_t)((float)out[r] * g.alpha);
                     }
                 } else if constexpr (EPI == TF_EPI_BIAS_RESID) {
-                    const f16x4 res = *(const f16x4*)(g.R + at);
+                    const f16x4 res = rpre[i][j];
 #pragma unroll
                     for (int r = 0; r < 4; ++r) out[r] = (half_t)((float)out[r] + (float)res[r]);
                 } else if constexpr (EPI == TF_EPI_BIAS_GELU) {
-                    *(f16x4*)(g.C2 + at) = out;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) out[r] = (half_t)tf_gelu((float)out[r]);
+                    for (int r = 0; r < 4; ++r) second[i][j][r] = (half_t)tf_gelu((float)out[r]);
                 }
             }
-            *(f16x4*)(g.C + at) = out;
+            *(f16x4*)(sOut + ml * OLD + nl) = out;
         }
     }
+    if constexpr (EPI == TF_EPI_BIAS_GELU) {
+        flush(g.C2);                                                  // the pre-activation
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) *(f16x4*)(sOut + (wm * 16 * MT + i * 16 + fr) * OLD + wn * 64 + j * 16 + 4 * fg) = second[i][j];
+    }
+    flush(g.C);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -484,10 +523,11 @@ __global__ __launch_bounds__(64 * TF_ATT_WAVES) void tf_attn_fwd(TfAttnArgs a) {
 //   a fixed order at the end (wave 1's partial sums go through LDS to wave 0).
 // LDS: v rows | dO rows | dO^T | k^T (rotated) | q^T (rotated) | per wave two 16 x 16 transpose tiles
 #define TF_ATT_STAGE (2 * TF_TP * TF_HD + 3 * TF_HD * TF_LDP)
-__host__ __device__ inline size_t tf_attn_bwd_lds() { return (size_t)(TF_ATT_STAGE + TF_ATT_WAVES * 512) * 2; }
+#define TF_ATT_TRB 4                 // key tiles turned query-major per batch (two 512-byte tiles each)
+__host__ __device__ inline size_t tf_attn_bwd_lds() { return (size_t)(TF_ATT_STAGE + TF_ATT_WAVES * TF_ATT_TRB * 512) * 2; }
 static_assert((size_t)TF_ATT_STAGE * 2 >= (size_t)(TF_ATT_WAVES - 1) * 4 * TF_NKT * 64 * 16, "the staging area also carries the partial sums");
 
-__global__ __launch_bounds__(64 * TF_ATT_WAVES) void tf_attn_bwd(TfAttnArgs a) {
+__global__ __launch_bounds__(64 * TF_ATT_WAVES, 2) void tf_attn_bwd(TfAttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char tf_smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.x / a.H, h = blockIdx.x % a.H;
@@ -497,7 +537,7 @@ __global__ __launch_bounds__(64 * TF_ATT_WAVES) void tf_attn_bwd(TfAttnArgs a) {
     half_t* sdOt = sdO + TF_TP * TF_HD;                        // [32][LDP]
     half_t* sKt = sdOt + TF_HD * TF_LDP;                       // [32][LDP] rotated k, transposed
     half_t* sQt = sKt + TF_HD * TF_LDP;                        // [32][LDP] rotated q, transposed
-    half_t* sT = sQt + TF_HD * TF_LDP + wave * 512;            // this wave's two 16 x 16 tiles
+    half_t* sT = sQt + TF_HD * TF_LDP + wave * TF_ATT_TRB * 512;   // this wave's transpose tiles: TF_ATT_TRB x (dS, P) of 16 x 16
     const half_t* base = a.qkv + (size_t)b * L * ld + h * TF_HD;
     const half_t* dob = a.dctx + (size_t)b * L * D + h * TF_HD;
     tf_zero_lds(sV, TF_ATT_STAGE, tid, 64 * TF_ATT_WAVES);
@@ -570,22 +610,35 @@ __global__ __launch_bounds__(64 * TF_ATT_WAVES) void tf_attn_bwd(TfAttnArgs a) {
         const f16x4 qf0 = *(const f16x4*)(sQt + (fr) * TF_LDP + qi * 16 + 4 * fg), qf1 = *(const f16x4*)(sQt + (16 + fr) * TF_LDP + qi * 16 + 4 * fg);
         const f16x4 of0 = *(const f16x4*)(sdOt + (fr) * TF_LDP + qi * 16 + 4 * fg), of1 = *(const f16x4*)(sdOt + (16 + fr) * TF_LDP + qi * 16 + 4 * fg);
 #pragma unroll
-        for (int j = 0; j < TF_NKT; ++j)
-            if (j < NK) {
-                *(f16x4*)(sT + fr * 16 + 4 * fg) = ds[j];
-                *(f16x4*)(sT + 256 + fr * 16 + 4 * fg) = pt[j];
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                const tf_hfx4 dsq_ = __builtin_amdgcn_ds_read_tr16_b64_v4f16((lds_tr_ptr)(sT + tr_off));
-                const tf_hfx4 pq_ = __builtin_amdgcn_ds_read_tr16_b64_v4f16((lds_tr_ptr)(sT + 256 + tr_off));
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                f16x4 dsq, pq;
+        for (int jb = 0; jb < TF_NKT; jb += TF_ATT_TRB) {
+            if (jb >= NK) break;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) { dsq[r] = (half_t)dsq_[r]; pq[r] = (half_t)pq_[r]; }
-                accK[0][j] = __builtin_amdgcn_mfma_f32_16x16x16f16(qf0, dsq, accK[0][j], 0, 0, 0);
-                accK[1][j] = __builtin_amdgcn_mfma_f32_16x16x16f16(qf1, dsq, accK[1][j], 0, 0, 0);
-                accV[0][j] = __builtin_amdgcn_mfma_f32_16x16x16f16(of0, pq, accV[0][j], 0, 0, 0);
-                accV[1][j] = __builtin_amdgcn_mfma_f32_16x16x16f16(of1, pq, accV[1][j], 0, 0, 0);
+            for (int u = 0; u < TF_ATT_TRB; ++u)
+                if (jb + u < NK) {
+                    *(f16x4*)(sT + u * 512 + fr * 16 + 4 * fg) = ds[jb + u];
+                    *(f16x4*)(sT + u * 512 + 256 + fr * 16 + 4 * fg) = pt[jb + u];
+                }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            tf_hfx4 dsq_[TF_ATT_TRB], pq_[TF_ATT_TRB];
+#pragma unroll
+            for (int u = 0; u < TF_ATT_TRB; ++u) {
+                dsq_[u] = __builtin_amdgcn_ds_read_tr16_b64_v4f16((lds_tr_ptr)(sT + u * 512 + tr_off));
+                pq_[u] = __builtin_amdgcn_ds_read_tr16_b64_v4f16((lds_tr_ptr)(sT + u * 512 + 256 + tr_off));
             }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int u = 0; u < TF_ATT_TRB; ++u)
+                if (jb + u < NK) {
+                    const int j = jb + u;
+                    f16x4 dsq, pq;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { dsq[r] = (half_t)dsq_[u][r]; pq[r] = (half_t)pq_[u][r]; }
+                    accK[0][j] = __builtin_amdgcn_mfma_f32_16x16x16f16(qf0, dsq, accK[0][j], 0, 0, 0);
+                    accK[1][j] = __builtin_amdgcn_mfma_f32_16x16x16f16(qf1, dsq, accK[1][j], 0, 0, 0);
+                    accV[0][j] = __builtin_amdgcn_mfma_f32_16x16x16f16(of0, pq, accV[0][j], 0, 0, 0);
+                    accV[1][j] = __builtin_amdgcn_mfma_f32_16x16x16f16(of1, pq, accV[1][j], 0, 0, 0);
+                }
+        }
     }
     // ---- sum the waves' partial dK^T, dV^T in wave order (wave 0 + wave 1 + ...), through the staging area
     __syncthreads();

@@ -158,24 +158,29 @@ static int tf_gemm(hipStream_t s, const half_t* A, const half_t* B, half_t* C, i
                    const half_t* R = nullptr, half_t* C2 = nullptr, float alpha = 1.f, int qcols = 0) {
     ARGCHK(M % 128 == 0 && N % 128 == 0 && K % 64 == 0, "transformer GEMM shape is not a multiple of the 128 x 128 x 64 tile");
     TfGemmArgs g{A, B, C, bias, R, C2, M, N, K, alpha, qcols};
-    // staged k depth x LDS buffers (tuning knob PPDE_TF_GEMM=64x2|64x3|32x2|32x3|32x4; default: the measured optimum)
+    // staged k depth x LDS buffers (tuning knob PPDE_TF_GEMM=64x2|64x3|32x2|32x3|32x4|64x2w8|32x3w8; default: the measured optimum)
     static const int variant = []() {
         const char* e = getenv("PPDE_TF_GEMM");
         if (!e) return TF_GEMM_DEFAULT;
         if (!strcmp(e, "64x2")) return 0; if (!strcmp(e, "64x3")) return 1; if (!strcmp(e, "32x2")) return 2;
-        if (!strcmp(e, "32x3")) return 3; if (!strcmp(e, "32x4")) return 4;
+        if (!strcmp(e, "32x3")) return 3; if (!strcmp(e, "32x4")) return 4; if (!strcmp(e, "64x2w8")) return 5;
+        if (!strcmp(e, "32x3w8")) return 6;
         return TF_GEMM_DEFAULT;
     }();
     const dim3 grid((M >> 7) * (N >> 7));
-#define TF_LAUNCH(BKV, STV) { constexpr size_t lds_ = (size_t)STV * 2 * 128 * BKV * 2; hipLaunchKernelGGL((tf_gemm_nt<EPI, BKV, STV>), grid, dim3(256), lds_, s, g); }
+#define TF_LAUNCH(BKV, STV) { constexpr size_t lds_ = tf_gemm_lds<BKV, STV>(); hipLaunchKernelGGL((tf_gemm_nt<EPI, BKV, STV, 4>), grid, dim3(256), lds_, s, g); }
+#define TF_LAUNCH8(BKV, STV) { constexpr size_t lds_ = tf_gemm_lds<BKV, STV>(); hipLaunchKernelGGL((tf_gemm_nt<EPI, BKV, STV, 8>), grid, dim3(512), lds_, s, g); }
     switch (variant) {
         case 0: TF_LAUNCH(64, 2) break;
         case 1: TF_LAUNCH(64, 3) break;
         case 2: TF_LAUNCH(32, 2) break;
         case 3: TF_LAUNCH(32, 3) break;
-        default: TF_LAUNCH(32, 4) break;
+        case 4: TF_LAUNCH(32, 4) break;
+        case 5: TF_LAUNCH8(64, 2) break;
+        default: TF_LAUNCH8(32, 3) break;
     }
 #undef TF_LAUNCH
+#undef TF_LAUNCH8
     HIPCHK(hipGetLastError());
     return PPDE_OK;
 }

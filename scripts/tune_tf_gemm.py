@@ -13,11 +13,12 @@ if os.environ.get("TF_TUNE_CHILD"):
     from ppde_amd import _hip
     lib = _hip.load()
     for M, N, K in SHAPES:
-        us = C.c_float()
-        _hip.check(lib.ppde_transformer_time_gemm(0, M, N, K, 30, C.byref(us)))
-        print(f"{os.environ.get('PPDE_TF_GEMM', 'default'):8s} M={M} N={N:5d} K={K:5d}: {us.value:8.1f} us  {2.0 * M * N * K / us.value / 1e6:7.1f} TFLOP/s", flush=True)
+        for epi, name in ((5, "plain"), (2, "bias+resid"), (3, "bias+gelu"), (4, "gelu'")):
+            us = C.c_float()
+            _hip.check(lib.ppde_transformer_time_gemm(0, M, N, K, 30, epi, C.byref(us)))
+            print(f"{os.environ.get('PPDE_TF_GEMM', 'default'):8s} M={M} N={N:5d} K={K:5d} {name:10s}: {us.value:8.1f} us  {2.0 * M * N * K / us.value / 1e6:7.1f} TFLOP/s", flush=True)
     sys.exit(0)
-for v in ("64x2", "64x3", "32x2", "32x3", "32x4"):
+for v in (sys.argv[1:] or ("64x2", "64x3", "32x2", "32x3", "32x4", "64x2w8", "32x3w8")):
     r = subprocess.run([sys.executable, os.path.abspath(__file__)], env=dict(os.environ, TF_TUNE_CHILD="1", PPDE_TF_GEMM=v), capture_output=True, text=True)
     sys.stdout.write(r.stdout)
     if r.returncode:
