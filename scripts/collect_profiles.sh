@@ -44,6 +44,15 @@ echo "MFMA (config 3) done"
 python3 "$ROOT/scripts/summarize_profiles.py" "${TAG}" --fetch "$OUT/prof_${TAG}_FETCH_SIZE" --write "$OUT/prof_${TAG}_WRITE_SIZE" --sq "$OUT/prof_${TAG}_SQ" --key PABP > /dev/null
 python3 "$ROOT/scripts/summarize_profiles.py" "${TAG}_gfp" --fetch "$OUT/prof_${TAG}_gfp_FETCH_SIZE" --write "$OUT/prof_${TAG}_gfp_WRITE_SIZE" --key GFP > /dev/null
 python3 "$ROOT/scripts/summarize_profiles.py" "${TAG}_config3" --mfma "$OUT/prof_${TAG}_MFMA" > /dev/null
+# 3b. transformer workload (BASELINE config 5): bench line, per-kernel table, GEMM shapes / epilogues
+python3 "$ROOT/bench.py" --workload transformer > "$OUT/prof_${TAG}_tf_bench.log" 2>&1
+grep '^{' "$OUT/prof_${TAG}_tf_bench.log" > "$P/${TAG}_transformer_bench_stdout.log"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_${TAG}_tf" -- python3 "$ROOT/bench.py" --workload transformer --steps 4 --warmup 1 --repeats 1 --no-cpu-baseline > "$OUT/prof_${TAG}_tf.log" 2>&1
+cp "$(ls -t "$OUT"/prof_${TAG}_tf/*/*kernel_stats.csv | head -1)" "$P/${TAG}_transformer_kernel_stats.csv"
+python3 "$ROOT/scripts/tune_tf_gemm.py" 64x2 64x2w8 32x3 2>&1 | grep -v amdgpu.ids > "$P/${TAG}_transformer_gemm_variants.log" || true
+echo "transformer done"
+# 3c. probes quoted in DESIGN.md
+(cd "$ROOT" && timeout -k 10 120 scripts/probes/xcd_probe > "$P/${TAG}_xcd_probe.log" 2>&1; timeout -k 10 60 scripts/probes/mfma_probe > "$P/${TAG}_mfma_probe.log" 2>&1) || true
 # 4. in-kernel stamps (diagnostic build; shares, not lengths) and the per-workgroup Potts timelines
 cd "$ROOT"
 python3 scripts/stamp_kernels.py > "$P/${TAG}_stamps_pabp.log" 2>&1 || true

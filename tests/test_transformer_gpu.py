@@ -134,3 +134,38 @@ def test_reference_style_energy_object_with_a_checkpoint_file():
         assert torch.equal(e, e2) and g.shape == (3, 24, 20) and torch.isfinite(g).all()
         assert torch.allclose(e, fit, atol=1e-6)            # wild type: Delta score is 0, so e = lamda * fit
         assert float(ef.get_unsupervised_expert(x).abs().max()) == 0.0
+
+
+def test_driver_with_the_transformer_expert():
+    """scripts/directed_evolution.py --unsupervised_expert potts+transformer end to end (toy checkpoint under the 150M
+    file name in --hub_dir/checkpoints, as the reference's torch-hub download would leave it)."""
+    import contextlib
+    import glob
+    import importlib.util
+    import io
+    import ppde_amd.energy as en
+    REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("ppde_amd_directed_evolution_tf", os.path.join(REPO, "scripts", "directed_evolution.py"))
+    drv = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(drv)
+    saved = dict(en.ESM2_CHECKPOINTS)
+    try:
+        with tempfile.TemporaryDirectory() as root, tempfile.TemporaryDirectory() as res:
+            synthetic.write_weights_dir(root, "TOY24", potts_seed=7)
+            synthetic.write_esm2_checkpoint(os.path.join(res, "checkpoints", "esm2_t30_150M_UR50D.pt"), 2, 128, 4, 256, seed=2)
+            en.ESM2_CHECKPOINTS["potts+transformer"] = ("esm2_t30_150M_UR50D", 4)      # (the toy stand-in has 4 heads of 32)
+            argv = ["--protein_weights", root, "--protein", "TOY24", "--results_path", res, "--hub_dir", res, "--device", "cuda:0",
+                    "--disable_MSA_transformer_scoring", "--sampler", "PPDE", "--unsupervised_expert", "potts+transformer",
+                    "--n_chains", "6", "--n_iters", "12", "--seed", "3", "--log_every", "5", "--energy_lamda", "1", "--ppde_rng", "philox"]
+            args = drv.build_parser().parse_args(argv)
+            args.ppde_reuse_grad = True
+            with contextlib.redirect_stdout(io.StringIO()) as buf:
+                out_dir = drv.main(args)
+            eh = np.load(os.path.join(out_dir, "energy_history.npy"))
+            pop = np.load(os.path.join(out_dir, "population.npy"))
+            assert eh.shape == (13, 6) and np.isfinite(eh).all() and pop.shape == (6, 24, 20)
+            assert np.array_equal(np.load(os.path.join(out_dir, "energy_scores.npy")), eh.max(0))
+            assert "[Iteration 4]" in buf.getvalue()
+    finally:
+        en.ESM2_CHECKPOINTS.clear()
+        en.ESM2_CHECKPOINTS.update(saved)
