@@ -74,6 +74,7 @@ struct PottsArgs {
     int n;                   // chains in the buffers (slot stride)
     int b_off, n_sub;        // this launch covers chains [b_off, b_off + n_sub)
     unsigned long long* dbg; // stamp buffer (diagnostic build)
+    int dbg_wg_base;         // first per-workgroup record of this launch's Potts tiles (the fused experts launch keeps the CNN's in front)
     Geom g;
 };
 
@@ -170,7 +171,7 @@ __device__ __forceinline__ void potts_body(const PottsArgs& a, const int tile, c
     const int b0 = a.b_off + by * CPB;
     const int b_end = a.b_off + a.n_sub;
     [[maybe_unused]] const bool stamp = tile == 0 && by == 0;
-    [[maybe_unused]] const int wg_lin = tile * ((a.n_sub + CPB - 1) / CPB) + by;
+    [[maybe_unused]] const int wg_lin = a.dbg_wg_base + tile * ((a.n_sub + CPB - 1) / CPB) + by;
     PPDE_STAMP(a.dbg, 0, stamp);
     PPDE_WG_STAMP(a.dbg, wg_lin, 0);
     const int slab_rows = RING ? POTTS_RING_CHUNKS * 80 : NC * 80;   // float4 rows of LDS per wave

@@ -339,7 +339,7 @@ static int launch_experts_fused(const ppde_model* m, const States& st, int n, co
     c.slot = t.slot; c.n = n; c.want_grad = 1; c.scale = scale;
     c.g = m->g;
     PottsArgs& p = a.p;
-    p.b_off = b_off; p.n_sub = n_sub; p.dbg = t.dbg;
+    p.b_off = b_off; p.n_sub = n_sub; p.dbg = t.dbg; p.dbg_wg_base = 1024;
     p.Jt = m->d_Jt; p.h = m->d_h; p.idxT = st.T; p.n_pad = st.n_pad; p.grad = t.grad; p.epart = t.epart;
     p.slot = t.slot; p.n = n;
     p.g = m->g;
@@ -742,9 +742,12 @@ int ppde_energy_grad(ppde_model* m, const uint8_t* idx_dev, int n, int which, fl
             delete m->s_tfw; m->s_tfw = nullptr;
             hipFree(m->s_gradT); hipFree(m->s_tfE); m->s_gradT = m->s_tfE = nullptr;
             m->s_tfw = new TfWork();
-            if ((rc = tf_alloc_work(m->tf, m->s_tfw, n))) return rc;
-            HIPCHK(dalloc(&m->s_gradT, (size_t)n * g.N));
-            HIPCHK(dalloc(&m->s_tfE, (size_t)n));
+            if ((rc = tf_alloc_work(m->tf, m->s_tfw, n)) != PPDE_OK || dalloc(&m->s_gradT, (size_t)n * g.N) != hipSuccess ||
+                dalloc(&m->s_tfE, (size_t)n) != hipSuccess) {          // leave no half-built workspace behind
+                delete m->s_tfw; m->s_tfw = nullptr;
+                hipFree(m->s_gradT); hipFree(m->s_tfE); m->s_gradT = m->s_tfE = nullptr;
+                return rc ? rc : fail(PPDE_ERR_HIP, "device allocation failed for the transformer workspace");
+            }
         }
         t.gradT = m->s_gradT; t.tfE = m->s_tfE; t.tfw = m->s_tfw;
     }
