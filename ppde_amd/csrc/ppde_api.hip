@@ -165,9 +165,10 @@ struct EvalTargets {
     TfWork* tfw = nullptr;
 };
 
-// chain groups (of 64) per Potts workgroup. Measured at 256 / 512 / 1024 chains: 4 groups 7.1 / 11.3 / 18.7 us,
-// 2 groups 8.4 / 11.4 / 17.7, 8 groups (one workgroup per CU by LDS) 7.1 / 14.4 / 25.7.
-static int potts_ng_for(int n) { return n <= 64 ? 1 : n <= 128 ? 2 : 4; }
+// chain groups (of 64) per Potts workgroup. Measured with this round's kernel (scripts/tune_potts.py, random states):
+// 128 chains: 1 group 5.08 us, 2 groups 4.66, 4 groups 5.63; 256 chains: 7.11 / 5.96 / 6.04. Beyond that (round 1's
+// kernel, 512 / 1024 chains): 4 groups 11.3 / 18.7 us, 2 groups 11.4 / 17.7.
+static int potts_ng_for(int n) { return n <= 64 ? 1 : n <= 256 ? 2 : 4; }
 
 
 // When set, every Potts launch is bracketed by a pair of events taken from this pool (in-situ timing).

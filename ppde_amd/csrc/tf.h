@@ -150,15 +150,17 @@ __global__ __launch_bounds__(64 * NWAVE, 2) void tf_gemm_nt(TfGemmArgs g) {
                 for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j], af[i], acc[i][j], 0, 0, 0);
         }
     };
-    // the epilogue's second operand (residual / pre-activation) is requested now: fetched at the tile's end it was a
-    // dependent, scattered 8-byte load per 16 x 16 tile with nothing left to overlap (+50 % on the N = 2560 GEMMs)
-    f16x4 rpre[MT][4];
+    // the epilogue's second operand (residual / pre-activation) is requested now, as whole 256-byte rows (16 bytes per
+    // lane; turned into the accumulator layout through LDS at the end): fetched at the tile's end it was a dependent,
+    // scattered 8-byte load per 16 x 16 tile with nothing left to overlap (+50 % on the N = 2560 GEMMs)
+    constexpr int RCH = (128 * 16) / (64 * NWAVE);                    // 16-byte chunks of the 128 x 128 tile per thread
+    [[maybe_unused]] f16x8 rraw[RCH];
     if constexpr (EPI == TF_EPI_BIAS_RESID || EPI == TF_EPI_GELU_BWD) {
 #pragma unroll
-        for (int i = 0; i < MT; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                rpre[i][j] = *(const f16x4*)(g.R + (size_t)(m0 + wm * 16 * MT + i * 16 + (lane & 15)) * g.N + n0 + wn * 64 + j * 16 + 4 * (lane >> 4));
+        for (int u = 0; u < RCH; ++u) {
+            const int c = tid + u * 64 * NWAVE, row = c >> 4, ch = c & 15;
+            rraw[u] = *(const f16x8*)(g.R + (size_t)(m0 + row) * g.N + n0 + ch * 8);
+        }
     }
     // ring of STAGES buffers, tiles kt+1 .. kt+STAGES-2 stay in flight across the barrier of iteration kt
 #pragma unroll
@@ -189,6 +191,20 @@ __global__ __launch_bounds__(64 * NWAVE, 2) void tf_gemm_nt(TfGemmArgs g) {
         }
     };
     __syncthreads();                                                  // every wave is done with the operand tiles
+    [[maybe_unused]] f16x4 rpre[MT][4];
+    if constexpr (EPI == TF_EPI_BIAS_RESID || EPI == TF_EPI_GELU_BWD) {
+#pragma unroll
+        for (int u = 0; u < RCH; ++u) {
+            const int c = tid + u * 64 * NWAVE, row = c >> 4, ch = c & 15;
+            *(f16x8*)(sOut + row * OLD + ch * 8) = rraw[u];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) rpre[i][j] = *(const f16x4*)(sOut + (wm * 16 * MT + i * 16 + fr) * OLD + wn * 64 + j * 16 + 4 * fg);
+        __syncthreads();
+    }
     [[maybe_unused]] f16x4 second[MT][4];                             // BIAS_GELU: the activation, stored after the pre-activation
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
