@@ -117,7 +117,7 @@ int ppde_model_get_transformer_wt_score(ppde_model* m, float* out_host);
 int ppde_transformer_time_gemm(int device, int M, int N, int K, int reps, int epilogue, float* avg_us);
 
 /* Diagnostics for the parity tests: an fp16 activation of the last stateless evaluation that used the transformer
- * expert, converted to fp32. what: 0 layer input, 1 q|k|v, 2 attention probabilities, 3 post-attention stream,
+ * expert, converted to fp32. what: 0 layer input, 1 q|k|v, 2 (not kept: the backward rebuilds the attention probabilities), 3 post-attention stream,
  * 4 fc1 pre-activation (all of `layer`), 5 final stream, 6 logits, 7 d logits, 8 d embedding, 9 d tokens,
  * 10 / 11 attention output / d q|k|v of the layer evaluated last. */
 int ppde_debug_transformer_read(ppde_model* m, int what, int layer, float* out_host, int64_t count);

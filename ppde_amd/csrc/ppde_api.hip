@@ -532,7 +532,7 @@ int ppde_debug_transformer_read(ppde_model* m, int what, int layer, float* out_h
     switch (what) {
         case 0: src = a.xin; break;
         case 1: src = a.qkv; break;
-        case 2: src = a.P; break;
+        case 2: return fail(PPDE_ERR_INVALID, "the attention probabilities are not kept (the backward rebuilds them)");
         case 3: src = a.xmid; break;
         case 4: src = a.hpre; break;
         case 5: src = w->xlast; break;

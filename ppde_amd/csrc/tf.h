@@ -403,7 +403,8 @@ typedef __fp16 tf_hfx4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
 struct TfAttnArgs {
     const half_t* qkv;      // [M][3D]
     half_t* ctx;            // forward out [M][D]
-    half_t* P;              // [n][H][L][TF_TP] attention probabilities (fp16), kept for the backward
+    float2* stat;           // [n][H][L] (row maximum, 1 / row sum) of the softmax: the backward rebuilds the fp16
+                            // probabilities from them bit for bit instead of reading 136 MB per layer back
     const float* rope_cos;  // [L][16]
     const float* rope_sin;  // [L][16]
     const half_t* dctx;     // backward in  [M][D]
@@ -412,46 +413,74 @@ struct TfAttnArgs {
     float qscale;           // hd^-0.5 (backward: d q_lin = d q * qscale)
 };
 
-// stage rows of q or k with the rotary embedding applied: item = (t, c in {0,1}) handles dims 8c..8c+7 and their
-// partners 16+8c..; dst row-major [TF_TP][32] or transposed [32][TF_LDP]; `tid` of `nthr` threads
-template <bool TRANSPOSED>
-__device__ __forceinline__ void tf_stage_rotary(const half_t* src, int ld, int L, const float* rc, const float* rs, half_t* dst, int tid, int nthr) {
-    for (int it = tid; it < L * 2; it += nthr) {
-        const int t = it >> 1, c = it & 1;
-        const f16x8 x1 = *(const f16x8*)(src + (size_t)t * ld + 8 * c);
-        const f16x8 x2 = *(const f16x8*)(src + (size_t)t * ld + 16 + 8 * c);
-        float co[8], si[8];
-        tf_load8(rc + t * 16 + 8 * c, co);
-        tf_load8(rs + t * 16 + 8 * c, si);
+// Staging of one head's rows. Every global load of the head is issued before the first value is used (the fetch_*
+// half), then rotated / transposed into LDS (the put_* half): staged array by array, each round of dependent loads
+// cost a full memory latency with two wavefronts to hide it. Items past L write zeros, so the [TF_TP] tiles need no
+// clearing pass (the 8 pad columns of the transposed images are never read).
+//   rotary item = (t, c in {0,1}): dims 8c..8c+7 and their partners 16+8c..;  plain item = (t, c in {0..3}): dims 8c..
+constexpr int TF_ATT_NTHR = 64 * TF_ATT_WAVES;
+constexpr int TF_ROT_R = 2 * TF_TP / TF_ATT_NTHR, TF_PLAIN_R = 4 * TF_TP / TF_ATT_NTHR;
+static_assert(2 * TF_TP % TF_ATT_NTHR == 0, "whole rounds");
+struct TfRotRaw { f16x8 x1[TF_ROT_R], x2[TF_ROT_R]; };
+struct TfRope { float co[TF_ROT_R][8], si[TF_ROT_R][8]; };
+struct TfPlainRaw { f16x8 x[TF_PLAIN_R]; };
+__device__ __forceinline__ void tf_fetch_rot(const half_t* src, int ld, int L, int tid, TfRotRaw& w) {
+#pragma unroll
+    for (int r = 0; r < TF_ROT_R; ++r) {
+        const int it = tid + r * TF_ATT_NTHR, t = min(it >> 1, L - 1), c = it & 1;
+        w.x1[r] = *(const f16x8*)(src + (size_t)t * ld + 8 * c);
+        w.x2[r] = *(const f16x8*)(src + (size_t)t * ld + 16 + 8 * c);
+    }
+}
+__device__ __forceinline__ void tf_fetch_rope(const float* rc, const float* rs, int L, int tid, TfRope& w) {
+#pragma unroll
+    for (int r = 0; r < TF_ROT_R; ++r) {
+        const int it = tid + r * TF_ATT_NTHR, t = min(it >> 1, L - 1), c = it & 1;
+        tf_load8(rc + t * 16 + 8 * c, w.co[r]);
+        tf_load8(rs + t * 16 + 8 * c, w.si[r]);
+    }
+}
+template <bool ROWS, bool TRANSPOSED>
+__device__ __forceinline__ void tf_put_rot(const TfRotRaw& w, const TfRope& rp, int L, int tid, half_t* dst, half_t* dst_t) {
+#pragma unroll
+    for (int r = 0; r < TF_ROT_R; ++r) {
+        const int it = tid + r * TF_ATT_NTHR, t = it >> 1, c = it & 1;
         f16x8 y1, y2;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            y1[e] = (half_t)((float)x1[e] * co[e] - (float)x2[e] * si[e]);
-            y2[e] = (half_t)((float)x2[e] * co[e] + (float)x1[e] * si[e]);
+            y1[e] = t < L ? (half_t)((float)w.x1[r][e] * rp.co[r][e] - (float)w.x2[r][e] * rp.si[r][e]) : (half_t)0;
+            y2[e] = t < L ? (half_t)((float)w.x2[r][e] * rp.co[r][e] + (float)w.x1[r][e] * rp.si[r][e]) : (half_t)0;
         }
-        if constexpr (!TRANSPOSED) {
+        if constexpr (ROWS) {
             *(f16x8*)(dst + t * TF_HD + 8 * c) = y1;
             *(f16x8*)(dst + t * TF_HD + 16 + 8 * c) = y2;
-        } else {
+        }
+        if constexpr (TRANSPOSED) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) { dst[(8 * c + e) * TF_LDP + t] = y1[e]; dst[(16 + 8 * c + e) * TF_LDP + t] = y2[e]; }
+            for (int e = 0; e < 8; ++e) { dst_t[(8 * c + e) * TF_LDP + t] = y1[e]; dst_t[(16 + 8 * c + e) * TF_LDP + t] = y2[e]; }
         }
     }
 }
+__device__ __forceinline__ void tf_fetch_plain(const half_t* src, int ld, int L, int tid, TfPlainRaw& w) {
+#pragma unroll
+    for (int r = 0; r < TF_PLAIN_R; ++r) {
+        const int it = tid + r * TF_ATT_NTHR, t = min(it >> 2, L - 1), c = it & 3;
+        w.x[r] = *(const f16x8*)(src + (size_t)t * ld + 8 * c);
+    }
+}
 template <bool TRANSPOSED>
-__device__ __forceinline__ void tf_stage_plain(const half_t* src, int ld, int L, half_t* dst, int tid, int nthr) {
-    for (int it = tid; it < L * 4; it += nthr) {
-        const int t = it >> 2, c = it & 3;
-        const f16x8 x = *(const f16x8*)(src + (size_t)t * ld + 8 * c);
+__device__ __forceinline__ void tf_put_plain(const TfPlainRaw& w, int L, int tid, half_t* dst) {
+#pragma unroll
+    for (int r = 0; r < TF_PLAIN_R; ++r) {
+        const int it = tid + r * TF_ATT_NTHR, t = it >> 2, c = it & 3;
+        f16x8 x = w.x[r];
+        if (t >= L) x = (f16x8){0, 0, 0, 0, 0, 0, 0, 0};
         if constexpr (!TRANSPOSED) *(f16x8*)(dst + t * TF_HD + 8 * c) = x;
         else {
 #pragma unroll
             for (int e = 0; e < 8; ++e) dst[(8 * c + e) * TF_LDP + t] = x[e];
         }
     }
-}
-__device__ __forceinline__ void tf_zero_lds(half_t* p, int halfs, int tid, int nthr) {
-    for (int i = tid * 8; i < halfs; i += nthr * 8) *(f16x8*)(p + i) = (f16x8){0, 0, 0, 0, 0, 0, 0, 0};
 }
 __device__ __forceinline__ float tf_quad_rows_max(float v) { return fmaxf(fmaxf(v, __shfl_xor(v, 16)), fmaxf(__shfl_xor(v, 32), __shfl_xor(v, 48))); }
 __device__ __forceinline__ float tf_quad_rows_sum(float v) { v += __shfl_xor(v, 16); v += __shfl_xor(v, 32); return v; }
@@ -468,15 +497,22 @@ __global__ __launch_bounds__(64 * TF_ATT_WAVES) void tf_attn_fwd(TfAttnArgs a) {
     half_t* sK = sQ + TF_TP * TF_HD;
     half_t* sVt = sK + TF_TP * TF_HD;                 // [32][TF_LDP]
     const half_t* base = a.qkv + (size_t)b * L * ld + h * TF_HD;
-    tf_zero_lds(sQ, 2 * TF_TP * TF_HD + TF_HD * TF_LDP, tid, 64 * TF_ATT_WAVES);
-    __syncthreads();
-    tf_stage_rotary<false>(base, ld, L, a.rope_cos, a.rope_sin, sQ, tid, 64 * TF_ATT_WAVES);
-    tf_stage_rotary<false>(base + D, ld, L, a.rope_cos, a.rope_sin, sK, tid, 64 * TF_ATT_WAVES);
-    tf_stage_plain<true>(base + 2 * D, ld, L, sVt, tid, 64 * TF_ATT_WAVES);
+    {
+        TfRotRaw rq, rk;
+        TfRope rp;
+        TfPlainRaw rv;
+        tf_fetch_rot(base, ld, L, tid, rq);
+        tf_fetch_rot(base + D, ld, L, tid, rk);
+        tf_fetch_plain(base + 2 * D, ld, L, tid, rv);
+        tf_fetch_rope(a.rope_cos, a.rope_sin, L, tid, rp);
+        tf_put_rot<true, false>(rq, rp, L, tid, sQ, nullptr);
+        tf_put_rot<true, false>(rk, rp, L, tid, sK, nullptr);
+        tf_put_plain<true>(rv, L, tid, sVt);
+    }
     __syncthreads();
     const int fr = lane & 15, fg = lane >> 4;
     const int NQ = (L + 15) >> 4, NK = NQ;
-    half_t* Pg = a.P + ((size_t)(b * a.H + h) * L) * TF_TP;
+    float2* stat = a.stat + (size_t)(b * a.H + h) * L;
     for (int qi = wave; qi < NQ; qi += TF_ATT_WAVES) {
         const f16x8 qf = *(const f16x8*)(sQ + (qi * 16 + fr) * TF_HD + fg * 8);
         tf_f32x4 s[TF_NKT];
@@ -506,6 +542,7 @@ __global__ __launch_bounds__(64 * TF_ATT_WAVES) void tf_attn_fwd(TfAttnArgs a) {
         sum = tf_quad_rows_sum(sum);
         const float inv = 1.0f / sum;
         const int q = qi * 16 + fr;
+        if (fg == 0 && q < L) stat[q] = make_float2(mx, inv);
         tf_f32x4 o[2] = {(tf_f32x4){0.f, 0.f, 0.f, 0.f}, (tf_f32x4){0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
         for (int j = 0; j < TF_NKT; ++j)
@@ -513,7 +550,6 @@ __global__ __launch_bounds__(64 * TF_ATT_WAVES) void tf_attn_fwd(TfAttnArgs a) {
                 f16x4 p;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) p[r] = (half_t)(s[j][r] * inv);
-                if (q < L) *(f16x4*)(Pg + (size_t)q * TF_TP + j * 16 + 4 * fg) = p;
                 // ctx^T [d][query] += V^T (rows d, k = these 16 keys) x P^T (k = key on the rows: the tile as it stands)
 #pragma unroll
                 for (int dj = 0; dj < 2; ++dj) {
@@ -538,9 +574,9 @@ __global__ __launch_bounds__(64 * TF_ATT_WAVES) void tf_attn_fwd(TfAttnArgs a) {
 //   dQ, dK and the q scaling. The waves of a head take the query tiles in turn; dK and dV are summed over the waves in
 //   a fixed order at the end (wave 1's partial sums go through LDS to wave 0).
 // LDS: v rows | dO rows | dO^T | k^T (rotated) | q^T (rotated) | per wave two 16 x 16 transpose tiles
-#define TF_ATT_STAGE (2 * TF_TP * TF_HD + 3 * TF_HD * TF_LDP)
+#define TF_ATT_STAGE (4 * TF_TP * TF_HD + 3 * TF_HD * TF_LDP)
 #define TF_ATT_TRB 4                 // key tiles turned query-major per batch (two 512-byte tiles each)
-__host__ __device__ inline size_t tf_attn_bwd_lds() { return (size_t)(TF_ATT_STAGE + TF_ATT_WAVES * TF_ATT_TRB * 512) * 2; }
+__host__ __device__ inline size_t tf_attn_bwd_lds() { return (size_t)(TF_ATT_STAGE + TF_ATT_WAVES * TF_ATT_TRB * 512) * 2 + TF_TP * sizeof(float2); }
 static_assert((size_t)TF_ATT_STAGE * 2 >= (size_t)(TF_ATT_WAVES - 1) * 4 * TF_NKT * 64 * 16, "the staging area also carries the partial sums");
 
 __global__ __launch_bounds__(64 * TF_ATT_WAVES, 2) void tf_attn_bwd(TfAttnArgs a) {
@@ -553,20 +589,31 @@ __global__ __launch_bounds__(64 * TF_ATT_WAVES, 2) void tf_attn_bwd(TfAttnArgs a
     half_t* sdOt = sdO + TF_TP * TF_HD;                        // [32][LDP]
     half_t* sKt = sdOt + TF_HD * TF_LDP;                       // [32][LDP] rotated k, transposed
     half_t* sQt = sKt + TF_HD * TF_LDP;                        // [32][LDP] rotated q, transposed
-    half_t* sT = sQt + TF_HD * TF_LDP + wave * TF_ATT_TRB * 512;   // this wave's transpose tiles: TF_ATT_TRB x (dS, P) of 16 x 16
+    half_t* sK = sQt + TF_HD * TF_LDP;                         // [TP][32] rotated k
+    half_t* sQ = sK + TF_TP * TF_HD;                           // [TP][32] rotated q
+    half_t* sT = sQ + TF_TP * TF_HD + wave * TF_ATT_TRB * 512;     // this wave's transpose tiles: TF_ATT_TRB x (dS, P) of 16 x 16
+    float2* sStat = (float2*)((half_t*)tf_smem + TF_ATT_STAGE + TF_ATT_WAVES * TF_ATT_TRB * 512);   // [TP] softmax row statistics
     const half_t* base = a.qkv + (size_t)b * L * ld + h * TF_HD;
     const half_t* dob = a.dctx + (size_t)b * L * D + h * TF_HD;
-    tf_zero_lds(sV, TF_ATT_STAGE, tid, 64 * TF_ATT_WAVES);
-    __syncthreads();
-    tf_stage_plain<false>(base + 2 * D, ld, L, sV, tid, 64 * TF_ATT_WAVES);
-    tf_stage_plain<false>(dob, D, L, sdO, tid, 64 * TF_ATT_WAVES);
-    tf_stage_plain<true>(dob, D, L, sdOt, tid, 64 * TF_ATT_WAVES);
-    tf_stage_rotary<true>(base + D, ld, L, a.rope_cos, a.rope_sin, sKt, tid, 64 * TF_ATT_WAVES);
-    tf_stage_rotary<true>(base, ld, L, a.rope_cos, a.rope_sin, sQt, tid, 64 * TF_ATT_WAVES);
+    {
+        TfRotRaw rq, rk;
+        TfRope rp;
+        TfPlainRaw rv, ro;
+        tf_fetch_plain(base + 2 * D, ld, L, tid, rv);
+        tf_fetch_plain(dob, D, L, tid, ro);
+        tf_fetch_rot(base + D, ld, L, tid, rk);
+        tf_fetch_rot(base, ld, L, tid, rq);
+        tf_fetch_rope(a.rope_cos, a.rope_sin, L, tid, rp);
+        tf_put_plain<false>(rv, L, tid, sV);
+        tf_put_plain<false>(ro, L, tid, sdO);
+        tf_put_plain<true>(ro, L, tid, sdOt);
+        tf_put_rot<true, true>(rk, rp, L, tid, sK, sKt);
+        tf_put_rot<true, true>(rq, rp, L, tid, sQ, sQt);
+        for (int t = tid; t < TF_TP; t += TF_ATT_NTHR) sStat[t] = t < L ? a.stat[(size_t)(b * a.H + h) * L + t] : make_float2(0.f, 0.f);
+    }
     __syncthreads();
     const int fr = lane & 15, fg = lane >> 4;
     const int NQ = (L + 15) >> 4, NK = NQ;
-    const half_t* Pg = a.P + ((size_t)(b * a.H + h) * L) * TF_TP;
     tf_f32x4 accK[2][TF_NKT], accV[2][TF_NKT];
 #pragma unroll
     for (int dj = 0; dj < 2; ++dj)
@@ -580,6 +627,8 @@ __global__ __launch_bounds__(64 * TF_ATT_WAVES, 2) void tf_attn_bwd(TfAttnArgs a
     for (int qi = wave; qi < NQ; qi += TF_ATT_WAVES) {
         const int q = qi * 16 + fr;
         const f16x8 dof = *(const f16x8*)(sdO + (qi * 16 + fr) * TF_HD + fg * 8);
+        const f16x8 qf = *(const f16x8*)(sQ + (qi * 16 + fr) * TF_HD + fg * 8);
+        const float2 st = sStat[qi * 16 + fr];
         tf_f32x4 dp[TF_NKT];
         f16x4 pt[TF_NKT], ds[TF_NKT];
         float delta = 0.f;
@@ -589,10 +638,18 @@ __global__ __launch_bounds__(64 * TF_ATT_WAVES, 2) void tf_attn_bwd(TfAttnArgs a
             pt[j] = (f16x4){0, 0, 0, 0};
             if (j < NK) {
                 const f16x8 vf = *(const f16x8*)(sV + (j * 16 + fr) * TF_HD + fg * 8);
+                const f16x8 kf = *(const f16x8*)(sK + (j * 16 + fr) * TF_HD + fg * 8);
                 dp[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, dof, dp[j], 0, 0, 0);   // [key][query]
-                if (q < L) pt[j] = *(const f16x4*)(Pg + (size_t)q * TF_TP + j * 16 + 4 * fg);
+                // the probabilities again, exactly as the forward rounded them: same product, same exponential, same scale
+                const tf_f32x4 sc = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf, (tf_f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) { dp[j][r] = (float)(half_t)dp[j][r]; delta += dp[j][r] * (float)pt[j][r]; }
+                for (int r = 0; r < 4; ++r) {
+                    const int key = j * 16 + 4 * fg + r;
+                    const float sv = key < L ? (float)(half_t)sc[r] : -INFINITY;
+                    pt[j][r] = (half_t)(__expf(sv - st.x) * st.y);
+                    dp[j][r] = (float)(half_t)dp[j][r];
+                    delta += dp[j][r] * (float)pt[j][r];
+                }
             }
         }
         delta = tf_quad_rows_sum(delta);

@@ -22,7 +22,8 @@ struct TfModel {
 };
 
 struct TfLayerAct {
-    half_t *xin = nullptr, *qkv = nullptr, *P = nullptr, *xmid = nullptr, *hpre = nullptr;
+    half_t *xin = nullptr, *qkv = nullptr, *xmid = nullptr, *hpre = nullptr;
+    float2* stat = nullptr;          // softmax row statistics [n][H][L]
     float *mean1 = nullptr, *rstd1 = nullptr, *mean2 = nullptr, *rstd2 = nullptr;
 };
 struct TfWork {
@@ -138,7 +139,7 @@ static int tf_alloc_work(const TfModel* t, TfWork* wk, int n) {
     };
     wk->act.resize(t->layers);
     for (auto& a : wk->act) {
-        A(&a.xin, (size_t)Mp * D); A(&a.qkv, (size_t)Mp * 3 * D); A(&a.P, (size_t)n * t->H * L * TF_TP);
+        A(&a.xin, (size_t)Mp * D); A(&a.qkv, (size_t)Mp * 3 * D); A(&a.stat, (size_t)n * t->H * L);
         A(&a.xmid, (size_t)Mp * D); A(&a.hpre, (size_t)Mp * F);
         A(&a.mean1, (size_t)Mp); A(&a.rstd1, (size_t)Mp); A(&a.mean2, (size_t)Mp); A(&a.rstd2, (size_t)Mp);
     }
@@ -219,7 +220,7 @@ static int tf_eval(const TfModel* t, TfWork* wk, const uint8_t* rows, int Ls, in
         half_t* xnext = l + 1 < t->layers ? wk->act[l + 1].xin : wk->xlast;
         TFRC(tf_ln(s, false, a.xin, wk->ln_out, w.ln1g, w.ln1b, a.mean1, a.rstd1, M, D));
         TFRC(tf_gemm<TF_EPI_BIAS_QSCALE>(s, wk->ln_out, w.Wqkv, a.qkv, Mp, 3 * D, D, w.bqkv, nullptr, nullptr, qs, D));
-        TfAttnArgs at{a.qkv, wk->ctx, a.P, t->rope_cos, t->rope_sin, nullptr, nullptr, n, L, H, D, qs};
+        TfAttnArgs at{a.qkv, wk->ctx, a.stat, t->rope_cos, t->rope_sin, nullptr, nullptr, n, L, H, D, qs};
         hipLaunchKernelGGL(tf_attn_fwd, dim3(n * H), dim3(64 * TF_ATT_WAVES), tf_attn_fwd_lds(), s, at);
         HIPCHK(hipGetLastError());
         TFRC(tf_gemm<TF_EPI_BIAS_RESID>(s, wk->ctx, w.Wo, a.xmid, Mp, D, D, w.bo, a.xin));
@@ -253,7 +254,7 @@ static int tf_eval(const TfModel* t, TfWork* wk, const uint8_t* rows, int Ls, in
         TFRC(tf_gemm<TF_EPI_PLAIN>(s, wk->dF, w.W1T, wk->tmpD, Mp, D, F));
         TFRC(tf_ln(s, true, a.xmid, wk->gB, w.ln2g, w.ln2b, a.mean2, a.rstd2, M, D, wk->tmpD, wk->gA));
         TFRC(tf_gemm<TF_EPI_PLAIN>(s, wk->gB, w.WoT, wk->tmpD, Mp, D, D));
-        TfAttnArgs at{a.qkv, nullptr, a.P, t->rope_cos, t->rope_sin, wk->tmpD, wk->dqkv, n, L, H, D, qs};
+        TfAttnArgs at{a.qkv, nullptr, a.stat, t->rope_cos, t->rope_sin, wk->tmpD, wk->dqkv, n, L, H, D, qs};
         hipLaunchKernelGGL(tf_attn_bwd, dim3(n * H), dim3(64 * TF_ATT_WAVES), tf_attn_bwd_lds(), s, at);
         HIPCHK(hipGetLastError());
         TFRC(tf_gemm<TF_EPI_PLAIN>(s, wk->dqkv, w.WqkvT, wk->tmpD, Mp, D, 3 * D));
