@@ -458,7 +458,6 @@ int ppde_model_set_transformer(ppde_model* m, int n_layers, int dim, int heads, 
     ARGCHK(m && w, "null argument");
     ARGCHK(n_layers >= 1 && n_layers <= 64, "1..64 transformer layers");
     ARGCHK(heads >= 1 && dim == heads * TF_HD, "the attention kernels are written for head width 32 (ESM-2 150M: 640 / 20)");
-    ARGCHK(heads % TF_ATT_WAVES == 0, "head count must be even");
     ARGCHK(dim % 128 == 0 && ffn % 128 == 0 && dim <= 2 * 64 * TF_LN_MAXP, "dim and ffn must be multiples of 128, dim <= 1024");
     ARGCHK(m->L <= TF_TP, "the transformer expert handles sequences of up to 128 residues");
     HIPCHK(hipSetDevice(m->device));

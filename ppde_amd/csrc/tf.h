@@ -385,7 +385,7 @@ __global__ void tf_embed(const uint8_t* __restrict__ idx, int Ls, int sh, int L,
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// Attention: one workgroup of TF_ATT_WAVES wavefronts per (chain, head); the waves share the head's staged q, k, v and
+// Attention: one workgroup of TF_ATT_WAVES_F / _B wavefronts per (chain, head); the waves share the head's staged q, k, v and
 // take the 16-query tiles in turn. qkv [M][3D] as the projection wrote it (q already scaled); the rotary embedding is
 // applied while staging q and k.
 // Orientation: every score tile is computed as S^T = K Q^T (v_mfma 16x16x32, k = head width), so a lane holds 4
@@ -394,7 +394,8 @@ __global__ void tf_embed(const uint8_t* __restrict__ idx, int Ls, int sh, int L,
 // round trip. Products that contract over the QUERY (dK, dV) take the tile through one 512-byte LDS tile and the
 // transposed read ds_read_b64_tr_b16 (lane maps of both instructions: scripts/probes/mfma_probe.hip).
 // ------------------------------------------------------------------------------------------------------------
-#define TF_ATT_WAVES 2
+#define TF_ATT_WAVES_F 4           // wavefronts per (chain, head) in the forward ...
+#define TF_ATT_WAVES_B 4           // ... and in the backward (a power of two: the partial dK, dV are summed in a tree)
 #define TF_TP 128                 // padded sequence length the attention kernels are written for (L <= 128)
 #define TF_NKT 8                  // key tiles of 16
 #define TF_LDP (TF_TP + 8)        // padded row length (halfs) of the transposed LDS images
@@ -418,33 +419,32 @@ struct TfAttnArgs {
 // cost a full memory latency with two wavefronts to hide it. Items past L write zeros, so the [TF_TP] tiles need no
 // clearing pass (the 8 pad columns of the transposed images are never read).
 //   rotary item = (t, c in {0,1}): dims 8c..8c+7 and their partners 16+8c..;  plain item = (t, c in {0..3}): dims 8c..
-constexpr int TF_ATT_NTHR = 64 * TF_ATT_WAVES;
-constexpr int TF_ROT_R = 2 * TF_TP / TF_ATT_NTHR, TF_PLAIN_R = 4 * TF_TP / TF_ATT_NTHR;
-static_assert(2 * TF_TP % TF_ATT_NTHR == 0, "whole rounds");
-struct TfRotRaw { f16x8 x1[TF_ROT_R], x2[TF_ROT_R]; };
-struct TfRope { float co[TF_ROT_R][8], si[TF_ROT_R][8]; };
-struct TfPlainRaw { f16x8 x[TF_PLAIN_R]; };
-__device__ __forceinline__ void tf_fetch_rot(const half_t* src, int ld, int L, int tid, TfRotRaw& w) {
+template <int NTHR> struct TfRotRaw { static constexpr int R = 2 * TF_TP / NTHR; f16x8 x1[R], x2[R]; static_assert(2 * TF_TP % NTHR == 0, "whole rounds"); };
+template <int NTHR> struct TfRope { static constexpr int R = 2 * TF_TP / NTHR; float co[R][8], si[R][8]; };
+template <int NTHR> struct TfPlainRaw { static constexpr int R = 4 * TF_TP / NTHR; f16x8 x[R]; };
+template <int NTHR>
+__device__ __forceinline__ void tf_fetch_rot(const half_t* src, int ld, int L, int tid, TfRotRaw<NTHR>& w) {
 #pragma unroll
-    for (int r = 0; r < TF_ROT_R; ++r) {
-        const int it = tid + r * TF_ATT_NTHR, t = min(it >> 1, L - 1), c = it & 1;
+    for (int r = 0; r < 2 * TF_TP / NTHR; ++r) {
+        const int it = tid + r * NTHR, t = min(it >> 1, L - 1), c = it & 1;
         w.x1[r] = *(const f16x8*)(src + (size_t)t * ld + 8 * c);
         w.x2[r] = *(const f16x8*)(src + (size_t)t * ld + 16 + 8 * c);
     }
 }
-__device__ __forceinline__ void tf_fetch_rope(const float* rc, const float* rs, int L, int tid, TfRope& w) {
+template <int NTHR>
+__device__ __forceinline__ void tf_fetch_rope(const float* rc, const float* rs, int L, int tid, TfRope<NTHR>& w) {
 #pragma unroll
-    for (int r = 0; r < TF_ROT_R; ++r) {
-        const int it = tid + r * TF_ATT_NTHR, t = min(it >> 1, L - 1), c = it & 1;
+    for (int r = 0; r < 2 * TF_TP / NTHR; ++r) {
+        const int it = tid + r * NTHR, t = min(it >> 1, L - 1), c = it & 1;
         tf_load8(rc + t * 16 + 8 * c, w.co[r]);
         tf_load8(rs + t * 16 + 8 * c, w.si[r]);
     }
 }
-template <bool ROWS, bool TRANSPOSED>
-__device__ __forceinline__ void tf_put_rot(const TfRotRaw& w, const TfRope& rp, int L, int tid, half_t* dst, half_t* dst_t) {
+template <bool ROWS, bool TRANSPOSED, int NTHR>
+__device__ __forceinline__ void tf_put_rot(const TfRotRaw<NTHR>& w, const TfRope<NTHR>& rp, int L, int tid, half_t* dst, half_t* dst_t) {
 #pragma unroll
-    for (int r = 0; r < TF_ROT_R; ++r) {
-        const int it = tid + r * TF_ATT_NTHR, t = it >> 1, c = it & 1;
+    for (int r = 0; r < 2 * TF_TP / NTHR; ++r) {
+        const int it = tid + r * NTHR, t = it >> 1, c = it & 1;
         f16x8 y1, y2;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
@@ -461,18 +461,19 @@ __device__ __forceinline__ void tf_put_rot(const TfRotRaw& w, const TfRope& rp, 
         }
     }
 }
-__device__ __forceinline__ void tf_fetch_plain(const half_t* src, int ld, int L, int tid, TfPlainRaw& w) {
+template <int NTHR>
+__device__ __forceinline__ void tf_fetch_plain(const half_t* src, int ld, int L, int tid, TfPlainRaw<NTHR>& w) {
 #pragma unroll
-    for (int r = 0; r < TF_PLAIN_R; ++r) {
-        const int it = tid + r * TF_ATT_NTHR, t = min(it >> 2, L - 1), c = it & 3;
+    for (int r = 0; r < 4 * TF_TP / NTHR; ++r) {
+        const int it = tid + r * NTHR, t = min(it >> 2, L - 1), c = it & 3;
         w.x[r] = *(const f16x8*)(src + (size_t)t * ld + 8 * c);
     }
 }
-template <bool TRANSPOSED>
-__device__ __forceinline__ void tf_put_plain(const TfPlainRaw& w, int L, int tid, half_t* dst) {
+template <bool TRANSPOSED, int NTHR>
+__device__ __forceinline__ void tf_put_plain(const TfPlainRaw<NTHR>& w, int L, int tid, half_t* dst) {
 #pragma unroll
-    for (int r = 0; r < TF_PLAIN_R; ++r) {
-        const int it = tid + r * TF_ATT_NTHR, t = it >> 2, c = it & 3;
+    for (int r = 0; r < 4 * TF_TP / NTHR; ++r) {
+        const int it = tid + r * NTHR, t = it >> 2, c = it & 3;
         f16x8 x = w.x[r];
         if (t >= L) x = (f16x8){0, 0, 0, 0, 0, 0, 0, 0};
         if constexpr (!TRANSPOSED) *(f16x8*)(dst + t * TF_HD + 8 * c) = x;
@@ -486,9 +487,9 @@ __device__ __forceinline__ float tf_quad_rows_max(float v) { return fmaxf(fmaxf(
 __device__ __forceinline__ float tf_quad_rows_sum(float v) { v += __shfl_xor(v, 16); v += __shfl_xor(v, 32); return v; }
 
 // LDS: q rows [TP][32] | k rows [TP][32] | v transposed [32][LDP]
-__host__ __device__ inline size_t tf_attn_fwd_lds() { return (size_t)(2 * TF_TP * TF_HD + TF_HD * TF_LDP) * 2; }
+__host__ __device__ constexpr size_t tf_attn_fwd_lds() { return (size_t)(2 * TF_TP * TF_HD + TF_HD * TF_LDP) * 2; }
 
-__global__ __launch_bounds__(64 * TF_ATT_WAVES) void tf_attn_fwd(TfAttnArgs a) {
+__global__ __launch_bounds__(64 * TF_ATT_WAVES_F) void tf_attn_fwd(TfAttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char tf_smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.x / a.H, h = blockIdx.x % a.H;
@@ -498,9 +499,10 @@ __global__ __launch_bounds__(64 * TF_ATT_WAVES) void tf_attn_fwd(TfAttnArgs a) {
     half_t* sVt = sK + TF_TP * TF_HD;                 // [32][TF_LDP]
     const half_t* base = a.qkv + (size_t)b * L * ld + h * TF_HD;
     {
-        TfRotRaw rq, rk;
-        TfRope rp;
-        TfPlainRaw rv;
+        constexpr int NT = 64 * TF_ATT_WAVES_F;
+        TfRotRaw<NT> rq, rk;
+        TfRope<NT> rp;
+        TfPlainRaw<NT> rv;
         tf_fetch_rot(base, ld, L, tid, rq);
         tf_fetch_rot(base + D, ld, L, tid, rk);
         tf_fetch_plain(base + 2 * D, ld, L, tid, rv);
@@ -513,7 +515,7 @@ __global__ __launch_bounds__(64 * TF_ATT_WAVES) void tf_attn_fwd(TfAttnArgs a) {
     const int fr = lane & 15, fg = lane >> 4;
     const int NQ = (L + 15) >> 4, NK = NQ;
     float2* stat = a.stat + (size_t)(b * a.H + h) * L;
-    for (int qi = wave; qi < NQ; qi += TF_ATT_WAVES) {
+    for (int qi = wave; qi < NQ; qi += TF_ATT_WAVES_F) {
         const f16x8 qf = *(const f16x8*)(sQ + (qi * 16 + fr) * TF_HD + fg * 8);
         tf_f32x4 s[TF_NKT];
         float mx = -INFINITY;
@@ -576,10 +578,70 @@ __global__ __launch_bounds__(64 * TF_ATT_WAVES) void tf_attn_fwd(TfAttnArgs a) {
 // LDS: v rows | dO rows | dO^T | k^T (rotated) | q^T (rotated) | per wave two 16 x 16 transpose tiles
 #define TF_ATT_STAGE (4 * TF_TP * TF_HD + 3 * TF_HD * TF_LDP)
 #define TF_ATT_TRB 4                 // key tiles turned query-major per batch (two 512-byte tiles each)
-__host__ __device__ inline size_t tf_attn_bwd_lds() { return (size_t)(TF_ATT_STAGE + TF_ATT_WAVES * TF_ATT_TRB * 512) * 2 + TF_TP * sizeof(float2); }
-static_assert((size_t)TF_ATT_STAGE * 2 >= (size_t)(TF_ATT_WAVES - 1) * 4 * TF_NKT * 64 * 16, "the staging area also carries the partial sums");
+__host__ __device__ constexpr size_t tf_attn_bwd_lds() { return (size_t)(TF_ATT_STAGE + TF_ATT_WAVES_B * TF_ATT_TRB * 512) * 2 + TF_TP * sizeof(float2); }
+#define TF_ATT_PART (4 * TF_NKT * 64)     // f32x4 elements of one wave's partial dK^T, dV^T
+static_assert(tf_attn_bwd_lds() >= (size_t)TF_ATT_WAVES_B * (TF_ATT_PART / 2) * 16, "the LDS image also carries the partial sums being swapped");
 
-__global__ __launch_bounds__(64 * TF_ATT_WAVES, 2) void tf_attn_bwd(TfAttnArgs a) {
+// tiles J0 .. J0 + NJ - 1 of a wave's partial sums to / from its LDS slot
+template <int J0, int NJ>
+__device__ __forceinline__ void tf_part_store(tf_f32x4* dst, const tf_f32x4 (&accK)[2][TF_NKT], const tf_f32x4 (&accV)[2][TF_NKT], int lane) {
+#pragma unroll
+    for (int dj = 0; dj < 2; ++dj)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) { dst[((dj * NJ + j) * 2 + 0) * 64 + lane] = accK[dj][J0 + j]; dst[((dj * NJ + j) * 2 + 1) * 64 + lane] = accV[dj][J0 + j]; }
+}
+template <int J0, int NJ>
+__device__ __forceinline__ void tf_part_add(const tf_f32x4* src, tf_f32x4 (&accK)[2][TF_NKT], tf_f32x4 (&accV)[2][TF_NKT], int lane) {
+#pragma unroll
+    for (int dj = 0; dj < 2; ++dj)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const tf_f32x4 k = src[((dj * NJ + j) * 2 + 0) * 64 + lane], v = src[((dj * NJ + j) * 2 + 1) * 64 + lane];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { accK[dj][J0 + j][r] += k[r]; accV[dj][J0 + j][r] += v[r]; }
+        }
+}
+// wave = 2 HI + LO of four: round 1 swaps with wave ^ 2 (keeps key tiles 4 HI .. 4 HI + 3), round 2 with wave ^ 1
+// (keeps 4 HI + 2 LO, + 1), then the rotary transpose on dK and the stores of the two tiles kept
+template <int HI, int LO>
+__device__ __forceinline__ void tf_attn_finish(tf_f32x4* red, tf_f32x4 (&accK)[2][TF_NKT], tf_f32x4 (&accV)[2][TF_NKT], const TfAttnArgs& a,
+                                               half_t* dq_out, int ld, int D, int L, int NK, int lane) {
+    static_assert(TF_ATT_WAVES_B == 4 && TF_NKT == 8, "two rounds of halving");
+    constexpr int W = 2 * HI + LO, SLOT1 = 4 * 4 * 64, SLOT2 = 2 * 4 * 64;       // f32x4 elements per wave and round
+    tf_part_store<4 * (1 - HI), 4>(red + W * SLOT1, accK, accV, lane);
+    __syncthreads();
+    tf_part_add<4 * HI, 4>(red + (W ^ 2) * SLOT1, accK, accV, lane);
+    __syncthreads();
+    tf_part_store<4 * HI + 2 * (1 - LO), 2>(red + W * SLOT2, accK, accV, lane);
+    __syncthreads();
+    tf_part_add<4 * HI + 2 * LO, 2>(red + (W ^ 1) * SLOT2, accK, accV, lane);
+    const int fr = lane & 15, fg = lane >> 4;
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) {
+        constexpr int JB = 4 * HI + 2 * LO;
+        const int j = JB + jj, key = j * 16 + fr;
+        if (j < NK && key < L) {
+            f16x4 k1, k2, v1, v2;
+            float co[4], si[4];
+            *(float4*)co = *(const float4*)(a.rope_cos + key * 16 + 4 * fg);
+            *(float4*)si = *(const float4*)(a.rope_sin + key * 16 + 4 * fg);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float y1 = (float)(half_t)accK[0][JB + jj][r], y2 = (float)(half_t)accK[1][JB + jj][r];
+                k1[r] = (half_t)(y1 * co[r] + y2 * si[r]);
+                k2[r] = (half_t)(y2 * co[r] - y1 * si[r]);
+                v1[r] = (half_t)accV[0][JB + jj][r];
+                v2[r] = (half_t)accV[1][JB + jj][r];
+            }
+            *(f16x4*)(dq_out + (size_t)key * ld + D + 4 * fg) = k1;
+            *(f16x4*)(dq_out + (size_t)key * ld + D + 16 + 4 * fg) = k2;
+            *(f16x4*)(dq_out + (size_t)key * ld + 2 * D + 4 * fg) = v1;
+            *(f16x4*)(dq_out + (size_t)key * ld + 2 * D + 16 + 4 * fg) = v2;
+        }
+    }
+}
+
+__global__ __launch_bounds__(64 * TF_ATT_WAVES_B, 2) void tf_attn_bwd(TfAttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char tf_smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.x / a.H, h = blockIdx.x % a.H;
@@ -592,13 +654,14 @@ __global__ __launch_bounds__(64 * TF_ATT_WAVES, 2) void tf_attn_bwd(TfAttnArgs a
     half_t* sK = sQt + TF_HD * TF_LDP;                         // [TP][32] rotated k
     half_t* sQ = sK + TF_TP * TF_HD;                           // [TP][32] rotated q
     half_t* sT = sQ + TF_TP * TF_HD + wave * TF_ATT_TRB * 512;     // this wave's transpose tiles: TF_ATT_TRB x (dS, P) of 16 x 16
-    float2* sStat = (float2*)((half_t*)tf_smem + TF_ATT_STAGE + TF_ATT_WAVES * TF_ATT_TRB * 512);   // [TP] softmax row statistics
+    float2* sStat = (float2*)((half_t*)tf_smem + TF_ATT_STAGE + TF_ATT_WAVES_B * TF_ATT_TRB * 512);   // [TP] softmax row statistics
     const half_t* base = a.qkv + (size_t)b * L * ld + h * TF_HD;
     const half_t* dob = a.dctx + (size_t)b * L * D + h * TF_HD;
     {
-        TfRotRaw rq, rk;
-        TfRope rp;
-        TfPlainRaw rv, ro;
+        constexpr int NT = 64 * TF_ATT_WAVES_B;
+        TfRotRaw<NT> rq, rk;
+        TfRope<NT> rp;
+        TfPlainRaw<NT> rv, ro;
         tf_fetch_plain(base + 2 * D, ld, L, tid, rv);
         tf_fetch_plain(dob, D, L, tid, ro);
         tf_fetch_rot(base + D, ld, L, tid, rk);
@@ -609,7 +672,7 @@ __global__ __launch_bounds__(64 * TF_ATT_WAVES, 2) void tf_attn_bwd(TfAttnArgs a
         tf_put_plain<true>(ro, L, tid, sdOt);
         tf_put_rot<true, true>(rk, rp, L, tid, sK, sKt);
         tf_put_rot<true, true>(rq, rp, L, tid, sQ, sQt);
-        for (int t = tid; t < TF_TP; t += TF_ATT_NTHR) sStat[t] = t < L ? a.stat[(size_t)(b * a.H + h) * L + t] : make_float2(0.f, 0.f);
+        for (int t = tid; t < TF_TP; t += 64 * TF_ATT_WAVES_B) sStat[t] = t < L ? a.stat[(size_t)(b * a.H + h) * L + t] : make_float2(0.f, 0.f);
     }
     __syncthreads();
     const int fr = lane & 15, fg = lane >> 4;
@@ -624,7 +687,7 @@ __global__ __launch_bounds__(64 * TF_ATT_WAVES, 2) void tf_attn_bwd(TfAttnArgs a
     // column fr of rows 4 fg .. 4 fg + 3
     typedef __attribute__((address_space(3))) tf_hfx4* lds_tr_ptr;
     const int tr_off = (4 * fg + (fr >> 2)) * 16 + 4 * (fr & 3);
-    for (int qi = wave; qi < NQ; qi += TF_ATT_WAVES) {
+    for (int qi = wave; qi < NQ; qi += TF_ATT_WAVES_B) {
         const int q = qi * 16 + fr;
         const f16x8 dof = *(const f16x8*)(sdO + (qi * 16 + fr) * TF_HD + fg * 8);
         const f16x8 qf = *(const f16x8*)(sQ + (qi * 16 + fr) * TF_HD + fg * 8);
@@ -713,49 +776,16 @@ __global__ __launch_bounds__(64 * TF_ATT_WAVES, 2) void tf_attn_bwd(TfAttnArgs a
                 }
         }
     }
-    // ---- sum the waves' partial dK^T, dV^T in wave order (wave 0 + wave 1 + ...), through the staging area
+    // ---- sum the waves' partial dK^T, dV^T as (w0 + w2) + (w1 + w3), scattered: partners swap the halves they do
+    // not keep, so each wave ends up owning two key tiles and writes them out itself (summed into one wave, the other
+    // three idled through a 128-register add and the store of all eight tiles while the workgroup held its LDS)
     __syncthreads();
     tf_f32x4* red = (tf_f32x4*)tf_smem;
-    for (int w = 1; w < TF_ATT_WAVES; ++w) {
-        if (wave == w) {
-#pragma unroll
-            for (int dj = 0; dj < 2; ++dj)
-#pragma unroll
-                for (int j = 0; j < TF_NKT; ++j) { red[((dj * TF_NKT + j) * 2 + 0) * 64 + lane] = accK[dj][j]; red[((dj * TF_NKT + j) * 2 + 1) * 64 + lane] = accV[dj][j]; }
-        }
-        __syncthreads();
-        if (wave == 0) {
-#pragma unroll
-            for (int dj = 0; dj < 2; ++dj)
-#pragma unroll
-                for (int j = 0; j < TF_NKT; ++j) {
-                    const tf_f32x4 k = red[((dj * TF_NKT + j) * 2 + 0) * 64 + lane], v = red[((dj * TF_NKT + j) * 2 + 1) * 64 + lane];
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) { accK[dj][j][r] += k[r]; accV[dj][j][r] += v[r]; }
-                }
-        }
-        __syncthreads();
-    }
-    if (wave != 0) return;
-#pragma unroll
-    for (int j = 0; j < TF_NKT; ++j) {
-        const int key = j * 16 + fr;
-        if (j < NK && key < L) {
-            f16x4 k1, k2, v1, v2;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float co = a.rope_cos[key * 16 + 4 * fg + r], si = a.rope_sin[key * 16 + 4 * fg + r];
-                const float y1 = (float)(half_t)accK[0][j][r], y2 = (float)(half_t)accK[1][j][r];
-                k1[r] = (half_t)(y1 * co + y2 * si);
-                k2[r] = (half_t)(y2 * co - y1 * si);
-                v1[r] = (half_t)accV[0][j][r];
-                v2[r] = (half_t)accV[1][j][r];
-            }
-            *(f16x4*)(dq_out + (size_t)key * ld + D + 4 * fg) = k1;
-            *(f16x4*)(dq_out + (size_t)key * ld + D + 16 + 4 * fg) = k2;
-            *(f16x4*)(dq_out + (size_t)key * ld + 2 * D + 4 * fg) = v1;
-            *(f16x4*)(dq_out + (size_t)key * ld + 2 * D + 16 + 4 * fg) = v2;
-        }
+    switch (wave) {
+        case 0: tf_attn_finish<0, 0>(red, accK, accV, a, dq_out, ld, D, L, NK, lane); break;
+        case 1: tf_attn_finish<0, 1>(red, accK, accV, a, dq_out, ld, D, L, NK, lane); break;
+        case 2: tf_attn_finish<1, 0>(red, accK, accV, a, dq_out, ld, D, L, NK, lane); break;
+        default: tf_attn_finish<1, 1>(red, accK, accV, a, dq_out, ld, D, L, NK, lane); break;
     }
 }
 
