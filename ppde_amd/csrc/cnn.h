@@ -403,11 +403,11 @@ __device__ __forceinline__ void cnn_body(const CnnArgs& a, const int bx, const i
     PPDE_WG_STAMP(a.dbg, wg_lin, 3);
 }
 
-template <int RT, int KT>
-__global__ __launch_bounds__(256, 2) void k_cnn(CnnArgs a) {
+template <int RT, int KT, int NT = 256>
+__global__ __launch_bounds__(NT, 2) void k_cnn(CnnArgs a) {
     warm_kernargs<sizeof(CnnArgs)>();
     extern __shared__ unsigned char smem_raw[];
-    cnn_body<RT, KT, 256>(a, blockIdx.x, blockIdx.y, gridDim.x, gridDim.y, smem_raw);
+    cnn_body<RT, KT, NT>(a, blockIdx.x, blockIdx.y, gridDim.x, gridDim.y, smem_raw);
 }
 // =====================================================================================================
 // Long sequences (the [T x C] activations of one chain do not fit LDS next to the routed gradient, e.g. GFP,

@@ -278,8 +278,10 @@ static int launch_cnn(const ppde_model* m, const States& st, int n, const EvalTa
     }
     size_t lds = cnn_lds_bytes(m->T, m->CP, m->FP, m->J, m->L);
     const dim3 grid(n_sub, m->n_nets);
+    static const int cnn_threads = []() { const char* e = getenv("PPDE_CNN_WAVES"); return e && atoi(e) == 8 ? 512 : 256; }();
 #define PPDE_CNN(RTV)                                                                           \
-    if (m->KT == 5) hipLaunchKernelGGL((k_cnn<RTV, 5>), grid, dim3(256), lds, s, a);              \
+    if (m->KT == 5 && cnn_threads == 512) hipLaunchKernelGGL((k_cnn<RTV, 5, 512>), grid, dim3(512), lds, s, a);   \
+    else if (m->KT == 5) hipLaunchKernelGGL((k_cnn<RTV, 5>), grid, dim3(256), lds, s, a);         \
     else hipLaunchKernelGGL((k_cnn<RTV, CNN_MAX_K>), grid, dim3(256), lds, s, a);
     switch (cnn_rows(m->T) / 16) {
         case 1: PPDE_CNN(1) break;

@@ -204,3 +204,15 @@ def test_bench_launches_its_own_ranks(monkeypatch):
     r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2"], capture_output=True, text=True,
                        env=dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0"), timeout=300)
     assert r.returncode != 0 and "WORLD_SIZE=1" in (r.stdout + r.stderr)
+
+
+def test_host_layer_under_address_sanitizer():
+    """The host side of the C ABI (no device code) against a mock HIP runtime under ASan + LSan: the whole call
+    sequence with all three experts, then once more per fallible runtime call with that call failing, so that every
+    clean-up path runs (tests/hostcheck/). Any leak or out-of-bounds copy fails the run."""
+    script = os.path.join(os.path.dirname(os.path.abspath(__file__)), "hostcheck", "build_and_run.sh")
+    r = subprocess.run(["bash", script, "sweep"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    m = re.search(r"hostcheck ok: (\d+) fallible runtime calls per sequence, (\d+) injected failures handled", r.stdout)
+    assert m and int(m.group(1)) > 100 and m.group(1) == m.group(2), r.stdout
+    assert "AddressSanitizer" not in r.stderr and "LeakSanitizer" not in r.stderr, r.stderr[-4000:]
