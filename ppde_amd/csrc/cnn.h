@@ -30,6 +30,8 @@ struct CnnNet {
 struct CnnArgs {
     CnnNet net[4];
     int n_nets;
+    int n_parts;                // output rows per chain: n_nets, or n_nets + 1 when the LAST network's features are cut in two
+                                // workgroups (parts n_nets - 1 and n_nets; the consumers add the parts up in order)
     int C, CP, K, KT, F, FP, T, J, JP;  // KT = taps the tables hold (K or CNN_MAX_K); J = KT*20; FP / JP rounded up to 16
     const uint8_t* idx;             // states [n][Ls]
     float* gradC;                   // [slots][nets][n][N]
@@ -206,20 +208,29 @@ __device__ __forceinline__ void cnn_route_rows(const CnnNet& net, const int rows
 }
 
 // Body of one workgroup = (chain bx of the launch, network ni); shared by k_cnn and the fused experts launch.
-// NT = threads per workgroup (256 in every shipped instantiation; the body does not depend on it).
-template <int RT, int KT, int NT = 256>
+// NT = threads per workgroup. The single-launch kernels ship with 512 (eight waves, two per SIMD: PABP step 106.2 -> 102.6 us
+// against four waves, unfused launches): the gather, list and route phases are latency-bound and gain from the second wave
+// per SIMD; the contractions are bound by the matrix pipe either way.
+#define CNN_NT 512
+template <int RT, int KT, int NT = CNN_NT>
 __device__ __forceinline__ void cnn_body(const CnnArgs& a, const int bx, const int ni, const int n_bx, const int n_ni,
                                          unsigned char* smem_raw) {
     const Geom g = a.g;
     const int b = a.b_off + bx, tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const CnnNet net = a.net[ni];
+    const int part = ni;                                            // output row; the network it belongs to:
+    const CnnNet net = a.net[min(part, a.n_nets - 1)];
     const int T = a.T, CP = a.CP, F = a.F, FP = a.FP, J = a.J, JP = a.JP;
     const int AS = cnn_astride(CP);
     const int rows = RT * 16;
     const int KSP = CP / 4;                                         // CP is padded to a multiple of 4*CNN_KB
     const int OS = J;
     const int BW = (CP + 31) / 32;                                  // gate words per row
+    // feature tiles of this workgroup: all of them, or one half of the split network's (a half does the whole convolution
+    // and both halves' gradients add up: every step after the arg-max is linear in the routed features)
+    const bool halved = a.n_parts > a.n_nets && part >= a.n_nets - 1;
+    const int FT = FP / 16, ct_mid = (FT + 1) / 2;
+    const int ct_lo = (halved && part == a.n_nets) ? ct_mid : 0, ct_hi = (halved && part < a.n_nets) ? ct_mid : FT;
     float* sH = (float*)smem_raw;                                   // [rows][AS] h1, later O [rows][J]
     float* sD = sH + (size_t)rows * (AS > OS ? AS : OS);            // [rows][AS] routed gradient
     uint32_t* sG = (uint32_t*)(sD + (size_t)rows * AS);             // [rows][BW] bit o of word: h1[t][o] > 0
@@ -255,6 +266,8 @@ __device__ __forceinline__ void cnn_body(const CnnArgs& a, const int bx, const i
     //      gate bits are OR-ed into sG with LDS atomics.
     for (int w = tid; w < rows * BW; w += NT) sG[w] = 0u;
     for (int e = tid; e < rows * 2; e += NT) sH[(e >> 1) * AS + CP + (e & 1)] = 0.f;   // (the contractions stop at CP: never read)
+    if (halved)
+        for (int f = tid; f < FP; f += NT) { sM[f] = 0.f; sTs[f] = 0; }                // the other half's features: never routed
     __syncthreads();
     {
         const int G4 = CP / 4;                                       // float4 groups per row
@@ -294,7 +307,7 @@ __device__ __forceinline__ void cnn_body(const CnnArgs& a, const int bx, const i
     PPDE_STAMP(a.dbg, sb + 2, stamp);
     // ---- pre2 = h1 We^T + be on the matrix cores; relu and the running max over t straight from the accumulators
     //      (strict >, rows ascending: the first index wins, like torch.max)
-    for (int ct = wave; ct < FP / 16; ct += NT / 64) {
+    for (int ct = ct_lo + wave; ct < ct_hi; ct += NT / 64) {
         f32x4 acc[RT];
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) acc[rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -341,7 +354,7 @@ __device__ __forceinline__ void cnn_body(const CnnArgs& a, const int bx, const i
         if (a.want_grad)
             for (int w = tid; w < rows * BWF; w += NT) sB[w] = 0u;  // route bitmap (filled behind the barrier below)
         const float tot = block_sum<NT / 64>(s, red, phase);             // (its barrier also orders the sM rewrite below)
-        if (tid == 0) a.fitC[((size_t)slot * a.n_nets + ni) * a.n + b] = tot + net.bd;
+        if (tid == 0) a.fitC[((size_t)slot * a.n_parts + part) * a.n + b] = part < a.n_nets ? tot + net.bd : tot;   // (the bias once)
         k = 0;
         for (int f = tid; f < FP; f += NT, ++k)
             if (k < 2) sM[f] = cf[k];
@@ -374,7 +387,7 @@ __device__ __forceinline__ void cnn_body(const CnnArgs& a, const int bx, const i
     __syncthreads();
     PPDE_STAMP(a.dbg, sb + 8, stamp);
     // ---- transposed convolution: dx[p][c] = sum_kappa O[p - kappa][kappa*20 + c]
-    float* out = a.gradC + (((size_t)slot * a.n_nets + ni) * a.n + b) * g.N;
+    float* out = a.gradC + (((size_t)slot * a.n_parts + part) * a.n + b) * g.N;
     for (int e0 = tid; e0 < g.N; e0 += 2 * NT) {                       // two elements per round: 2*KT LDS reads in flight
         float x[2][KT];
         int pp[2];
@@ -403,7 +416,7 @@ __device__ __forceinline__ void cnn_body(const CnnArgs& a, const int bx, const i
     PPDE_WG_STAMP(a.dbg, wg_lin, 3);
 }
 
-template <int RT, int KT, int NT = 256>
+template <int RT, int KT, int NT = CNN_NT>
 __global__ __launch_bounds__(NT, 2) void k_cnn(CnnArgs a) {
     warm_kernargs<sizeof(CnnArgs)>();
     extern __shared__ unsigned char smem_raw[];
@@ -597,7 +610,7 @@ __global__ __launch_bounds__(256, 2) void k_cnn_bwd_chunk(CnnChunkArgs ca) {
         sTs[f] = ts;
     }
     const float tot = block_sum<4>(part, red, phase);
-    if (c == 0 && tid == 0) a.fitC[((size_t)slot * a.n_nets + ni) * a.n + b] = tot + net.bd;
+    if (c == 0 && tid == 0) a.fitC[((size_t)slot * a.n_parts + ni) * a.n + b] = tot + net.bd;
     if (!a.want_grad) return;
 
     for (int w = tid; w < rows * ((FP + 31) / 32); w += 256) ((uint32_t*)sD)[w] = 0u;   // route bitmap (in sD's storage)
@@ -633,7 +646,7 @@ __global__ __launch_bounds__(256, 2) void k_cnn_bwd_chunk(CnnChunkArgs ca) {
     __syncthreads();
     PPDE_STAMP(a.dbg, 44, stamp);
     // ---- transposed convolution for this chunk's own output positions
-    float* out = a.gradC + (((size_t)slot * a.n_nets + ni) * a.n + b) * g.N;
+    float* out = a.gradC + (((size_t)slot * a.n_parts + ni) * a.n + b) * g.N;
     const int p1 = min(p0 + PO, g.L);
     for (int e = p0 * 20 + tid; e < p1 * 20; e += 256) {
         const int p = e / 20, cc = e - 20 * p;

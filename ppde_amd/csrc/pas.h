@@ -39,6 +39,7 @@ struct PasArgs {
     const float* gradC;         // [2][nets][n][N]  lamda * d fit_net/dx / nets   (NULL without the CNN expert)
     const float* fitC;          // [2][nets][n]     per-network predictions
     int n_nets;
+    int n_parts;                // rows of gradC / fitC per chain (cnn.h: n_nets, or n_nets + 1 with the last network cut in two)
     const float* gradT;         // [2][n][N]  d (transformer score) / dx                  (NULL without the transformer expert)
     const float* tfE;           // [2][n]     transformer local score
     float tf_wt;                // the wild type's (nets.py:188)
@@ -182,10 +183,10 @@ __device__ __forceinline__ RowSrc slot_row(const PasArgs& a, int slot, int b) {
     r.c[0] = r.c[1] = r.c[2] = r.c[3] = nullptr;
     r.t = (a.which & 4) ? (const float4*)(a.gradT + ((size_t)slot * a.n + b) * a.g.N) : nullptr;
     if (a.which & 2) {
-        r.nc = a.n_nets;
+        r.nc = a.n_parts;
 #pragma unroll
         for (int k = 0; k < 4; ++k)
-            if (k < a.n_nets) r.c[k] = (const float4*)(a.gradC + (((size_t)slot * a.n_nets + k) * a.n + b) * a.g.N);
+            if (k < a.n_parts) r.c[k] = (const float4*)(a.gradC + (((size_t)slot * a.n_parts + k) * a.n + b) * a.g.N);
     }
     return r;
 }
@@ -643,7 +644,7 @@ __device__ __forceinline__ void slot_energy(const PasArgs& a, int slot, int b, f
     if (a.which & 4) dH += a.tfE[(size_t)slot * a.n + b] - a.tf_wt;   // PottsTransformer: potts + transformer (nets.py:311-312)
     f = 0.f;
     if (a.which & 2) {                               // EnsembleProtein: mean of the networks' outputs
-        for (int k = 0; k < a.n_nets; ++k) f += a.fitC[((size_t)slot * a.n_nets + k) * a.n + b];
+        for (int k = 0; k < a.n_parts; ++k) f += a.fitC[((size_t)slot * a.n_parts + k) * a.n + b];
         f = f / (float)a.n_nets;
     }
     e = (a.which == 2) ? f : dH + a.lamda * f;
@@ -665,11 +666,11 @@ __device__ __forceinline__ EnergyPrefetch prefetch_energy(const PasArgs& a, int 
         p.e1 = ep[min(lane + 64, a.g.Lp - 1)];
     }
     if (a.which & 2) {
-        const float* fc = a.fitC + (size_t)slot * a.n_nets * a.n + b;
+        const float* fc = a.fitC + (size_t)slot * a.n_parts * a.n + b;
         p.f0 = fc[0];
-        if (a.n_nets > 1) p.f1 = fc[(size_t)a.n];
-        if (a.n_nets > 2) p.f2 = fc[(size_t)2 * a.n];
-        if (a.n_nets > 3) p.f3 = fc[(size_t)3 * a.n];
+        if (a.n_parts > 1) p.f1 = fc[(size_t)a.n];
+        if (a.n_parts > 2) p.f2 = fc[(size_t)2 * a.n];
+        if (a.n_parts > 3) p.f3 = fc[(size_t)3 * a.n];
     }
     return p;
 }
@@ -690,9 +691,9 @@ __device__ __forceinline__ void finish_energy(const PasArgs& a, int slot, int b,
     f = 0.f;
     if (a.which & 2) {
         f = 0.f + p.f0;                               // same order as slot_energy: ((0 + f0) + f1) + ...
-        if (a.n_nets > 1) f += p.f1;
-        if (a.n_nets > 2) f += p.f2;
-        if (a.n_nets > 3) f += p.f3;
+        if (a.n_parts > 1) f += p.f1;
+        if (a.n_parts > 2) f += p.f2;
+        if (a.n_parts > 3) f += p.f3;
         f = f / (float)a.n_nets;
     }
     e = (a.which == 2) ? f : dH + a.lamda * f;

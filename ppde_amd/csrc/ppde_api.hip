@@ -233,6 +233,16 @@ static bool cnn_single_launch(const ppde_model* m) {
     return 2 * lds <= 160 * 1024 || chunked_override == 0;
 }
 
+// Output rows of the CNN expert per chain. The single-launch kernel cuts the LAST network's features into two workgroups:
+// chains x networks workgroups on 256 CUs at two per CU left half of the CUs with one workgroup (32 us) and half with
+// two (45 us) at 128 chains x 3 networks; with 2 whole + 2 half units per chain every CU pairs a whole unit with a half
+// one. The cut does not depend on the batch (a chain's numbers never depend on the batch it sits in).
+static int cnn_parts(const ppde_model* m) {
+    static const bool split = []() { const char* e = getenv("PPDE_CNN_SPLIT"); return !e || atoi(e) != 0; }();   // tuning knob
+    if (!m->has_cnn) return std::max(m->n_nets, 1);
+    return (split && cnn_single_launch(m) && m->n_nets <= 3 && m->FP >= 32) ? m->n_nets + 1 : m->n_nets;
+}
+
 static size_t cnn_chunk_max_count(const ppde_model* m, int n) { return (size_t)m->n_nets * n * cnn_fwd_chunks(m->T) * m->FP; }
 static size_t cnn_chunk_gate_count(const ppde_model* m, int n) {
     return (size_t)m->n_nets * n * cnn_fwd_chunks(m->T) * CNN_FCH_RT * 16 * ((m->CP + 31) / 32);
@@ -255,7 +265,7 @@ static int launch_cnn(const ppde_model* m, const States& st, int n, const EvalTa
     CnnArgs a{};
     a.b_off = b_off; a.dbg = t.dbg;
     for (int k = 0; k < m->n_nets; ++k) a.net[k] = m->nets[k];
-    a.n_nets = m->n_nets; a.C = m->C; a.CP = m->CP; a.K = m->K; a.KT = m->KT; a.F = m->F; a.FP = m->FP; a.T = m->T; a.J = m->J; a.JP = m->JP;
+    a.n_nets = m->n_nets; a.n_parts = cnn_parts(m); a.C = m->C; a.CP = m->CP; a.K = m->K; a.KT = m->KT; a.F = m->F; a.FP = m->FP; a.T = m->T; a.J = m->J; a.JP = m->JP;
     a.idx = st.rows; a.gradC = t.gradC; a.fitC = t.fitC;
     a.slot = t.slot; a.n = n; a.want_grad = want_grad; a.scale = scale;
     a.g = m->g;
@@ -277,12 +287,10 @@ static int launch_cnn(const ppde_model* m, const States& st, int n, const EvalTa
         return PPDE_OK;
     }
     size_t lds = cnn_lds_bytes(m->T, m->CP, m->FP, m->J, m->L);
-    const dim3 grid(n_sub, m->n_nets);
-    static const int cnn_threads = []() { const char* e = getenv("PPDE_CNN_WAVES"); return e && atoi(e) == 8 ? 512 : 256; }();
+    const dim3 grid(n_sub, a.n_parts);
 #define PPDE_CNN(RTV)                                                                           \
-    if (m->KT == 5 && cnn_threads == 512) hipLaunchKernelGGL((k_cnn<RTV, 5, 512>), grid, dim3(512), lds, s, a);   \
-    else if (m->KT == 5) hipLaunchKernelGGL((k_cnn<RTV, 5>), grid, dim3(256), lds, s, a);         \
-    else hipLaunchKernelGGL((k_cnn<RTV, CNN_MAX_K>), grid, dim3(256), lds, s, a);
+    if (m->KT == 5) hipLaunchKernelGGL((k_cnn<RTV, 5>), grid, dim3(CNN_NT), lds, s, a);           \
+    else hipLaunchKernelGGL((k_cnn<RTV, CNN_MAX_K>), grid, dim3(CNN_NT), lds, s, a);
     switch (cnn_rows(m->T) / 16) {
         case 1: PPDE_CNN(1) break;
         case 2: PPDE_CNN(2) break;
@@ -312,7 +320,7 @@ struct ExpertsArgs {
     int potts_items, potts_nby;   // then potts_items = tiles x potts_nby (chain blocks) Potts workgroups
 };
 template <int RT, int NG>
-__global__ __launch_bounds__(256, 2) void k_experts(ExpertsArgs a) {
+__global__ __launch_bounds__(CNN_NT, 2) void k_experts(ExpertsArgs a) {
     warm_kernargs<sizeof(ExpertsArgs)>();
     extern __shared__ float4 smem_experts[];
     const int w = blockIdx.x, n_cnn = a.cnn_bx * a.cnn_ni;
@@ -320,6 +328,7 @@ __global__ __launch_bounds__(256, 2) void k_experts(ExpertsArgs a) {
         const int ni = w / a.cnn_bx;
         cnn_body<RT, 5>(a.c, w - ni * a.cnn_bx, ni, a.cnn_bx, a.cnn_ni, (unsigned char*)smem_experts);
     } else {
+        if (threadIdx.x >= 256) return;          // a Potts tile is the work of four waves (the barrier counts live waves only)
         const int v = xcd_contiguous(w - n_cnn, a.potts_items);
         potts_body<NG>(a.p, v / a.potts_nby, v % a.potts_nby, smem_experts);
     }
@@ -337,7 +346,7 @@ static int launch_experts_fused(const ppde_model* m, const States& st, int n, co
     CnnArgs& c = a.c;
     c.b_off = b_off; c.dbg = t.dbg;
     for (int k = 0; k < m->n_nets; ++k) c.net[k] = m->nets[k];
-    c.n_nets = m->n_nets; c.C = m->C; c.CP = m->CP; c.K = m->K; c.KT = m->KT; c.F = m->F; c.FP = m->FP; c.T = m->T; c.J = m->J; c.JP = m->JP;
+    c.n_nets = m->n_nets; c.n_parts = cnn_parts(m); c.C = m->C; c.CP = m->CP; c.K = m->K; c.KT = m->KT; c.F = m->F; c.FP = m->FP; c.T = m->T; c.J = m->J; c.JP = m->JP;
     c.idx = st.rows; c.gradC = t.gradC; c.fitC = t.fitC;
     c.slot = t.slot; c.n = n; c.want_grad = 1; c.scale = scale;
     c.g = m->g;
@@ -346,14 +355,14 @@ static int launch_experts_fused(const ppde_model* m, const States& st, int n, co
     p.Jt = m->d_Jt; p.h = m->d_h; p.idxT = st.T; p.n_pad = st.n_pad; p.grad = t.grad; p.epart = t.epart;
     p.slot = t.slot; p.n = n;
     p.g = m->g;
-    a.cnn_bx = n_sub; a.cnn_ni = m->n_nets;
+    a.cnn_bx = n_sub; a.cnn_ni = c.n_parts;
     const int CPB = NG * 64;
     a.potts_nby = (n_sub + CPB - 1) / CPB;
     a.potts_items = m->g.Lp * 5 * a.potts_nby;
     const dim3 grid(a.cnn_bx * a.cnn_ni + a.potts_items);
 #define PPDE_EX(RTV)                                                                              \
-    if (NG == 1) hipLaunchKernelGGL((k_experts<RTV, 1>), grid, dim3(256), lds_c, s, a);            \
-    else hipLaunchKernelGGL((k_experts<RTV, 2>), grid, dim3(256), lds_c, s, a);
+    if (NG == 1) hipLaunchKernelGGL((k_experts<RTV, 1>), grid, dim3(CNN_NT), lds_c, s, a);         \
+    else hipLaunchKernelGGL((k_experts<RTV, 2>), grid, dim3(CNN_NT), lds_c, s, a);
     switch (cnn_rows(m->T) / 16) {
         case 1: PPDE_EX(1) break;
         case 2: PPDE_EX(2) break;
@@ -403,7 +412,7 @@ static int eval_experts(const ppde_model* m, int which, const States& states, in
 static PasArgs base_pas_args(const ppde_model* m, int which, int n) {
     PasArgs a{};
     a.g = m->g; a.n = n; a.wt = m->d_wt; a.wt_H = m->wt_H; a.lamda = m->lamda; a.which = which;
-    a.n_nets = m->n_nets;
+    a.n_nets = m->n_nets; a.n_parts = cnn_parts(m);
     a.tf_wt = m->tf ? m->tf->wt_score : 0.f;
     return a;
 }
@@ -687,8 +696,8 @@ static int ensure_scratch(ppde_model* m, int n) {
     HIPCHK(hipMemset(m->s_grad, 0, (size_t)n * g.N * sizeof(float)));
     HIPCHK(dalloc(&m->s_epart, (size_t)n * std::max(g.Lp, 1)));
     if (m->has_cnn) {
-        HIPCHK(dalloc(&m->s_gradC, (size_t)m->n_nets * n * g.N));
-        HIPCHK(dalloc(&m->s_fitC, (size_t)m->n_nets * n));
+        HIPCHK(dalloc(&m->s_gradC, (size_t)cnn_parts(m) * n * g.N));
+        HIPCHK(dalloc(&m->s_fitC, (size_t)cnn_parts(m) * n));
     }
     m->scratch_n = n;
     return PPDE_OK;
@@ -980,7 +989,7 @@ int ppde_chains_create(ppde_chains** out, ppde_model* m, const ppde_chain_config
     c->m = m; c->device = m->device; c->cfg = *cfg; c->n = cfg->n_chains; c->T = cfg->max_steps; c->mu_max = 2 * cfg->pas_length - 1;
     const Geom& g = m->g;
     const size_t n = c->n, T1 = (size_t)c->T + 1;
-    const int nets = std::max(m->n_nets, 1);
+    const int nets = cnn_parts(m);
     bool ok = true;
     auto A = [&](auto** p, size_t count, bool zero) {
         if (!ok) return;
