@@ -75,13 +75,18 @@ def main(args, rank, world, local, backend):
 
     dt, dts = timed(bool(args.reuse_grad))
     dt_other, _ = timed(not bool(args.reuse_grad))
-    # dominant kernel: tf_gemm_nt at the fc1 shape
+    # dominant kernel: tf_gemm_nt at the fc1 shape (bias + GELU epilogue), timed IN SITU: a HIP event pair around every fc1
+    # launch of one real evaluation (what rocprofv3's per-kernel average of the same command sees). The same kernel on
+    # pseudo-random operands, launched back to back, is reported beside it: random fp16 data toggles more of the matrix
+    # pipe and runs at a lower clock than the activations of a real evaluation do.
     M = (n * L + 127) // 128 * 128
-    us = C.c_float()
-    _hip.check(_hip.load().ppde_transformer_time_gemm(local, M, F, D, 50, 3, C.byref(us)))
+    x = torch.as_tensor(np.tile(wt, (n, 1))).to(device, torch.uint8).contiguous()
+    us, nl = C.c_float(), C.c_int()
+    _hip.check(_hip.load().ppde_transformer_time_fc1_in_situ(m.handle, _hip.ptr(x), n, C.byref(us), C.byref(nl)))
+    us_rand = C.c_float()
+    _hip.check(_hip.load().ppde_transformer_time_gemm(local, M, F, D, 50, 3, C.byref(us_rand)))
     gemm_tf = 2.0 * M * F * D / (us.value * 1e-6) / 1e12
     # one evaluation on its own
-    x = torch.as_tensor(np.tile(wt, (n, 1))).to(device)
     m.energy_grad(x, 4)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -107,7 +112,9 @@ def main(args, rank, world, local, backend):
         "roofline": {"kernel": "tf_gemm_nt<bias+GELU> (fc1 shape)", "bound": "mfma", "achieved": gemm_tf, "peak": MFMA_F16_PEAK_TF / 1.0,
                      "unit": "TFLOP/s", "frac": gemm_tf / MFMA_F16_PEAK_TF, "traffic": None,
                      "traffic_source": None, "algorithmic_flops_per_launch": 2.0 * M * F * D, "avg_launch_us": us.value,
-                     "launches_timed": 50, "shape": [M, F, D]},
+                     "launches_timed": nl.value, "shape": [M, F, D],
+                     "timing": "HIP event pair around every fc1 launch of one evaluation (in situ)",
+                     "avg_launch_us_random_operands_back_to_back": us_rand.value},
         "evaluation": {"ms": ev * 1e3, "algorithmic_tflop": fl / 1e12, "tflops": fl / ev / 1e12,
                        "note": "one transformer energy+gradient evaluation of all chains (forward + input gradient, every kernel)"},
         ("value_reuse_grad" if not args.reuse_grad else "value_reevaluate"): steps / dt_other,

@@ -122,6 +122,11 @@ int ppde_transformer_time_gemm(int device, int M, int N, int K, int reps, int ep
  * 10 / 11 attention output / d q|k|v of the layer evaluated last. */
 int ppde_debug_transformer_read(ppde_model* m, int what, int layer, float* out_host, int64_t count);
 
+/* The fc1 GEMM timed IN SITU for bench.py's roofline object: one stateless transformer evaluation (energy + gradient)
+ * of idx_dev [n, L] with a HIP event pair around every fc1 launch (real activations, real neighbouring kernels); mean
+ * event-to-event time in microseconds and the number of launches timed (= layers). */
+int ppde_transformer_time_fc1_in_situ(ppde_model* m, const uint8_t* idx_dev, int n, float* avg_us, int* launches);
+
 /* lamda of e = dH + lamda * fit (energy.py:74, :99-100). */
 int ppde_model_set_lamda(ppde_model* m, float lamda);
 

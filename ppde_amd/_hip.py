@@ -49,6 +49,7 @@ SIGNATURES = {
     "ppde_model_get_transformer_wt_score": (_i, [_p, C.POINTER(_f)]),
     "ppde_debug_transformer_read": (_i, [_p, _i, _i, _p, C.c_int64]),
     "ppde_transformer_time_gemm": (_i, [_i, _i, _i, _i, _i, _i, C.POINTER(_f)]),
+    "ppde_transformer_time_fc1_in_situ": (_i, [_p, _p, _i, C.POINTER(_f), C.POINTER(_i)]),
     "ppde_model_get_wt_hamiltonian": (_i, [_p, C.POINTER(_f)]),
     "ppde_onehot_to_idx": (_i, [_p, _p, _i, _p, _p]),
     "ppde_idx_to_onehot": (_i, [_p, _p, _i, _p, _p]),

@@ -530,6 +530,35 @@ int ppde_transformer_time_gemm(int device, int M, int N, int K, int reps, int ep
     return PPDE_OK;
 }
 
+// The same kernel timed IN SITU: one stateless transformer evaluation (energy + gradient) of idx_dev [n, L] with a HIP event
+// pair around every fc1 GEMM launch; mean event-to-event time and the number of launches timed.
+int ppde_transformer_time_fc1_in_situ(ppde_model* m, const uint8_t* idx_dev, int n, float* avg_us, int* launches) {
+    ARGCHK(m && m->tf && idx_dev && n >= 1 && avg_us && launches, "bad argument");
+    HIPCHK(hipSetDevice(m->device));
+    DevTmp e, fit, grad;
+    HIPCHK(e.alloc<float>((size_t)n)); HIPCHK(fit.alloc<float>((size_t)n)); HIPCHK(grad.alloc<float>((size_t)n * m->g.N));
+    struct Guard { TfEventList l; ~Guard() { g_tf_fc1_events = nullptr; for (hipEvent_t x : l.ev) if (x) hipEventDestroy(x); } } g;
+    g.l.ev.assign((size_t)2 * m->tf->layers, nullptr);
+    for (auto& x : g.l.ev) HIPCHK(hipEventCreate(&x));
+    int rc = ppde_energy_grad(m, idx_dev, n, 4, e.as<float>(), fit.as<float>(), grad.as<float>(), nullptr);   // warm (workspace, caches)
+    if (rc) return rc;
+    g_tf_fc1_events = &g.l;
+    rc = ppde_energy_grad(m, idx_dev, n, 4, e.as<float>(), fit.as<float>(), grad.as<float>(), nullptr);
+    g_tf_fc1_events = nullptr;
+    if (rc) return rc;
+    HIPCHK(hipDeviceSynchronize());
+    double tot = 0.0;
+    int cnt = 0;
+    for (size_t i = 0; i + 1 < g.l.used; i += 2) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, g.l.ev[i], g.l.ev[i + 1]) == hipSuccess) { tot += ms; ++cnt; }
+    }
+    ARGCHK(cnt > 0, "no fc1 launch was timed");
+    *avg_us = (float)(tot * 1000.0 / cnt);
+    *launches = cnt;
+    return PPDE_OK;
+}
+
 // Diagnostics: an activation of the LAST stateless transformer evaluation (ppde_energy_grad with bit 2) as fp32.
 int ppde_debug_transformer_read(ppde_model* m, int what, int layer, float* out_host, int64_t count) {
     ARGCHK(m && m->tf && m->s_tfw && out_host && count >= 0, "no transformer evaluation to read from");

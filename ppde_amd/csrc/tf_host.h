@@ -206,6 +206,11 @@ __global__ void tf_fill_random(half_t* p, size_t count, uint32_t seed) {
 }
 #define TFRC(x) do { int rc_ = (x); if (rc_) return rc_; } while (0)
 
+// When set, every fc1 GEMM launch (bias + GELU, the largest kernel of an evaluation) of tf_eval is bracketed by a pair of
+// events from this list: in-situ timing for bench.py's roofline object (real activations, real neighbours).
+struct TfEventList { std::vector<hipEvent_t> ev; size_t used = 0; };
+static thread_local TfEventList* g_tf_fc1_events = nullptr;
+
 // One evaluation: scores of n chains (state rows) into score_out [n], and, when grad_out is not NULL, the gradient of
 // the scores w.r.t. the Potts one-hot input into grad_out rows [n][L*20] (fp32).
 static int tf_eval(const TfModel* t, TfWork* wk, const uint8_t* rows, int Ls, int sh, int n, float* score_out, float* grad_out, hipStream_t s) {
@@ -225,7 +230,11 @@ static int tf_eval(const TfModel* t, TfWork* wk, const uint8_t* rows, int Ls, in
         HIPCHK(hipGetLastError());
         TFRC(tf_gemm<TF_EPI_BIAS_RESID>(s, wk->ctx, w.Wo, a.xmid, Mp, D, D, w.bo, a.xin));
         TFRC(tf_ln(s, false, a.xmid, wk->ln_out, w.ln2g, w.ln2b, a.mean2, a.rstd2, M, D));
+        TfEventList* el = g_tf_fc1_events;
+        if (el && el->used + 2 > el->ev.size()) el = nullptr;
+        if (el && hipEventRecord(el->ev[el->used++], s) != hipSuccess) return fail(PPDE_ERR_HIP, "event record failed");
         TFRC(tf_gemm<TF_EPI_BIAS_GELU>(s, wk->ln_out, w.W1, wk->actf, Mp, F, D, w.b1, nullptr, a.hpre));
+        if (el && hipEventRecord(el->ev[el->used++], s) != hipSuccess) return fail(PPDE_ERR_HIP, "event record failed");
         TFRC(tf_gemm<TF_EPI_BIAS_RESID>(s, wk->actf, w.W2, xnext, Mp, D, F, w.b2, a.xmid));
     }
     TFRC(tf_ln(s, false, wk->xlast, wk->ln_out, t->lnf_g, t->lnf_b, wk->meanf, wk->rstdf, M, D));
