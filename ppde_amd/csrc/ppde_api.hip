@@ -470,7 +470,7 @@ int ppde_model_set_transformer(ppde_model* m, int n_layers, int dim, int heads, 
     ARGCHK(n_layers >= 1 && n_layers <= 64, "1..64 transformer layers");
     ARGCHK(heads >= 1 && dim == heads * TF_HD, "the attention kernels are written for head width 32 (ESM-2 150M: 640 / 20)");
     ARGCHK(dim % 128 == 0 && ffn % 128 == 0 && dim <= 2 * 64 * TF_LN_MAXP, "dim and ffn must be multiples of 128, dim <= 1024");
-    ARGCHK(m->L <= TF_TP, "the transformer expert handles sequences of up to 128 residues");
+    ARGCHK(m->L <= TF_TP_MAX, "the transformer expert handles sequences of up to 256 residues");
     HIPCHK(hipSetDevice(m->device));
     delete m->tf; m->tf = nullptr;
     delete m->s_tfw; m->s_tfw = nullptr;

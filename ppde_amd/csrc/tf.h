@@ -15,6 +15,7 @@
 // matrix cores), tf_ln_fwd / tf_ln_bwd, tf_embed, tf_score (log-softmax, score, gradient seeds), tf_finish_grad.
 #pragma once
 #include "common.h"
+#include <type_traits>
 #include "potts.h"      // wait_vmcnt, xcd_contiguous
 
 typedef _Float16 half_t;
@@ -396,9 +397,9 @@ __global__ void tf_embed(const uint8_t* __restrict__ idx, int Ls, int sh, int L,
 // ------------------------------------------------------------------------------------------------------------
 #define TF_ATT_WAVES_F 4           // wavefronts per (chain, head) in the forward ...
 #define TF_ATT_WAVES_B 4           // ... and in the backward (a power of two: the partial dK, dV are summed in a tree)
-#define TF_TP 128                 // padded sequence length the attention kernels are written for (L <= 128)
-#define TF_NKT 8                  // key tiles of 16
-#define TF_LDP (TF_TP + 8)        // padded row length (halfs) of the transposed LDS images
+// TP = padded sequence length a kernel instance is written for (128, or 256 for longer proteins such as GFP): TP / 16 key
+// tiles, transposed LDS images with rows of TP + 8 halfs
+#define TF_TP_MAX 256
 typedef __fp16 tf_hfx4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
 
 struct TfAttnArgs {
@@ -416,34 +417,34 @@ struct TfAttnArgs {
 
 // Staging of one head's rows. Every global load of the head is issued before the first value is used (the fetch_*
 // half), then rotated / transposed into LDS (the put_* half): staged array by array, each round of dependent loads
-// cost a full memory latency with two wavefronts to hide it. Items past L write zeros, so the [TF_TP] tiles need no
+// cost a full memory latency with two wavefronts to hide it. Items past L write zeros, so the [TP] tiles need no
 // clearing pass (the 8 pad columns of the transposed images are never read).
 //   rotary item = (t, c in {0,1}): dims 8c..8c+7 and their partners 16+8c..;  plain item = (t, c in {0..3}): dims 8c..
-template <int NTHR> struct TfRotRaw { static constexpr int R = 2 * TF_TP / NTHR; f16x8 x1[R], x2[R]; static_assert(2 * TF_TP % NTHR == 0, "whole rounds"); };
-template <int NTHR> struct TfRope { static constexpr int R = 2 * TF_TP / NTHR; float co[R][8], si[R][8]; };
-template <int NTHR> struct TfPlainRaw { static constexpr int R = 4 * TF_TP / NTHR; f16x8 x[R]; };
-template <int NTHR>
-__device__ __forceinline__ void tf_fetch_rot(const half_t* src, int ld, int L, int tid, TfRotRaw<NTHR>& w) {
+template <int NTHR, int TP> struct TfRotRaw { static constexpr int R = 2 * TP / NTHR; f16x8 x1[R], x2[R]; static_assert(2 * TP % NTHR == 0, "whole rounds"); };
+template <int NTHR, int TP> struct TfRope { static constexpr int R = 2 * TP / NTHR; float co[R][8], si[R][8]; };
+template <int NTHR, int TP> struct TfPlainRaw { static constexpr int R = 4 * TP / NTHR; f16x8 x[R]; };
+template <int NTHR, int TP>
+__device__ __forceinline__ void tf_fetch_rot(const half_t* src, int ld, int L, int tid, TfRotRaw<NTHR, TP>& w) {
 #pragma unroll
-    for (int r = 0; r < 2 * TF_TP / NTHR; ++r) {
+    for (int r = 0; r < 2 * TP / NTHR; ++r) {
         const int it = tid + r * NTHR, t = min(it >> 1, L - 1), c = it & 1;
         w.x1[r] = *(const f16x8*)(src + (size_t)t * ld + 8 * c);
         w.x2[r] = *(const f16x8*)(src + (size_t)t * ld + 16 + 8 * c);
     }
 }
-template <int NTHR>
-__device__ __forceinline__ void tf_fetch_rope(const float* rc, const float* rs, int L, int tid, TfRope<NTHR>& w) {
+template <int NTHR, int TP>
+__device__ __forceinline__ void tf_fetch_rope(const float* rc, const float* rs, int L, int tid, TfRope<NTHR, TP>& w) {
 #pragma unroll
-    for (int r = 0; r < 2 * TF_TP / NTHR; ++r) {
+    for (int r = 0; r < 2 * TP / NTHR; ++r) {
         const int it = tid + r * NTHR, t = min(it >> 1, L - 1), c = it & 1;
         tf_load8(rc + t * 16 + 8 * c, w.co[r]);
         tf_load8(rs + t * 16 + 8 * c, w.si[r]);
     }
 }
-template <bool ROWS, bool TRANSPOSED, int NTHR>
-__device__ __forceinline__ void tf_put_rot(const TfRotRaw<NTHR>& w, const TfRope<NTHR>& rp, int L, int tid, half_t* dst, half_t* dst_t) {
+template <bool ROWS, bool TRANSPOSED, int NTHR, int TP>
+__device__ __forceinline__ void tf_put_rot(const TfRotRaw<NTHR, TP>& w, const TfRope<NTHR, TP>& rp, int L, int tid, half_t* dst, half_t* dst_t) {
 #pragma unroll
-    for (int r = 0; r < 2 * TF_TP / NTHR; ++r) {
+    for (int r = 0; r < 2 * TP / NTHR; ++r) {
         const int it = tid + r * NTHR, t = it >> 1, c = it & 1;
         f16x8 y1, y2;
 #pragma unroll
@@ -457,29 +458,29 @@ __device__ __forceinline__ void tf_put_rot(const TfRotRaw<NTHR>& w, const TfRope
         }
         if constexpr (TRANSPOSED) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) { dst_t[(8 * c + e) * TF_LDP + t] = y1[e]; dst_t[(16 + 8 * c + e) * TF_LDP + t] = y2[e]; }
+            for (int e = 0; e < 8; ++e) { dst_t[(8 * c + e) * (TP + 8) + t] = y1[e]; dst_t[(16 + 8 * c + e) * (TP + 8) + t] = y2[e]; }
         }
     }
 }
-template <int NTHR>
-__device__ __forceinline__ void tf_fetch_plain(const half_t* src, int ld, int L, int tid, TfPlainRaw<NTHR>& w) {
+template <int NTHR, int TP>
+__device__ __forceinline__ void tf_fetch_plain(const half_t* src, int ld, int L, int tid, TfPlainRaw<NTHR, TP>& w) {
 #pragma unroll
-    for (int r = 0; r < 4 * TF_TP / NTHR; ++r) {
+    for (int r = 0; r < 4 * TP / NTHR; ++r) {
         const int it = tid + r * NTHR, t = min(it >> 2, L - 1), c = it & 3;
         w.x[r] = *(const f16x8*)(src + (size_t)t * ld + 8 * c);
     }
 }
-template <bool TRANSPOSED, int NTHR>
-__device__ __forceinline__ void tf_put_plain(const TfPlainRaw<NTHR>& w, int L, int tid, half_t* dst) {
+template <bool TRANSPOSED, int NTHR, int TP>
+__device__ __forceinline__ void tf_put_plain(const TfPlainRaw<NTHR, TP>& w, int L, int tid, half_t* dst) {
 #pragma unroll
-    for (int r = 0; r < 4 * TF_TP / NTHR; ++r) {
+    for (int r = 0; r < 4 * TP / NTHR; ++r) {
         const int it = tid + r * NTHR, t = it >> 2, c = it & 3;
         f16x8 x = w.x[r];
         if (t >= L) x = (f16x8){0, 0, 0, 0, 0, 0, 0, 0};
         if constexpr (!TRANSPOSED) *(f16x8*)(dst + t * TF_HD + 8 * c) = x;
         else {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) dst[(8 * c + e) * TF_LDP + t] = x[e];
+            for (int e = 0; e < 8; ++e) dst[(8 * c + e) * (TP + 8) + t] = x[e];
         }
     }
 }
@@ -487,22 +488,24 @@ __device__ __forceinline__ float tf_quad_rows_max(float v) { return fmaxf(fmaxf(
 __device__ __forceinline__ float tf_quad_rows_sum(float v) { v += __shfl_xor(v, 16); v += __shfl_xor(v, 32); return v; }
 
 // LDS: q rows [TP][32] | k rows [TP][32] | v transposed [32][LDP]
-__host__ __device__ constexpr size_t tf_attn_fwd_lds() { return (size_t)(2 * TF_TP * TF_HD + TF_HD * TF_LDP) * 2; }
+template <int TP> __host__ __device__ constexpr size_t tf_attn_fwd_lds() { return (size_t)(2 * TP * TF_HD + TF_HD * (TP + 8)) * 2; }
 
+template <int TP>
 __global__ __launch_bounds__(64 * TF_ATT_WAVES_F) void tf_attn_fwd(TfAttnArgs a) {
+    constexpr int NKT = TP / 16, LDP = TP + 8;
     extern __shared__ __attribute__((aligned(16))) unsigned char tf_smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.x / a.H, h = blockIdx.x % a.H;
     const int L = a.L, D = a.D, ld = 3 * D;
     half_t* sQ = (half_t*)tf_smem;
-    half_t* sK = sQ + TF_TP * TF_HD;
-    half_t* sVt = sK + TF_TP * TF_HD;                 // [32][TF_LDP]
+    half_t* sK = sQ + TP * TF_HD;
+    half_t* sVt = sK + TP * TF_HD;                 // [32][LDP]
     const half_t* base = a.qkv + (size_t)b * L * ld + h * TF_HD;
     {
         constexpr int NT = 64 * TF_ATT_WAVES_F;
-        TfRotRaw<NT> rq, rk;
-        TfRope<NT> rp;
-        TfPlainRaw<NT> rv;
+        TfRotRaw<NT, TP> rq, rk;
+        TfRope<NT, TP> rp;
+        TfPlainRaw<NT, TP> rv;
         tf_fetch_rot(base, ld, L, tid, rq);
         tf_fetch_rot(base + D, ld, L, tid, rk);
         tf_fetch_plain(base + 2 * D, ld, L, tid, rv);
@@ -517,10 +520,10 @@ __global__ __launch_bounds__(64 * TF_ATT_WAVES_F) void tf_attn_fwd(TfAttnArgs a)
     float2* stat = a.stat + (size_t)(b * a.H + h) * L;
     for (int qi = wave; qi < NQ; qi += TF_ATT_WAVES_F) {
         const f16x8 qf = *(const f16x8*)(sQ + (qi * 16 + fr) * TF_HD + fg * 8);
-        tf_f32x4 s[TF_NKT];
+        tf_f32x4 s[NKT];
         float mx = -INFINITY;
 #pragma unroll
-        for (int j = 0; j < TF_NKT; ++j) {
+        for (int j = 0; j < NKT; ++j) {
             s[j] = (tf_f32x4){0.f, 0.f, 0.f, 0.f};
             if (j < NK) {
                 const f16x8 kf = *(const f16x8*)(sK + (j * 16 + fr) * TF_HD + fg * 8);
@@ -536,7 +539,7 @@ __global__ __launch_bounds__(64 * TF_ATT_WAVES_F) void tf_attn_fwd(TfAttnArgs a)
         mx = tf_quad_rows_max(mx);
         float sum = 0.f;
 #pragma unroll
-        for (int j = 0; j < TF_NKT; ++j)
+        for (int j = 0; j < NKT; ++j)
             if (j < NK) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) { s[j][r] = __expf(s[j][r] - mx); sum += s[j][r]; }
@@ -547,7 +550,7 @@ __global__ __launch_bounds__(64 * TF_ATT_WAVES_F) void tf_attn_fwd(TfAttnArgs a)
         if (fg == 0 && q < L) stat[q] = make_float2(mx, inv);
         tf_f32x4 o[2] = {(tf_f32x4){0.f, 0.f, 0.f, 0.f}, (tf_f32x4){0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
-        for (int j = 0; j < TF_NKT; ++j)
+        for (int j = 0; j < NKT; ++j)
             if (j < NK) {
                 f16x4 p;
 #pragma unroll
@@ -555,7 +558,7 @@ __global__ __launch_bounds__(64 * TF_ATT_WAVES_F) void tf_attn_fwd(TfAttnArgs a)
                 // ctx^T [d][query] += V^T (rows d, k = these 16 keys) x P^T (k = key on the rows: the tile as it stands)
 #pragma unroll
                 for (int dj = 0; dj < 2; ++dj) {
-                    const f16x4 vf = *(const f16x4*)(sVt + (dj * 16 + fr) * TF_LDP + j * 16 + 4 * fg);
+                    const f16x4 vf = *(const f16x4*)(sVt + (dj * 16 + fr) * LDP + j * 16 + 4 * fg);
                     o[dj] = __builtin_amdgcn_mfma_f32_16x16x16f16(vf, p, o[dj], 0, 0, 0);
                 }
             }
@@ -576,22 +579,21 @@ __global__ __launch_bounds__(64 * TF_ATT_WAVES_F) void tf_attn_fwd(TfAttnArgs a)
 //   dQ, dK and the q scaling. The waves of a head take the query tiles in turn; dK and dV are summed over the waves in
 //   a fixed order at the end (wave 1's partial sums go through LDS to wave 0).
 // LDS: v rows | dO rows | dO^T | k^T (rotated) | q^T (rotated) | per wave two 16 x 16 transpose tiles
-#define TF_ATT_STAGE (4 * TF_TP * TF_HD + 3 * TF_HD * TF_LDP)
+template <int TP> __host__ __device__ constexpr int tf_att_stage() { return 4 * TP * TF_HD + 3 * TF_HD * (TP + 8); }
 #define TF_ATT_TRB 4                 // key tiles turned query-major per batch (two 512-byte tiles each)
-__host__ __device__ constexpr size_t tf_attn_bwd_lds() { return (size_t)(TF_ATT_STAGE + TF_ATT_WAVES_B * TF_ATT_TRB * 512) * 2 + TF_TP * sizeof(float2); }
-#define TF_ATT_PART (4 * TF_NKT * 64)     // f32x4 elements of one wave's partial dK^T, dV^T
-static_assert(tf_attn_bwd_lds() >= (size_t)TF_ATT_WAVES_B * (TF_ATT_PART / 2) * 16, "the LDS image also carries the partial sums being swapped");
+template <int TP> __host__ __device__ constexpr size_t tf_attn_bwd_lds() { return (size_t)(tf_att_stage<TP>() + TF_ATT_WAVES_B * TF_ATT_TRB * 512) * 2 + TP * sizeof(float2); }
+static_assert(tf_attn_bwd_lds<128>() >= (size_t)TF_ATT_WAVES_B * (4 * 8 * 64 / 2) * 16 && tf_attn_bwd_lds<256>() <= 160 * 1024, "the LDS image also carries the partial sums being swapped");
 
 // tiles J0 .. J0 + NJ - 1 of a wave's partial sums to / from its LDS slot
-template <int J0, int NJ>
-__device__ __forceinline__ void tf_part_store(tf_f32x4* dst, const tf_f32x4 (&accK)[2][TF_NKT], const tf_f32x4 (&accV)[2][TF_NKT], int lane) {
+template <int J0, int NJ, int NKT>
+__device__ __forceinline__ void tf_part_store(tf_f32x4* dst, const tf_f32x4 (&accK)[2][NKT], const tf_f32x4 (&accV)[2][NKT], int lane) {
 #pragma unroll
     for (int dj = 0; dj < 2; ++dj)
 #pragma unroll
         for (int j = 0; j < NJ; ++j) { dst[((dj * NJ + j) * 2 + 0) * 64 + lane] = accK[dj][J0 + j]; dst[((dj * NJ + j) * 2 + 1) * 64 + lane] = accV[dj][J0 + j]; }
 }
-template <int J0, int NJ>
-__device__ __forceinline__ void tf_part_add(const tf_f32x4* src, tf_f32x4 (&accK)[2][TF_NKT], tf_f32x4 (&accV)[2][TF_NKT], int lane) {
+template <int J0, int NJ, int NKT>
+__device__ __forceinline__ void tf_part_add(const tf_f32x4* src, tf_f32x4 (&accK)[2][NKT], tf_f32x4 (&accV)[2][NKT], int lane) {
 #pragma unroll
     for (int dj = 0; dj < 2; ++dj)
 #pragma unroll
@@ -601,25 +603,27 @@ __device__ __forceinline__ void tf_part_add(const tf_f32x4* src, tf_f32x4 (&accK
             for (int r = 0; r < 4; ++r) { accK[dj][J0 + j][r] += k[r]; accV[dj][J0 + j][r] += v[r]; }
         }
 }
-// wave = 2 HI + LO of four: round 1 swaps with wave ^ 2 (keeps key tiles 4 HI .. 4 HI + 3), round 2 with wave ^ 1
-// (keeps 4 HI + 2 LO, + 1), then the rotary transpose on dK and the stores of the two tiles kept
-template <int HI, int LO>
-__device__ __forceinline__ void tf_attn_finish(tf_f32x4* red, tf_f32x4 (&accK)[2][TF_NKT], tf_f32x4 (&accV)[2][TF_NKT], const TfAttnArgs& a,
-                                               half_t* dq_out, int ld, int D, int L, int NK, int lane) {
-    static_assert(TF_ATT_WAVES_B == 4 && TF_NKT == 8, "two rounds of halving");
-    constexpr int W = 2 * HI + LO, SLOT1 = 4 * 4 * 64, SLOT2 = 2 * 4 * 64;       // f32x4 elements per wave and round
-    tf_part_store<4 * (1 - HI), 4>(red + W * SLOT1, accK, accV, lane);
+// wave = 2 HI + LO of four: round 1 swaps with wave ^ 2 (keeps key tiles HI * NKT/2 ..), round 2 with wave ^ 1 (keeps
+// NKT/4 tiles from HI * NKT/2 + LO * NKT/4), then the rotary transpose on dK and the stores of the tiles kept
+template <int HI, int LO, int NKT>
+__device__ __forceinline__ void tf_attn_finish(tf_f32x4* red, tf_f32x4 (&accK)[2][NKT], tf_f32x4 (&accV)[2][NKT], const TfAttnArgs& a,
+                                               half_t* dq_out, int ld, int D, int L, int NK, int jbase) {
+    static_assert(TF_ATT_WAVES_B == 4 && NKT % 4 == 0, "two rounds of halving");
+    const int lane = threadIdx.x & 63;            // (recomputed: nothing of the prologue stays live across the main loop for this)
+    constexpr int H2 = NKT / 2, H4 = NKT / 4;
+    constexpr int W = 2 * HI + LO, SLOT1 = H2 * 4 * 64, SLOT2 = H4 * 4 * 64;     // f32x4 elements per wave and round
+    tf_part_store<H2 * (1 - HI), H2, NKT>(red + W * SLOT1, accK, accV, lane);
     __syncthreads();
-    tf_part_add<4 * HI, 4>(red + (W ^ 2) * SLOT1, accK, accV, lane);
+    tf_part_add<H2 * HI, H2, NKT>(red + (W ^ 2) * SLOT1, accK, accV, lane);
     __syncthreads();
-    tf_part_store<4 * HI + 2 * (1 - LO), 2>(red + W * SLOT2, accK, accV, lane);
+    tf_part_store<H2 * HI + H4 * (1 - LO), H4, NKT>(red + W * SLOT2, accK, accV, lane);
     __syncthreads();
-    tf_part_add<4 * HI + 2 * LO, 2>(red + (W ^ 1) * SLOT2, accK, accV, lane);
+    tf_part_add<H2 * HI + H4 * LO, H4, NKT>(red + (W ^ 1) * SLOT2, accK, accV, lane);
     const int fr = lane & 15, fg = lane >> 4;
 #pragma unroll
-    for (int jj = 0; jj < 2; ++jj) {
-        constexpr int JB = 4 * HI + 2 * LO;
-        const int j = JB + jj, key = j * 16 + fr;
+    for (int jj = 0; jj < H4; ++jj) {
+        constexpr int JB = H2 * HI + H4 * LO;
+        const int j = jbase + JB + jj, key = j * 16 + fr;                 // (jbase: first key tile of the pass)
         if (j < NK && key < L) {
             f16x4 k1, k2, v1, v2;
             float co[4], si[4];
@@ -641,152 +645,169 @@ __device__ __forceinline__ void tf_attn_finish(tf_f32x4* red, tf_f32x4 (&accK)[2
     }
 }
 
-__global__ __launch_bounds__(64 * TF_ATT_WAVES_B, 2) void tf_attn_bwd(TfAttnArgs a) {
+// TP = 256 (sequences of 129..256 residues, e.g. GFP): the dK / dV accumulators of all 16 key tiles would be 256 registers per
+// lane, so the kernel makes one pass per HALF of the keys (8 key tiles of accumulators, as for TP = 128): every pass
+// re-stages the head (the exchange of partial sums at the end of a pass reuses the LDS image), rebuilds P and dS of
+// all keys (the softmax gradient needs the whole row) and accumulates dK, dV of its own 8 key tiles; dQ is written by
+// the first pass. One workgroup per CU (134 KB of LDS): a rarely used path, correct first.
+template <int TP>
+__global__ __launch_bounds__(64 * TF_ATT_WAVES_B, TP == 128 ? 2 : 1) void tf_attn_bwd(TfAttnArgs a) {   // (second figure: waves per SIMD)
+    constexpr int NKT = TP / 16, LDP = TP + 8, NH = TP / 128, KH = 8;     // key tiles; passes; key tiles per pass
+    constexpr int TRB = TF_ATT_TRB;
     extern __shared__ __attribute__((aligned(16))) unsigned char tf_smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.x / a.H, h = blockIdx.x % a.H;
     const int L = a.L, D = a.D, ld = 3 * D;
     half_t* sV = (half_t*)tf_smem;                             // [TP][32]
-    half_t* sdO = sV + TF_TP * TF_HD;                          // [TP][32]
-    half_t* sdOt = sdO + TF_TP * TF_HD;                        // [32][LDP]
-    half_t* sKt = sdOt + TF_HD * TF_LDP;                       // [32][LDP] rotated k, transposed
-    half_t* sQt = sKt + TF_HD * TF_LDP;                        // [32][LDP] rotated q, transposed
-    half_t* sK = sQt + TF_HD * TF_LDP;                         // [TP][32] rotated k
-    half_t* sQ = sK + TF_TP * TF_HD;                           // [TP][32] rotated q
-    half_t* sT = sQ + TF_TP * TF_HD + wave * TF_ATT_TRB * 512;     // this wave's transpose tiles: TF_ATT_TRB x (dS, P) of 16 x 16
-    float2* sStat = (float2*)((half_t*)tf_smem + TF_ATT_STAGE + TF_ATT_WAVES_B * TF_ATT_TRB * 512);   // [TP] softmax row statistics
+    half_t* sdO = sV + TP * TF_HD;                             // [TP][32]
+    half_t* sdOt = sdO + TP * TF_HD;                           // [32][LDP]
+    half_t* sKt = sdOt + TF_HD * LDP;                          // [32][LDP] rotated k, transposed
+    half_t* sQt = sKt + TF_HD * LDP;                           // [32][LDP] rotated q, transposed
+    half_t* sK = sQt + TF_HD * LDP;                            // [TP][32] rotated k
+    half_t* sQ = sK + TP * TF_HD;                              // [TP][32] rotated q
+    half_t* sT = sQ + TP * TF_HD + wave * TF_ATT_TRB * 512;    // this wave's transpose tiles: TF_ATT_TRB x (dS, P) of 16 x 16
+    float2* sStat = (float2*)((half_t*)tf_smem + tf_att_stage<TP>() + TF_ATT_WAVES_B * TF_ATT_TRB * 512);   // [TP] softmax row statistics
     const half_t* base = a.qkv + (size_t)b * L * ld + h * TF_HD;
     const half_t* dob = a.dctx + (size_t)b * L * D + h * TF_HD;
-    {
-        constexpr int NT = 64 * TF_ATT_WAVES_B;
-        TfRotRaw<NT> rq, rk;
-        TfRope<NT> rp;
-        TfPlainRaw<NT> rv, ro;
-        tf_fetch_plain(base + 2 * D, ld, L, tid, rv);
-        tf_fetch_plain(dob, D, L, tid, ro);
-        tf_fetch_rot(base + D, ld, L, tid, rk);
-        tf_fetch_rot(base, ld, L, tid, rq);
-        tf_fetch_rope(a.rope_cos, a.rope_sin, L, tid, rp);
-        tf_put_plain<false>(rv, L, tid, sV);
-        tf_put_plain<false>(ro, L, tid, sdO);
-        tf_put_plain<true>(ro, L, tid, sdOt);
-        tf_put_rot<true, true>(rk, rp, L, tid, sK, sKt);
-        tf_put_rot<true, true>(rq, rp, L, tid, sQ, sQt);
-        for (int t = tid; t < TF_TP; t += 64 * TF_ATT_WAVES_B) sStat[t] = t < L ? a.stat[(size_t)(b * a.H + h) * L + t] : make_float2(0.f, 0.f);
-    }
-    __syncthreads();
+    half_t* dq_out = a.dqkv + (size_t)b * L * ld + h * TF_HD;
     const int fr = lane & 15, fg = lane >> 4;
     const int NQ = (L + 15) >> 4, NK = NQ;
-    tf_f32x4 accK[2][TF_NKT], accV[2][TF_NKT];
-#pragma unroll
-    for (int dj = 0; dj < 2; ++dj)
-#pragma unroll
-        for (int j = 0; j < TF_NKT; ++j) { accK[dj][j] = (tf_f32x4){0.f, 0.f, 0.f, 0.f}; accV[dj][j] = (tf_f32x4){0.f, 0.f, 0.f, 0.f}; }
-    half_t* dq_out = a.dqkv + (size_t)b * L * ld + h * TF_HD;
     // the transposed read: lane (fr, fg) supplies row 4 fg + (fr >> 2), columns 4 (fr & 3) .. of the tile and receives
     // column fr of rows 4 fg .. 4 fg + 3
     typedef __attribute__((address_space(3))) tf_hfx4* lds_tr_ptr;
     const int tr_off = (4 * fg + (fr >> 2)) * 16 + 4 * (fr & 3);
-    for (int qi = wave; qi < NQ; qi += TF_ATT_WAVES_B) {
-        const int q = qi * 16 + fr;
-        const f16x8 dof = *(const f16x8*)(sdO + (qi * 16 + fr) * TF_HD + fg * 8);
-        const f16x8 qf = *(const f16x8*)(sQ + (qi * 16 + fr) * TF_HD + fg * 8);
-        const float2 st = sStat[qi * 16 + fr];
-        tf_f32x4 dp[TF_NKT];
-        f16x4 pt[TF_NKT], ds[TF_NKT];
-        float delta = 0.f;
+
+    auto pass = [&](auto half_c) {
+        constexpr int HALF = decltype(half_c)::value, J0 = HALF * KH;        // this pass owns key tiles J0 .. J0 + 7
+        {
+            constexpr int NT = 64 * TF_ATT_WAVES_B;
+            TfRotRaw<NT, TP> rq, rk;
+            TfRope<NT, TP> rp;
+            TfPlainRaw<NT, TP> rv, ro;
+            tf_fetch_plain(base + 2 * D, ld, L, tid, rv);
+            tf_fetch_plain(dob, D, L, tid, ro);
+            tf_fetch_rot(base + D, ld, L, tid, rk);
+            tf_fetch_rot(base, ld, L, tid, rq);
+            tf_fetch_rope(a.rope_cos, a.rope_sin, L, tid, rp);
+            if constexpr (HALF > 0) __syncthreads();                         // the previous pass has read its partial sums
+            tf_put_plain<false>(rv, L, tid, sV);
+            tf_put_plain<false>(ro, L, tid, sdO);
+            tf_put_plain<true>(ro, L, tid, sdOt);
+            tf_put_rot<true, true>(rk, rp, L, tid, sK, sKt);
+            tf_put_rot<true, true>(rq, rp, L, tid, sQ, sQt);
+            for (int t = tid; t < TP; t += 64 * TF_ATT_WAVES_B) sStat[t] = t < L ? a.stat[(size_t)(b * a.H + h) * L + t] : make_float2(0.f, 0.f);
+        }
+        __syncthreads();
+        tf_f32x4 accK[2][KH], accV[2][KH];
 #pragma unroll
-        for (int j = 0; j < TF_NKT; ++j) {
-            dp[j] = (tf_f32x4){0.f, 0.f, 0.f, 0.f};
-            pt[j] = (f16x4){0, 0, 0, 0};
-            if (j < NK) {
-                const f16x8 vf = *(const f16x8*)(sV + (j * 16 + fr) * TF_HD + fg * 8);
-                const f16x8 kf = *(const f16x8*)(sK + (j * 16 + fr) * TF_HD + fg * 8);
-                dp[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, dof, dp[j], 0, 0, 0);   // [key][query]
-                // the probabilities again, exactly as the forward rounded them: same product, same exponential, same scale
-                const tf_f32x4 sc = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf, (tf_f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+        for (int dj = 0; dj < 2; ++dj)
+#pragma unroll
+            for (int j = 0; j < KH; ++j) { accK[dj][j] = (tf_f32x4){0.f, 0.f, 0.f, 0.f}; accV[dj][j] = (tf_f32x4){0.f, 0.f, 0.f, 0.f}; }
+        for (int qi = wave; qi < NQ; qi += TF_ATT_WAVES_B) {
+            const int q = qi * 16 + fr;
+            const f16x8 dof = *(const f16x8*)(sdO + (qi * 16 + fr) * TF_HD + fg * 8);
+            const f16x8 qf = *(const f16x8*)(sQ + (qi * 16 + fr) * TF_HD + fg * 8);
+            const float2 st = sStat[qi * 16 + fr];
+            f16x4 pt[NKT], ds[NKT];                                      // ds: dP as the fp16 tensor it is, then dS in place
+            float delta = 0.f;
+            const tf_f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < NKT; ++j) {
+                ds[j] = (f16x4){0, 0, 0, 0};
+                pt[j] = (f16x4){0, 0, 0, 0};
+                if (j < NK) {
+                    const f16x8 vf = *(const f16x8*)(sV + (j * 16 + fr) * TF_HD + fg * 8);
+                    const f16x8 kf = *(const f16x8*)(sK + (j * 16 + fr) * TF_HD + fg * 8);
+                    const tf_f32x4 dp = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, dof, zero4, 0, 0, 0);   // [key][query]
+                    // the probabilities again, exactly as the forward rounded them: same product, same exponential, same scale
+                    const tf_f32x4 sc = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf, zero4, 0, 0, 0);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int key = j * 16 + 4 * fg + r;
+                        const float sv = key < L ? (float)(half_t)sc[r] : -INFINITY;
+                        pt[j][r] = (half_t)(__expf(sv - st.x) * st.y);
+                        ds[j][r] = (half_t)dp[r];
+                        delta += (float)ds[j][r] * (float)pt[j][r];
+                    }
+                }
+            }
+            delta = tf_quad_rows_sum(delta);
+            tf_f32x4 o[2] = {(tf_f32x4){0.f, 0.f, 0.f, 0.f}, (tf_f32x4){0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+            for (int j = 0; j < NKT; ++j)
+                if (j < NK) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) ds[j][r] = (half_t)((float)pt[j][r] * ((float)ds[j][r] - delta));
+                    if constexpr (HALF == 0) {
+                        // dQ^T [d][query] += Kr^T (rows d, k = these keys) x dS^T (k = key on the rows: the tile as it stands)
+#pragma unroll
+                        for (int dj = 0; dj < 2; ++dj) {
+                            const f16x4 kf = *(const f16x4*)(sKt + (dj * 16 + fr) * LDP + j * 16 + 4 * fg);
+                            o[dj] = __builtin_amdgcn_mfma_f32_16x16x16f16(kf, ds[j], o[dj], 0, 0, 0);
+                        }
+                    }
+                }
+            if (HALF == 0 && q < L) {
+                f16x4 o1, o2;         // rotary transpose on (d, d + 16) = (o[0][r], o[1][r]), d = 4 fg + r, then the q scaling
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int key = j * 16 + 4 * fg + r;
-                    const float sv = key < L ? (float)(half_t)sc[r] : -INFINITY;
-                    pt[j][r] = (half_t)(__expf(sv - st.x) * st.y);
-                    dp[j][r] = (float)(half_t)dp[j][r];
-                    delta += dp[j][r] * (float)pt[j][r];
+                    const float co = a.rope_cos[q * 16 + 4 * fg + r], si = a.rope_sin[q * 16 + 4 * fg + r];
+                    const float y1 = (float)(half_t)o[0][r], y2 = (float)(half_t)o[1][r];
+                    o1[r] = (half_t)((float)(half_t)(y1 * co + y2 * si) * a.qscale);
+                    o2[r] = (half_t)((float)(half_t)(y2 * co - y1 * si) * a.qscale);
                 }
+                *(f16x4*)(dq_out + (size_t)q * ld + 4 * fg) = o1;
+                *(f16x4*)(dq_out + (size_t)q * ld + 16 + 4 * fg) = o2;
+            }
+            // dK^T [d][key] += Qr^T (rows d, k = these queries) x dS (k = query on the rows);  dV^T += dO^T x P: the tiles
+            // turned query-major through LDS
+            const f16x4 qf0 = *(const f16x4*)(sQt + (fr) * LDP + qi * 16 + 4 * fg), qf1 = *(const f16x4*)(sQt + (16 + fr) * LDP + qi * 16 + 4 * fg);
+            const f16x4 of0 = *(const f16x4*)(sdOt + (fr) * LDP + qi * 16 + 4 * fg), of1 = *(const f16x4*)(sdOt + (16 + fr) * LDP + qi * 16 + 4 * fg);
+#pragma unroll
+            for (int jb = 0; jb < KH; jb += TRB) {
+                if (J0 + jb >= NK) break;
+#pragma unroll
+                for (int u = 0; u < TRB; ++u)
+                    if (J0 + jb + u < NK) {
+                        *(f16x4*)(sT + u * 512 + fr * 16 + 4 * fg) = ds[J0 + jb + u];
+                        *(f16x4*)(sT + u * 512 + 256 + fr * 16 + 4 * fg) = pt[J0 + jb + u];
+                    }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                tf_hfx4 dsq_[TRB], pq_[TRB];
+#pragma unroll
+                for (int u = 0; u < TRB; ++u) {
+                    dsq_[u] = __builtin_amdgcn_ds_read_tr16_b64_v4f16((lds_tr_ptr)(sT + u * 512 + tr_off));
+                    pq_[u] = __builtin_amdgcn_ds_read_tr16_b64_v4f16((lds_tr_ptr)(sT + u * 512 + 256 + tr_off));
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+                for (int u = 0; u < TRB; ++u)
+                    if (J0 + jb + u < NK) {
+                        const int j = jb + u;
+                        f16x4 dsq, pq;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) { dsq[r] = (half_t)dsq_[u][r]; pq[r] = (half_t)pq_[u][r]; }
+                        accK[0][j] = __builtin_amdgcn_mfma_f32_16x16x16f16(qf0, dsq, accK[0][j], 0, 0, 0);
+                        accK[1][j] = __builtin_amdgcn_mfma_f32_16x16x16f16(qf1, dsq, accK[1][j], 0, 0, 0);
+                        accV[0][j] = __builtin_amdgcn_mfma_f32_16x16x16f16(of0, pq, accV[0][j], 0, 0, 0);
+                        accV[1][j] = __builtin_amdgcn_mfma_f32_16x16x16f16(of1, pq, accV[1][j], 0, 0, 0);
+                    }
             }
         }
-        delta = tf_quad_rows_sum(delta);
-        tf_f32x4 o[2] = {(tf_f32x4){0.f, 0.f, 0.f, 0.f}, (tf_f32x4){0.f, 0.f, 0.f, 0.f}};
-#pragma unroll
-        for (int j = 0; j < TF_NKT; ++j)
-            if (j < NK) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) ds[j][r] = (half_t)((float)pt[j][r] * (dp[j][r] - delta));
-                // dQ^T [d][query] += Kr^T (rows d, k = these keys) x dS^T (k = key on the rows: the tile as it stands)
-#pragma unroll
-                for (int dj = 0; dj < 2; ++dj) {
-                    const f16x4 kf = *(const f16x4*)(sKt + (dj * 16 + fr) * TF_LDP + j * 16 + 4 * fg);
-                    o[dj] = __builtin_amdgcn_mfma_f32_16x16x16f16(kf, ds[j], o[dj], 0, 0, 0);
-                }
-            }
-        if (q < L) {
-            f16x4 o1, o2;         // rotary transpose on (d, d + 16) = (o[0][r], o[1][r]), d = 4 fg + r, then the q scaling
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float co = a.rope_cos[q * 16 + 4 * fg + r], si = a.rope_sin[q * 16 + 4 * fg + r];
-                const float y1 = (float)(half_t)o[0][r], y2 = (float)(half_t)o[1][r];
-                o1[r] = (half_t)((float)(half_t)(y1 * co + y2 * si) * a.qscale);
-                o2[r] = (half_t)((float)(half_t)(y2 * co - y1 * si) * a.qscale);
-            }
-            *(f16x4*)(dq_out + (size_t)q * ld + 4 * fg) = o1;
-            *(f16x4*)(dq_out + (size_t)q * ld + 16 + 4 * fg) = o2;
+        // ---- sum the waves' partial dK^T, dV^T as (w0 + w2) + (w1 + w3), scattered: partners swap the halves they do
+        // not keep, so each wave ends up owning two key tiles and writes them out itself (summed into one wave, the other
+        // three idled through a 128-register add and the store of all eight tiles while the workgroup held its LDS)
+        __syncthreads();
+        tf_f32x4* red = (tf_f32x4*)tf_smem;
+        switch (wave) {
+            case 0: tf_attn_finish<0, 0, KH>(red, accK, accV, a, dq_out, ld, D, L, NK, J0); break;
+            case 1: tf_attn_finish<0, 1, KH>(red, accK, accV, a, dq_out, ld, D, L, NK, J0); break;
+            case 2: tf_attn_finish<1, 0, KH>(red, accK, accV, a, dq_out, ld, D, L, NK, J0); break;
+            default: tf_attn_finish<1, 1, KH>(red, accK, accV, a, dq_out, ld, D, L, NK, J0); break;
         }
-        // dK^T [d][key] += Qr^T (rows d, k = these queries) x dS (k = query on the rows);  dV^T += dO^T x P: the tiles
-        // turned query-major through LDS
-        const f16x4 qf0 = *(const f16x4*)(sQt + (fr) * TF_LDP + qi * 16 + 4 * fg), qf1 = *(const f16x4*)(sQt + (16 + fr) * TF_LDP + qi * 16 + 4 * fg);
-        const f16x4 of0 = *(const f16x4*)(sdOt + (fr) * TF_LDP + qi * 16 + 4 * fg), of1 = *(const f16x4*)(sdOt + (16 + fr) * TF_LDP + qi * 16 + 4 * fg);
-#pragma unroll
-        for (int jb = 0; jb < TF_NKT; jb += TF_ATT_TRB) {
-            if (jb >= NK) break;
-#pragma unroll
-            for (int u = 0; u < TF_ATT_TRB; ++u)
-                if (jb + u < NK) {
-                    *(f16x4*)(sT + u * 512 + fr * 16 + 4 * fg) = ds[jb + u];
-                    *(f16x4*)(sT + u * 512 + 256 + fr * 16 + 4 * fg) = pt[jb + u];
-                }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            tf_hfx4 dsq_[TF_ATT_TRB], pq_[TF_ATT_TRB];
-#pragma unroll
-            for (int u = 0; u < TF_ATT_TRB; ++u) {
-                dsq_[u] = __builtin_amdgcn_ds_read_tr16_b64_v4f16((lds_tr_ptr)(sT + u * 512 + tr_off));
-                pq_[u] = __builtin_amdgcn_ds_read_tr16_b64_v4f16((lds_tr_ptr)(sT + u * 512 + 256 + tr_off));
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-            for (int u = 0; u < TF_ATT_TRB; ++u)
-                if (jb + u < NK) {
-                    const int j = jb + u;
-                    f16x4 dsq, pq;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) { dsq[r] = (half_t)dsq_[u][r]; pq[r] = (half_t)pq_[u][r]; }
-                    accK[0][j] = __builtin_amdgcn_mfma_f32_16x16x16f16(qf0, dsq, accK[0][j], 0, 0, 0);
-                    accK[1][j] = __builtin_amdgcn_mfma_f32_16x16x16f16(qf1, dsq, accK[1][j], 0, 0, 0);
-                    accV[0][j] = __builtin_amdgcn_mfma_f32_16x16x16f16(of0, pq, accV[0][j], 0, 0, 0);
-                    accV[1][j] = __builtin_amdgcn_mfma_f32_16x16x16f16(of1, pq, accV[1][j], 0, 0, 0);
-                }
-        }
-    }
-    // ---- sum the waves' partial dK^T, dV^T as (w0 + w2) + (w1 + w3), scattered: partners swap the halves they do
-    // not keep, so each wave ends up owning two key tiles and writes them out itself (summed into one wave, the other
-    // three idled through a 128-register add and the store of all eight tiles while the workgroup held its LDS)
-    __syncthreads();
-    tf_f32x4* red = (tf_f32x4*)tf_smem;
-    switch (wave) {
-        case 0: tf_attn_finish<0, 0>(red, accK, accV, a, dq_out, ld, D, L, NK, lane); break;
-        case 1: tf_attn_finish<0, 1>(red, accK, accV, a, dq_out, ld, D, L, NK, lane); break;
-        case 2: tf_attn_finish<1, 0>(red, accK, accV, a, dq_out, ld, D, L, NK, lane); break;
-        default: tf_attn_finish<1, 1>(red, accK, accV, a, dq_out, ld, D, L, NK, lane); break;
-    }
+    };
+    pass(std::integral_constant<int, 0>{});
+    if constexpr (NH == 2) pass(std::integral_constant<int, 1>{});
 }
 
 // ------------------------------------------------------------------------------------------------------------

@@ -226,7 +226,8 @@ static int tf_eval(const TfModel* t, TfWork* wk, const uint8_t* rows, int Ls, in
         TFRC(tf_ln(s, false, a.xin, wk->ln_out, w.ln1g, w.ln1b, a.mean1, a.rstd1, M, D));
         TFRC(tf_gemm<TF_EPI_BIAS_QSCALE>(s, wk->ln_out, w.Wqkv, a.qkv, Mp, 3 * D, D, w.bqkv, nullptr, nullptr, qs, D));
         TfAttnArgs at{a.qkv, wk->ctx, a.stat, t->rope_cos, t->rope_sin, nullptr, nullptr, n, L, H, D, qs};
-        hipLaunchKernelGGL(tf_attn_fwd, dim3(n * H), dim3(64 * TF_ATT_WAVES_F), tf_attn_fwd_lds(), s, at);
+        if (L <= 128) hipLaunchKernelGGL(tf_attn_fwd<128>, dim3(n * H), dim3(64 * TF_ATT_WAVES_F), tf_attn_fwd_lds<128>(), s, at);
+        else hipLaunchKernelGGL(tf_attn_fwd<256>, dim3(n * H), dim3(64 * TF_ATT_WAVES_F), tf_attn_fwd_lds<256>(), s, at);
         HIPCHK(hipGetLastError());
         TFRC(tf_gemm<TF_EPI_BIAS_RESID>(s, wk->ctx, w.Wo, a.xmid, Mp, D, D, w.bo, a.xin));
         TFRC(tf_ln(s, false, a.xmid, wk->ln_out, w.ln2g, w.ln2b, a.mean2, a.rstd2, M, D));
@@ -264,7 +265,8 @@ static int tf_eval(const TfModel* t, TfWork* wk, const uint8_t* rows, int Ls, in
         TFRC(tf_ln(s, true, a.xmid, wk->gB, w.ln2g, w.ln2b, a.mean2, a.rstd2, M, D, wk->tmpD, wk->gA));
         TFRC(tf_gemm<TF_EPI_PLAIN>(s, wk->gB, w.WoT, wk->tmpD, Mp, D, D));
         TfAttnArgs at{a.qkv, nullptr, a.stat, t->rope_cos, t->rope_sin, wk->tmpD, wk->dqkv, n, L, H, D, qs};
-        hipLaunchKernelGGL(tf_attn_bwd, dim3(n * H), dim3(64 * TF_ATT_WAVES_B), tf_attn_bwd_lds(), s, at);
+        if (L <= 128) hipLaunchKernelGGL(tf_attn_bwd<128>, dim3(n * H), dim3(64 * TF_ATT_WAVES_B), tf_attn_bwd_lds<128>(), s, at);
+        else hipLaunchKernelGGL(tf_attn_bwd<256>, dim3(n * H), dim3(64 * TF_ATT_WAVES_B), tf_attn_bwd_lds<256>(), s, at);
         HIPCHK(hipGetLastError());
         TFRC(tf_gemm<TF_EPI_PLAIN>(s, wk->dqkv, w.WqkvT, wk->tmpD, Mp, D, 3 * D));
         TFRC(tf_ln(s, true, a.xin, wk->gA, w.ln1g, w.ln1b, a.mean1, a.rstd1, M, D, wk->tmpD, wk->gB, l == 0 ? TF_TOKEN_DROPOUT_SCALE : 1.f));

@@ -43,7 +43,11 @@ def _read(m, what, layer, shape):
 
 
 @pytest.mark.parametrize("L,layers,dim,heads,ffn,n", [(24, 2, 128, 4, 256, 5),        # toy
-                                                       (104, 30, 640, 20, 2560, 3)])    # esm2_t30_150M shapes, UBE4B length
+                                                       (104, 30, 640, 20, 2560, 3),     # esm2_t30_150M shapes, UBE4B length
+                                                       (128, 2, 128, 4, 256, 3),        # the 128-residue attention kernels, full
+                                                       (129, 2, 128, 4, 256, 2),        # the 256-residue kernels, one row past 128
+                                                       (237, 3, 256, 8, 512, 3),        # GFP length: two passes over the key halves
+                                                       (256, 2, 128, 4, 256, 2)])       # the longest sequence supported
 def test_score_and_gradient_vs_oracle(L, layers, dim, heads, ffn, n):
     m, wt, st, _ = _model(L, layers, dim, heads, ffn)
     orc = eo.EsmOracle(st, layers, dim, heads, half_points=True)
