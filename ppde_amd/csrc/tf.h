@@ -26,7 +26,7 @@ typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef float tf_f32x4 __attribute__((ext_vector_type(4)));
 #endif
 
-#define TF_HD 32                 // head width (ESM-2 150M: 640 / 20); the attention kernels are written for it
+#define TF_HD 32                 // default head width (ESM-2 150M: 640 / 20); the attention kernels are instantiated for 32 and 64
 #define TF_VOCAB 33
 #define TF_VOCAB_PAD 128         // logits / token-gradient GEMMs run on a 128-wide padded vocabulary
 #define TF_TOKEN_DROPOUT_SCALE 0.88f
@@ -258,8 +258,7 @@ __global__ __launch_bounds__(64 * NWAVE, 2) void tf_gemm_nt(TfGemmArgs g) {
 // ------------------------------------------------------------------------------------------------------------
 // Layer norm over rows of D halfs (D even), one wavefront per row, statistics in fp32.
 // ------------------------------------------------------------------------------------------------------------
-#define TF_LN_MAXP 8              // (D <= 2 * 64 * TF_LN_MAXP = 1024)
-#define TF_LN_MAXC 2              // 16-byte chunks (8 halfs) per lane
+#define TF_LN_MAXD 1536           // widest row: MAXC = 3 chunks of 8 halfs per lane (the kernels are instantiated for 2 and 3)
 struct TfLnArgs {
     const half_t* x;        // [M][D]
     half_t* y;              // forward output / backward: gradient written here
@@ -278,6 +277,7 @@ __device__ __forceinline__ void tf_load8(const float* p, float (&v)[8]) {
 }
 
 // one wavefront per row; a lane holds up to TF_LN_MAXC chunks of 8 halfs (16-byte loads and stores)
+template <int TF_LN_MAXC>
 __global__ __launch_bounds__(256) void tf_ln_fwd(TfLnArgs a) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (row >= a.M) return;
@@ -323,6 +323,7 @@ __global__ __launch_bounds__(256) void tf_ln_fwd(TfLnArgs a) {
 }
 
 // dx = rstd * (dy*gamma - mean(dy*gamma) - xhat * mean(dy*gamma*xhat));  out = fp16(gres + dx) [* out_scale]
+template <int TF_LN_MAXC>
 __global__ __launch_bounds__(256) void tf_ln_bwd(TfLnArgs a) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (row >= a.M) return;
@@ -396,9 +397,9 @@ __global__ void tf_embed(const uint8_t* __restrict__ idx, int Ls, int sh, int L,
 // transposed read ds_read_b64_tr_b16 (lane maps of both instructions: scripts/probes/mfma_probe.hip).
 // ------------------------------------------------------------------------------------------------------------
 #define TF_ATT_WAVES_F 4           // wavefronts per (chain, head) in the forward ...
-#define TF_ATT_WAVES_B 4           // ... and in the backward (a power of two: the partial dK, dV are summed in a tree)
+#define TF_ATT_WAVES_B 4           // ... and in the backward (the partial dK, dV are summed in two rounds of halving)
 // TP = padded sequence length a kernel instance is written for (128, or 256 for longer proteins such as GFP): TP / 16 key
-// tiles, transposed LDS images with rows of TP + 8 halfs
+// tiles, transposed LDS images with rows of TP + 8 halfs. HD = head width: 32 (esm2_t30_150M) or 64 (esm2_t33_650M).
 #define TF_TP_MAX 256
 typedef __fp16 tf_hfx4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
 
@@ -407,8 +408,8 @@ struct TfAttnArgs {
     half_t* ctx;            // forward out [M][D]
     float2* stat;           // [n][H][L] (row maximum, 1 / row sum) of the softmax: the backward rebuilds the fp16
                             // probabilities from them bit for bit instead of reading 136 MB per layer back
-    const float* rope_cos;  // [L][16]
-    const float* rope_sin;  // [L][16]
+    const float* rope_cos;  // [L][HD / 2]
+    const float* rope_sin;  // [L][HD / 2]
     const half_t* dctx;     // backward in  [M][D]
     half_t* dqkv;           // backward out [M][3D]
     int n, L, H, D;
@@ -419,33 +420,36 @@ struct TfAttnArgs {
 // half), then rotated / transposed into LDS (the put_* half): staged array by array, each round of dependent loads
 // cost a full memory latency with two wavefronts to hide it. Items past L write zeros, so the [TP] tiles need no
 // clearing pass (the 8 pad columns of the transposed images are never read).
-//   rotary item = (t, c in {0,1}): dims 8c..8c+7 and their partners 16+8c..;  plain item = (t, c in {0..3}): dims 8c..
-template <int NTHR, int TP> struct TfRotRaw { static constexpr int R = 2 * TP / NTHR; f16x8 x1[R], x2[R]; static_assert(2 * TP % NTHR == 0, "whole rounds"); };
-template <int NTHR, int TP> struct TfRope { static constexpr int R = 2 * TP / NTHR; float co[R][8], si[R][8]; };
-template <int NTHR, int TP> struct TfPlainRaw { static constexpr int R = 4 * TP / NTHR; f16x8 x[R]; };
-template <int NTHR, int TP>
-__device__ __forceinline__ void tf_fetch_rot(const half_t* src, int ld, int L, int tid, TfRotRaw<NTHR, TP>& w) {
+//   rotary item = (t, c < HD/16): dims 8c..8c+7 and their partners HD/2 + 8c..;  plain item = (t, c < HD/8): dims 8c..
+template <int NTHR, int TP, int HD> struct TfRotRaw { static constexpr int R = (HD / 16) * TP / NTHR; f16x8 x1[R], x2[R]; static_assert((HD / 16) * TP % NTHR == 0, "whole rounds"); };
+template <int NTHR, int TP, int HD> struct TfRope { static constexpr int R = (HD / 16) * TP / NTHR; float co[R][8], si[R][8]; };
+template <int NTHR, int TP, int HD> struct TfPlainRaw { static constexpr int R = (HD / 8) * TP / NTHR; f16x8 x[R]; };
+template <int NTHR, int TP, int HD>
+__device__ __forceinline__ void tf_fetch_rot(const half_t* src, int ld, int L, int tid, TfRotRaw<NTHR, TP, HD>& w) {
+    constexpr int CPR = HD / 16;
 #pragma unroll
-    for (int r = 0; r < 2 * TP / NTHR; ++r) {
-        const int it = tid + r * NTHR, t = min(it >> 1, L - 1), c = it & 1;
+    for (int r = 0; r < CPR * TP / NTHR; ++r) {
+        const int it = tid + r * NTHR, t = min(it / CPR, L - 1), c = it % CPR;
         w.x1[r] = *(const f16x8*)(src + (size_t)t * ld + 8 * c);
-        w.x2[r] = *(const f16x8*)(src + (size_t)t * ld + 16 + 8 * c);
+        w.x2[r] = *(const f16x8*)(src + (size_t)t * ld + HD / 2 + 8 * c);
     }
 }
-template <int NTHR, int TP>
-__device__ __forceinline__ void tf_fetch_rope(const float* rc, const float* rs, int L, int tid, TfRope<NTHR, TP>& w) {
+template <int NTHR, int TP, int HD>
+__device__ __forceinline__ void tf_fetch_rope(const float* rc, const float* rs, int L, int tid, TfRope<NTHR, TP, HD>& w) {
+    constexpr int CPR = HD / 16;
 #pragma unroll
-    for (int r = 0; r < 2 * TP / NTHR; ++r) {
-        const int it = tid + r * NTHR, t = min(it >> 1, L - 1), c = it & 1;
-        tf_load8(rc + t * 16 + 8 * c, w.co[r]);
-        tf_load8(rs + t * 16 + 8 * c, w.si[r]);
+    for (int r = 0; r < CPR * TP / NTHR; ++r) {
+        const int it = tid + r * NTHR, t = min(it / CPR, L - 1), c = it % CPR;
+        tf_load8(rc + t * (HD / 2) + 8 * c, w.co[r]);
+        tf_load8(rs + t * (HD / 2) + 8 * c, w.si[r]);
     }
 }
-template <bool ROWS, bool TRANSPOSED, int NTHR, int TP>
-__device__ __forceinline__ void tf_put_rot(const TfRotRaw<NTHR, TP>& w, const TfRope<NTHR, TP>& rp, int L, int tid, half_t* dst, half_t* dst_t) {
+template <bool ROWS, bool TRANSPOSED, int NTHR, int TP, int HD>
+__device__ __forceinline__ void tf_put_rot(const TfRotRaw<NTHR, TP, HD>& w, const TfRope<NTHR, TP, HD>& rp, int L, int tid, half_t* dst, half_t* dst_t) {
+    constexpr int CPR = HD / 16;
 #pragma unroll
-    for (int r = 0; r < 2 * TP / NTHR; ++r) {
-        const int it = tid + r * NTHR, t = it >> 1, c = it & 1;
+    for (int r = 0; r < CPR * TP / NTHR; ++r) {
+        const int it = tid + r * NTHR, t = it / CPR, c = it % CPR;
         f16x8 y1, y2;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
@@ -453,31 +457,33 @@ __device__ __forceinline__ void tf_put_rot(const TfRotRaw<NTHR, TP>& w, const Tf
             y2[e] = t < L ? (half_t)((float)w.x2[r][e] * rp.co[r][e] + (float)w.x1[r][e] * rp.si[r][e]) : (half_t)0;
         }
         if constexpr (ROWS) {
-            *(f16x8*)(dst + t * TF_HD + 8 * c) = y1;
-            *(f16x8*)(dst + t * TF_HD + 16 + 8 * c) = y2;
+            *(f16x8*)(dst + t * HD + 8 * c) = y1;
+            *(f16x8*)(dst + t * HD + HD / 2 + 8 * c) = y2;
         }
         if constexpr (TRANSPOSED) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) { dst_t[(8 * c + e) * (TP + 8) + t] = y1[e]; dst_t[(16 + 8 * c + e) * (TP + 8) + t] = y2[e]; }
+            for (int e = 0; e < 8; ++e) { dst_t[(8 * c + e) * (TP + 8) + t] = y1[e]; dst_t[(HD / 2 + 8 * c + e) * (TP + 8) + t] = y2[e]; }
         }
     }
 }
-template <int NTHR, int TP>
-__device__ __forceinline__ void tf_fetch_plain(const half_t* src, int ld, int L, int tid, TfPlainRaw<NTHR, TP>& w) {
+template <int NTHR, int TP, int HD>
+__device__ __forceinline__ void tf_fetch_plain(const half_t* src, int ld, int L, int tid, TfPlainRaw<NTHR, TP, HD>& w) {
+    constexpr int CPR = HD / 8;
 #pragma unroll
-    for (int r = 0; r < 4 * TP / NTHR; ++r) {
-        const int it = tid + r * NTHR, t = min(it >> 2, L - 1), c = it & 3;
+    for (int r = 0; r < CPR * TP / NTHR; ++r) {
+        const int it = tid + r * NTHR, t = min(it / CPR, L - 1), c = it % CPR;
         w.x[r] = *(const f16x8*)(src + (size_t)t * ld + 8 * c);
     }
 }
-template <bool TRANSPOSED, int NTHR, int TP>
-__device__ __forceinline__ void tf_put_plain(const TfPlainRaw<NTHR, TP>& w, int L, int tid, half_t* dst) {
+template <bool TRANSPOSED, int NTHR, int TP, int HD>
+__device__ __forceinline__ void tf_put_plain(const TfPlainRaw<NTHR, TP, HD>& w, int L, int tid, half_t* dst) {
+    constexpr int CPR = HD / 8;
 #pragma unroll
-    for (int r = 0; r < 4 * TP / NTHR; ++r) {
-        const int it = tid + r * NTHR, t = it >> 2, c = it & 3;
+    for (int r = 0; r < CPR * TP / NTHR; ++r) {
+        const int it = tid + r * NTHR, t = it / CPR, c = it % CPR;
         f16x8 x = w.x[r];
         if (t >= L) x = (f16x8){0, 0, 0, 0, 0, 0, 0, 0};
-        if constexpr (!TRANSPOSED) *(f16x8*)(dst + t * TF_HD + 8 * c) = x;
+        if constexpr (!TRANSPOSED) *(f16x8*)(dst + t * HD + 8 * c) = x;
         else {
 #pragma unroll
             for (int e = 0; e < 8; ++e) dst[(8 * c + e) * (TP + 8) + t] = x[e];
@@ -487,25 +493,37 @@ __device__ __forceinline__ void tf_put_plain(const TfPlainRaw<NTHR, TP>& w, int 
 __device__ __forceinline__ float tf_quad_rows_max(float v) { return fmaxf(fmaxf(v, __shfl_xor(v, 16)), fmaxf(__shfl_xor(v, 32), __shfl_xor(v, 48))); }
 __device__ __forceinline__ float tf_quad_rows_sum(float v) { v += __shfl_xor(v, 16); v += __shfl_xor(v, 32); return v; }
 
-// LDS: q rows [TP][32] | k rows [TP][32] | v transposed [32][LDP]
-template <int TP> __host__ __device__ constexpr size_t tf_attn_fwd_lds() { return (size_t)(2 * TP * TF_HD + TF_HD * (TP + 8)) * 2; }
+// one 16 x 16 score tile S^T [key][query] = sum over the head width of K rows x Q rows (HD / 32 MFMA k steps)
+template <int HD>
+__device__ __forceinline__ tf_f32x4 tf_tile_kq(const half_t* krows, const half_t* qrows, int fg) {
+    tf_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < HD / 32; ++ks) {
+        const f16x8 kf = *(const f16x8*)(krows + ks * 32 + fg * 8), qf = *(const f16x8*)(qrows + ks * 32 + fg * 8);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf, acc, 0, 0, 0);
+    }
+    return acc;
+}
 
-template <int TP>
+// LDS: q rows [TP][HD] | k rows [TP][HD] | v transposed [HD][LDP]
+template <int TP, int HD> __host__ __device__ constexpr size_t tf_attn_fwd_lds() { return (size_t)(2 * TP * HD + HD * (TP + 8)) * 2; }
+
+template <int TP, int HD>
 __global__ __launch_bounds__(64 * TF_ATT_WAVES_F) void tf_attn_fwd(TfAttnArgs a) {
-    constexpr int NKT = TP / 16, LDP = TP + 8;
+    constexpr int NKT = TP / 16, LDP = TP + 8, ND = HD / 16;
     extern __shared__ __attribute__((aligned(16))) unsigned char tf_smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.x / a.H, h = blockIdx.x % a.H;
     const int L = a.L, D = a.D, ld = 3 * D;
     half_t* sQ = (half_t*)tf_smem;
-    half_t* sK = sQ + TP * TF_HD;
-    half_t* sVt = sK + TP * TF_HD;                 // [32][LDP]
-    const half_t* base = a.qkv + (size_t)b * L * ld + h * TF_HD;
+    half_t* sK = sQ + TP * HD;
+    half_t* sVt = sK + TP * HD;                 // [HD][LDP]
+    const half_t* base = a.qkv + (size_t)b * L * ld + h * HD;
     {
         constexpr int NT = 64 * TF_ATT_WAVES_F;
-        TfRotRaw<NT, TP> rq, rk;
-        TfRope<NT, TP> rp;
-        TfPlainRaw<NT, TP> rv;
+        TfRotRaw<NT, TP, HD> rq, rk;
+        TfRope<NT, TP, HD> rp;
+        TfPlainRaw<NT, TP, HD> rv;
         tf_fetch_rot(base, ld, L, tid, rq);
         tf_fetch_rot(base + D, ld, L, tid, rk);
         tf_fetch_plain(base + 2 * D, ld, L, tid, rv);
@@ -519,15 +537,13 @@ __global__ __launch_bounds__(64 * TF_ATT_WAVES_F) void tf_attn_fwd(TfAttnArgs a)
     const int NQ = (L + 15) >> 4, NK = NQ;
     float2* stat = a.stat + (size_t)(b * a.H + h) * L;
     for (int qi = wave; qi < NQ; qi += TF_ATT_WAVES_F) {
-        const f16x8 qf = *(const f16x8*)(sQ + (qi * 16 + fr) * TF_HD + fg * 8);
         tf_f32x4 s[NKT];
         float mx = -INFINITY;
 #pragma unroll
         for (int j = 0; j < NKT; ++j) {
             s[j] = (tf_f32x4){0.f, 0.f, 0.f, 0.f};
             if (j < NK) {
-                const f16x8 kf = *(const f16x8*)(sK + (j * 16 + fr) * TF_HD + fg * 8);
-                s[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf, s[j], 0, 0, 0);   // [key 4fg+r][query fr]
+                s[j] = tf_tile_kq<HD>(sK + (j * 16 + fr) * HD, sQ + (qi * 16 + fr) * HD, fg);   // [key 4fg+r][query fr]
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int key = j * 16 + 4 * fg + r;
@@ -548,7 +564,9 @@ __global__ __launch_bounds__(64 * TF_ATT_WAVES_F) void tf_attn_fwd(TfAttnArgs a)
         const float inv = 1.0f / sum;
         const int q = qi * 16 + fr;
         if (fg == 0 && q < L) stat[q] = make_float2(mx, inv);
-        tf_f32x4 o[2] = {(tf_f32x4){0.f, 0.f, 0.f, 0.f}, (tf_f32x4){0.f, 0.f, 0.f, 0.f}};
+        tf_f32x4 o[ND];
+#pragma unroll
+        for (int dj = 0; dj < ND; ++dj) o[dj] = (tf_f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int j = 0; j < NKT; ++j)
             if (j < NK) {
@@ -557,45 +575,49 @@ __global__ __launch_bounds__(64 * TF_ATT_WAVES_F) void tf_attn_fwd(TfAttnArgs a)
                 for (int r = 0; r < 4; ++r) p[r] = (half_t)(s[j][r] * inv);
                 // ctx^T [d][query] += V^T (rows d, k = these 16 keys) x P^T (k = key on the rows: the tile as it stands)
 #pragma unroll
-                for (int dj = 0; dj < 2; ++dj) {
+                for (int dj = 0; dj < ND; ++dj) {
                     const f16x4 vf = *(const f16x4*)(sVt + (dj * 16 + fr) * LDP + j * 16 + 4 * fg);
                     o[dj] = __builtin_amdgcn_mfma_f32_16x16x16f16(vf, p, o[dj], 0, 0, 0);
                 }
             }
         if (q < L) {
 #pragma unroll
-            for (int dj = 0; dj < 2; ++dj) {
+            for (int dj = 0; dj < ND; ++dj) {
                 f16x4 ov;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) ov[r] = (half_t)o[dj][r];
-                *(f16x4*)(a.ctx + (size_t)(b * L + q) * D + h * TF_HD + dj * 16 + 4 * fg) = ov;
+                *(f16x4*)(a.ctx + (size_t)(b * L + q) * D + h * HD + dj * 16 + 4 * fg) = ov;
             }
         }
     }
 }
 
-// Backward of the same: dqkv from dctx, P and re-staged q, k, v.
+// Backward of the same: dqkv from dctx, the softmax row statistics and re-staged q, k, v.
 //   dP^T = V dO^T, dS = P o (dP - rowsum(dP o P)), dQ = dS K, dK = dS^T Q, dV = P^T dO; then the rotary transpose on
 //   dQ, dK and the q scaling. The waves of a head take the query tiles in turn; dK and dV are summed over the waves in
-//   a fixed order at the end (wave 1's partial sums go through LDS to wave 0).
-// LDS: v rows | dO rows | dO^T | k^T (rotated) | q^T (rotated) | per wave two 16 x 16 transpose tiles
-template <int TP> __host__ __device__ constexpr int tf_att_stage() { return 4 * TP * TF_HD + 3 * TF_HD * (TP + 8); }
+//   a fixed order at the end.
+// LDS: v rows | dO rows | dO^T | k^T (rotated) | q^T (rotated) | k rows | q rows | per wave transpose tiles | row statistics
+template <int TP, int HD> __host__ __device__ constexpr int tf_att_stage() { return 4 * TP * HD + 3 * HD * (TP + 8); }
 #define TF_ATT_TRB 4                 // key tiles turned query-major per batch (two 512-byte tiles each)
-template <int TP> __host__ __device__ constexpr size_t tf_attn_bwd_lds() { return (size_t)(tf_att_stage<TP>() + TF_ATT_WAVES_B * TF_ATT_TRB * 512) * 2 + TP * sizeof(float2); }
-static_assert(tf_attn_bwd_lds<128>() >= (size_t)TF_ATT_WAVES_B * (4 * 8 * 64 / 2) * 16 && tf_attn_bwd_lds<256>() <= 160 * 1024, "the LDS image also carries the partial sums being swapped");
+template <int TP, int HD> __host__ __device__ constexpr size_t tf_attn_bwd_lds() {
+    const size_t image = (size_t)(tf_att_stage<TP, HD>() + TF_ATT_WAVES_B * TF_ATT_TRB * 512) * 2 + TP * sizeof(float2);
+    const size_t swap = (size_t)TF_ATT_WAVES_B * (4 * 32 / HD) * (HD / 16) * 2 * 1024;   // four waves x half a pass's key tiles x HD/16 x (dK, dV) x 1 KiB
+    return image > swap ? image : swap;
+}
+static_assert(tf_attn_bwd_lds<256, 32>() <= 160 * 1024 && tf_attn_bwd_lds<128, 64>() <= 160 * 1024, "one workgroup must fit a CU's LDS");
 
 // tiles J0 .. J0 + NJ - 1 of a wave's partial sums to / from its LDS slot
-template <int J0, int NJ, int NKT>
-__device__ __forceinline__ void tf_part_store(tf_f32x4* dst, const tf_f32x4 (&accK)[2][NKT], const tf_f32x4 (&accV)[2][NKT], int lane) {
+template <int J0, int NJ, int ND, int NKT>
+__device__ __forceinline__ void tf_part_store(tf_f32x4* dst, const tf_f32x4 (&accK)[ND][NKT], const tf_f32x4 (&accV)[ND][NKT], int lane) {
 #pragma unroll
-    for (int dj = 0; dj < 2; ++dj)
+    for (int dj = 0; dj < ND; ++dj)
 #pragma unroll
         for (int j = 0; j < NJ; ++j) { dst[((dj * NJ + j) * 2 + 0) * 64 + lane] = accK[dj][J0 + j]; dst[((dj * NJ + j) * 2 + 1) * 64 + lane] = accV[dj][J0 + j]; }
 }
-template <int J0, int NJ, int NKT>
-__device__ __forceinline__ void tf_part_add(const tf_f32x4* src, tf_f32x4 (&accK)[2][NKT], tf_f32x4 (&accV)[2][NKT], int lane) {
+template <int J0, int NJ, int ND, int NKT>
+__device__ __forceinline__ void tf_part_add(const tf_f32x4* src, tf_f32x4 (&accK)[ND][NKT], tf_f32x4 (&accV)[ND][NKT], int lane) {
 #pragma unroll
-    for (int dj = 0; dj < 2; ++dj)
+    for (int dj = 0; dj < ND; ++dj)
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
             const tf_f32x4 k = src[((dj * NJ + j) * 2 + 0) * 64 + lane], v = src[((dj * NJ + j) * 2 + 1) * 64 + lane];
@@ -605,71 +627,77 @@ __device__ __forceinline__ void tf_part_add(const tf_f32x4* src, tf_f32x4 (&accK
 }
 // wave = 2 HI + LO of four: round 1 swaps with wave ^ 2 (keeps key tiles HI * NKT/2 ..), round 2 with wave ^ 1 (keeps
 // NKT/4 tiles from HI * NKT/2 + LO * NKT/4), then the rotary transpose on dK and the stores of the tiles kept
-template <int HI, int LO, int NKT>
-__device__ __forceinline__ void tf_attn_finish(tf_f32x4* red, tf_f32x4 (&accK)[2][NKT], tf_f32x4 (&accV)[2][NKT], const TfAttnArgs& a,
+template <int HI, int LO, int ND, int NKT>
+__device__ __forceinline__ void tf_attn_finish(tf_f32x4* red, tf_f32x4 (&accK)[ND][NKT], tf_f32x4 (&accV)[ND][NKT], const TfAttnArgs& a,
                                                half_t* dq_out, int ld, int D, int L, int NK, int jbase) {
     static_assert(TF_ATT_WAVES_B == 4 && NKT % 4 == 0, "two rounds of halving");
     const int lane = threadIdx.x & 63;            // (recomputed: nothing of the prologue stays live across the main loop for this)
-    constexpr int H2 = NKT / 2, H4 = NKT / 4;
-    constexpr int W = 2 * HI + LO, SLOT1 = H2 * 4 * 64, SLOT2 = H4 * 4 * 64;     // f32x4 elements per wave and round
-    tf_part_store<H2 * (1 - HI), H2, NKT>(red + W * SLOT1, accK, accV, lane);
+    constexpr int H2 = NKT / 2, H4 = NKT / 4, NDH = ND / 2, HD = 16 * ND;
+    constexpr int W = 2 * HI + LO, SLOT1 = H2 * 2 * ND * 64, SLOT2 = H4 * 2 * ND * 64;     // f32x4 elements per wave and round
+    tf_part_store<H2 * (1 - HI), H2>(red + W * SLOT1, accK, accV, lane);
     __syncthreads();
-    tf_part_add<H2 * HI, H2, NKT>(red + (W ^ 2) * SLOT1, accK, accV, lane);
+    tf_part_add<H2 * HI, H2>(red + (W ^ 2) * SLOT1, accK, accV, lane);
     __syncthreads();
-    tf_part_store<H2 * HI + H4 * (1 - LO), H4, NKT>(red + W * SLOT2, accK, accV, lane);
+    tf_part_store<H2 * HI + H4 * (1 - LO), H4>(red + W * SLOT2, accK, accV, lane);
     __syncthreads();
-    tf_part_add<H2 * HI + H4 * LO, H4, NKT>(red + (W ^ 1) * SLOT2, accK, accV, lane);
+    tf_part_add<H2 * HI + H4 * LO, H4>(red + (W ^ 1) * SLOT2, accK, accV, lane);
     const int fr = lane & 15, fg = lane >> 4;
 #pragma unroll
     for (int jj = 0; jj < H4; ++jj) {
         constexpr int JB = H2 * HI + H4 * LO;
         const int j = jbase + JB + jj, key = j * 16 + fr;                 // (jbase: first key tile of the pass)
         if (j < NK && key < L) {
-            f16x4 k1, k2, v1, v2;
-            float co[4], si[4];
-            *(float4*)co = *(const float4*)(a.rope_cos + key * 16 + 4 * fg);
-            *(float4*)si = *(const float4*)(a.rope_sin + key * 16 + 4 * fg);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float y1 = (float)(half_t)accK[0][JB + jj][r], y2 = (float)(half_t)accK[1][JB + jj][r];
-                k1[r] = (half_t)(y1 * co[r] + y2 * si[r]);
-                k2[r] = (half_t)(y2 * co[r] - y1 * si[r]);
-                v1[r] = (half_t)accV[0][JB + jj][r];
-                v2[r] = (half_t)accV[1][JB + jj][r];
+            for (int dj = 0; dj < NDH; ++dj) {                            // rotary pairs (d, d + HD/2) = tiles (dj, dj + ND/2)
+                f16x4 k1, k2, v1, v2;
+                float co[4], si[4];
+                *(float4*)co = *(const float4*)(a.rope_cos + key * (HD / 2) + dj * 16 + 4 * fg);
+                *(float4*)si = *(const float4*)(a.rope_sin + key * (HD / 2) + dj * 16 + 4 * fg);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float y1 = (float)(half_t)accK[dj][JB + jj][r], y2 = (float)(half_t)accK[dj + NDH][JB + jj][r];
+                    k1[r] = (half_t)(y1 * co[r] + y2 * si[r]);
+                    k2[r] = (half_t)(y2 * co[r] - y1 * si[r]);
+                    v1[r] = (half_t)accV[dj][JB + jj][r];
+                    v2[r] = (half_t)accV[dj + NDH][JB + jj][r];
+                }
+                *(f16x4*)(dq_out + (size_t)key * ld + D + dj * 16 + 4 * fg) = k1;
+                *(f16x4*)(dq_out + (size_t)key * ld + D + HD / 2 + dj * 16 + 4 * fg) = k2;
+                *(f16x4*)(dq_out + (size_t)key * ld + 2 * D + dj * 16 + 4 * fg) = v1;
+                *(f16x4*)(dq_out + (size_t)key * ld + 2 * D + HD / 2 + dj * 16 + 4 * fg) = v2;
             }
-            *(f16x4*)(dq_out + (size_t)key * ld + D + 4 * fg) = k1;
-            *(f16x4*)(dq_out + (size_t)key * ld + D + 16 + 4 * fg) = k2;
-            *(f16x4*)(dq_out + (size_t)key * ld + 2 * D + 4 * fg) = v1;
-            *(f16x4*)(dq_out + (size_t)key * ld + 2 * D + 16 + 4 * fg) = v2;
         }
     }
 }
 
-// TP = 256 (sequences of 129..256 residues, e.g. GFP): the dK / dV accumulators of all 16 key tiles would be 256 registers per
-// lane, so the kernel makes one pass per HALF of the keys (8 key tiles of accumulators, as for TP = 128): every pass
-// re-stages the head (the exchange of partial sums at the end of a pass reuses the LDS image), rebuilds P and dS of
-// all keys (the softmax gradient needs the whole row) and accumulates dK, dV of its own 8 key tiles; dQ is written by
-// the first pass. One workgroup per CU (134 KB of LDS): a rarely used path, correct first.
-template <int TP>
-__global__ __launch_bounds__(64 * TF_ATT_WAVES_B, TP == 128 ? 2 : 1) void tf_attn_bwd(TfAttnArgs a) {   // (second figure: waves per SIMD)
-    constexpr int NKT = TP / 16, LDP = TP + 8, NH = TP / 128, KH = 8;     // key tiles; passes; key tiles per pass
+// TP = 256 (sequences of 129..256 residues, e.g. GFP) and HD = 64 (esm2_t33_650M): the dK / dV accumulators of all key tiles
+// would be 256 registers per lane, so the kernel makes one pass per HALF of the keys (128 accumulator registers, as
+// for TP = 128, HD = 32): every pass re-stages the head (the exchange of partial sums at the end of a pass reuses the
+// LDS image), rebuilds P and dS of all keys (the softmax gradient needs the whole row) and accumulates dK, dV of its
+// own key tiles; dQ is written by the first pass. One workgroup per CU (134 / 132 KB of LDS): rarely used paths,
+// correct first. (HD = 64 with TP = 256 does not fit a CU's LDS.)
+template <int TP, int HD>
+__global__ __launch_bounds__(64 * TF_ATT_WAVES_B, (TP == 128 && HD == 32) ? 2 : 1) void tf_attn_bwd(TfAttnArgs a) {   // (second figure: waves per SIMD)
+    constexpr int NKT = TP / 16, LDP = TP + 8, ND = HD / 16, NDH = ND / 2;
+    constexpr int KH = 8 * 32 / HD, NH = NKT / KH;              // key tiles per pass (128 accumulator registers), passes
+    static_assert(NH == 1 || NH == 2, "one or two passes");
     constexpr int TRB = TF_ATT_TRB;
     extern __shared__ __attribute__((aligned(16))) unsigned char tf_smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.x / a.H, h = blockIdx.x % a.H;
     const int L = a.L, D = a.D, ld = 3 * D;
-    half_t* sV = (half_t*)tf_smem;                             // [TP][32]
-    half_t* sdO = sV + TP * TF_HD;                             // [TP][32]
-    half_t* sdOt = sdO + TP * TF_HD;                           // [32][LDP]
-    half_t* sKt = sdOt + TF_HD * LDP;                          // [32][LDP] rotated k, transposed
-    half_t* sQt = sKt + TF_HD * LDP;                           // [32][LDP] rotated q, transposed
-    half_t* sK = sQt + TF_HD * LDP;                            // [TP][32] rotated k
-    half_t* sQ = sK + TP * TF_HD;                              // [TP][32] rotated q
-    half_t* sT = sQ + TP * TF_HD + wave * TF_ATT_TRB * 512;    // this wave's transpose tiles: TF_ATT_TRB x (dS, P) of 16 x 16
-    float2* sStat = (float2*)((half_t*)tf_smem + tf_att_stage<TP>() + TF_ATT_WAVES_B * TF_ATT_TRB * 512);   // [TP] softmax row statistics
-    const half_t* base = a.qkv + (size_t)b * L * ld + h * TF_HD;
-    const half_t* dob = a.dctx + (size_t)b * L * D + h * TF_HD;
-    half_t* dq_out = a.dqkv + (size_t)b * L * ld + h * TF_HD;
+    half_t* sV = (half_t*)tf_smem;                             // [TP][HD]
+    half_t* sdO = sV + TP * HD;                                // [TP][HD]
+    half_t* sdOt = sdO + TP * HD;                              // [HD][LDP]
+    half_t* sKt = sdOt + HD * LDP;                             // [HD][LDP] rotated k, transposed
+    half_t* sQt = sKt + HD * LDP;                              // [HD][LDP] rotated q, transposed
+    half_t* sK = sQt + HD * LDP;                               // [TP][HD] rotated k
+    half_t* sQ = sK + TP * HD;                                 // [TP][HD] rotated q
+    half_t* sT = sQ + TP * HD + wave * TF_ATT_TRB * 512;       // this wave's transpose tiles: TF_ATT_TRB x (dS, P) of 16 x 16
+    float2* sStat = (float2*)((half_t*)tf_smem + tf_att_stage<TP, HD>() + TF_ATT_WAVES_B * TF_ATT_TRB * 512);   // [TP] softmax row statistics
+    const half_t* base = a.qkv + (size_t)b * L * ld + h * HD;
+    const half_t* dob = a.dctx + (size_t)b * L * D + h * HD;
+    half_t* dq_out = a.dqkv + (size_t)b * L * ld + h * HD;
     const int fr = lane & 15, fg = lane >> 4;
     const int NQ = (L + 15) >> 4, NK = NQ;
     // the transposed read: lane (fr, fg) supplies row 4 fg + (fr >> 2), columns 4 (fr & 3) .. of the tile and receives
@@ -681,9 +709,9 @@ __global__ __launch_bounds__(64 * TF_ATT_WAVES_B, TP == 128 ? 2 : 1) void tf_att
         constexpr int HALF = decltype(half_c)::value, J0 = HALF * KH;        // this pass owns key tiles J0 .. J0 + 7
         {
             constexpr int NT = 64 * TF_ATT_WAVES_B;
-            TfRotRaw<NT, TP> rq, rk;
-            TfRope<NT, TP> rp;
-            TfPlainRaw<NT, TP> rv, ro;
+            TfRotRaw<NT, TP, HD> rq, rk;
+            TfRope<NT, TP, HD> rp;
+            TfPlainRaw<NT, TP, HD> rv, ro;
             tf_fetch_plain(base + 2 * D, ld, L, tid, rv);
             tf_fetch_plain(dob, D, L, tid, ro);
             tf_fetch_rot(base + D, ld, L, tid, rk);
@@ -698,29 +726,24 @@ __global__ __launch_bounds__(64 * TF_ATT_WAVES_B, TP == 128 ? 2 : 1) void tf_att
             for (int t = tid; t < TP; t += 64 * TF_ATT_WAVES_B) sStat[t] = t < L ? a.stat[(size_t)(b * a.H + h) * L + t] : make_float2(0.f, 0.f);
         }
         __syncthreads();
-        tf_f32x4 accK[2][KH], accV[2][KH];
+        tf_f32x4 accK[ND][KH], accV[ND][KH];
 #pragma unroll
-        for (int dj = 0; dj < 2; ++dj)
+        for (int dj = 0; dj < ND; ++dj)
 #pragma unroll
             for (int j = 0; j < KH; ++j) { accK[dj][j] = (tf_f32x4){0.f, 0.f, 0.f, 0.f}; accV[dj][j] = (tf_f32x4){0.f, 0.f, 0.f, 0.f}; }
         for (int qi = wave; qi < NQ; qi += TF_ATT_WAVES_B) {
             const int q = qi * 16 + fr;
-            const f16x8 dof = *(const f16x8*)(sdO + (qi * 16 + fr) * TF_HD + fg * 8);
-            const f16x8 qf = *(const f16x8*)(sQ + (qi * 16 + fr) * TF_HD + fg * 8);
             const float2 st = sStat[qi * 16 + fr];
             f16x4 pt[NKT], ds[NKT];                                      // ds: dP as the fp16 tensor it is, then dS in place
             float delta = 0.f;
-            const tf_f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int j = 0; j < NKT; ++j) {
                 ds[j] = (f16x4){0, 0, 0, 0};
                 pt[j] = (f16x4){0, 0, 0, 0};
                 if (j < NK) {
-                    const f16x8 vf = *(const f16x8*)(sV + (j * 16 + fr) * TF_HD + fg * 8);
-                    const f16x8 kf = *(const f16x8*)(sK + (j * 16 + fr) * TF_HD + fg * 8);
-                    const tf_f32x4 dp = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, dof, zero4, 0, 0, 0);   // [key][query]
+                    const tf_f32x4 dp = tf_tile_kq<HD>(sV + (j * 16 + fr) * HD, sdO + (qi * 16 + fr) * HD, fg);   // dP^T [key][query]
                     // the probabilities again, exactly as the forward rounded them: same product, same exponential, same scale
-                    const tf_f32x4 sc = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf, zero4, 0, 0, 0);
+                    const tf_f32x4 sc = tf_tile_kq<HD>(sK + (j * 16 + fr) * HD, sQ + (qi * 16 + fr) * HD, fg);
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const int key = j * 16 + 4 * fg + r;
@@ -732,7 +755,9 @@ __global__ __launch_bounds__(64 * TF_ATT_WAVES_B, TP == 128 ? 2 : 1) void tf_att
                 }
             }
             delta = tf_quad_rows_sum(delta);
-            tf_f32x4 o[2] = {(tf_f32x4){0.f, 0.f, 0.f, 0.f}, (tf_f32x4){0.f, 0.f, 0.f, 0.f}};
+            tf_f32x4 o[ND];
+#pragma unroll
+            for (int dj = 0; dj < ND; ++dj) o[dj] = (tf_f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int j = 0; j < NKT; ++j)
                 if (j < NK) {
@@ -741,28 +766,36 @@ __global__ __launch_bounds__(64 * TF_ATT_WAVES_B, TP == 128 ? 2 : 1) void tf_att
                     if constexpr (HALF == 0) {
                         // dQ^T [d][query] += Kr^T (rows d, k = these keys) x dS^T (k = key on the rows: the tile as it stands)
 #pragma unroll
-                        for (int dj = 0; dj < 2; ++dj) {
+                        for (int dj = 0; dj < ND; ++dj) {
                             const f16x4 kf = *(const f16x4*)(sKt + (dj * 16 + fr) * LDP + j * 16 + 4 * fg);
                             o[dj] = __builtin_amdgcn_mfma_f32_16x16x16f16(kf, ds[j], o[dj], 0, 0, 0);
                         }
                     }
                 }
             if (HALF == 0 && q < L) {
-                f16x4 o1, o2;         // rotary transpose on (d, d + 16) = (o[0][r], o[1][r]), d = 4 fg + r, then the q scaling
+                // rotary transpose on (d, d + HD/2) = (o[dj][r], o[dj + ND/2][r]), d = 16 dj + 4 fg + r, then the q scaling
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float co = a.rope_cos[q * 16 + 4 * fg + r], si = a.rope_sin[q * 16 + 4 * fg + r];
-                    const float y1 = (float)(half_t)o[0][r], y2 = (float)(half_t)o[1][r];
-                    o1[r] = (half_t)((float)(half_t)(y1 * co + y2 * si) * a.qscale);
-                    o2[r] = (half_t)((float)(half_t)(y2 * co - y1 * si) * a.qscale);
+                for (int dj = 0; dj < NDH; ++dj) {
+                    f16x4 o1, o2;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float co = a.rope_cos[q * (HD / 2) + dj * 16 + 4 * fg + r], si = a.rope_sin[q * (HD / 2) + dj * 16 + 4 * fg + r];
+                        const float y1 = (float)(half_t)o[dj][r], y2 = (float)(half_t)o[dj + NDH][r];
+                        o1[r] = (half_t)((float)(half_t)(y1 * co + y2 * si) * a.qscale);
+                        o2[r] = (half_t)((float)(half_t)(y2 * co - y1 * si) * a.qscale);
+                    }
+                    *(f16x4*)(dq_out + (size_t)q * ld + dj * 16 + 4 * fg) = o1;
+                    *(f16x4*)(dq_out + (size_t)q * ld + HD / 2 + dj * 16 + 4 * fg) = o2;
                 }
-                *(f16x4*)(dq_out + (size_t)q * ld + 4 * fg) = o1;
-                *(f16x4*)(dq_out + (size_t)q * ld + 16 + 4 * fg) = o2;
             }
             // dK^T [d][key] += Qr^T (rows d, k = these queries) x dS (k = query on the rows);  dV^T += dO^T x P: the tiles
             // turned query-major through LDS
-            const f16x4 qf0 = *(const f16x4*)(sQt + (fr) * LDP + qi * 16 + 4 * fg), qf1 = *(const f16x4*)(sQt + (16 + fr) * LDP + qi * 16 + 4 * fg);
-            const f16x4 of0 = *(const f16x4*)(sdOt + (fr) * LDP + qi * 16 + 4 * fg), of1 = *(const f16x4*)(sdOt + (16 + fr) * LDP + qi * 16 + 4 * fg);
+            f16x4 qfd[ND], ofd[ND];
+#pragma unroll
+            for (int dj = 0; dj < ND; ++dj) {
+                qfd[dj] = *(const f16x4*)(sQt + (dj * 16 + fr) * LDP + qi * 16 + 4 * fg);
+                ofd[dj] = *(const f16x4*)(sdOt + (dj * 16 + fr) * LDP + qi * 16 + 4 * fg);
+            }
 #pragma unroll
             for (int jb = 0; jb < KH; jb += TRB) {
                 if (J0 + jb >= NK) break;
@@ -787,10 +820,11 @@ __global__ __launch_bounds__(64 * TF_ATT_WAVES_B, TP == 128 ? 2 : 1) void tf_att
                         f16x4 dsq, pq;
 #pragma unroll
                         for (int r = 0; r < 4; ++r) { dsq[r] = (half_t)dsq_[u][r]; pq[r] = (half_t)pq_[u][r]; }
-                        accK[0][j] = __builtin_amdgcn_mfma_f32_16x16x16f16(qf0, dsq, accK[0][j], 0, 0, 0);
-                        accK[1][j] = __builtin_amdgcn_mfma_f32_16x16x16f16(qf1, dsq, accK[1][j], 0, 0, 0);
-                        accV[0][j] = __builtin_amdgcn_mfma_f32_16x16x16f16(of0, pq, accV[0][j], 0, 0, 0);
-                        accV[1][j] = __builtin_amdgcn_mfma_f32_16x16x16f16(of1, pq, accV[1][j], 0, 0, 0);
+#pragma unroll
+                        for (int dj = 0; dj < ND; ++dj) {
+                            accK[dj][j] = __builtin_amdgcn_mfma_f32_16x16x16f16(qfd[dj], dsq, accK[dj][j], 0, 0, 0);
+                            accV[dj][j] = __builtin_amdgcn_mfma_f32_16x16x16f16(ofd[dj], pq, accV[dj][j], 0, 0, 0);
+                        }
                     }
             }
         }
@@ -800,10 +834,10 @@ __global__ __launch_bounds__(64 * TF_ATT_WAVES_B, TP == 128 ? 2 : 1) void tf_att
         __syncthreads();
         tf_f32x4* red = (tf_f32x4*)tf_smem;
         switch (wave) {
-            case 0: tf_attn_finish<0, 0, KH>(red, accK, accV, a, dq_out, ld, D, L, NK, J0); break;
-            case 1: tf_attn_finish<0, 1, KH>(red, accK, accV, a, dq_out, ld, D, L, NK, J0); break;
-            case 2: tf_attn_finish<1, 0, KH>(red, accK, accV, a, dq_out, ld, D, L, NK, J0); break;
-            default: tf_attn_finish<1, 1, KH>(red, accK, accV, a, dq_out, ld, D, L, NK, J0); break;
+            case 0: tf_attn_finish<0, 0>(red, accK, accV, a, dq_out, ld, D, L, NK, J0); break;
+            case 1: tf_attn_finish<0, 1>(red, accK, accV, a, dq_out, ld, D, L, NK, J0); break;
+            case 2: tf_attn_finish<1, 0>(red, accK, accV, a, dq_out, ld, D, L, NK, J0); break;
+            default: tf_attn_finish<1, 1>(red, accK, accV, a, dq_out, ld, D, L, NK, J0); break;
         }
     };
     pass(std::integral_constant<int, 0>{});

@@ -9,13 +9,13 @@ struct TfLayerW {
     float *bqkv = nullptr, *bo = nullptr, *b1 = nullptr, *b2 = nullptr, *ln1g = nullptr, *ln1b = nullptr, *ln2g = nullptr, *ln2b = nullptr;
 };
 struct TfModel {
-    int layers = 0, D = 0, H = 0, F = 0, L = 0;
+    int layers = 0, D = 0, H = 0, F = 0, L = 0, HD = TF_HD;     // HD = D / H: 32 or 64
     std::vector<TfLayerW> lw;
     half_t *E16 = nullptr, *E16T = nullptr, *Wd = nullptr, *WdT = nullptr;      // E16 [128][D] (rows >= 33 zero), E16T [D][128]
     float *bd = nullptr, *lnf_g = nullptr, *lnf_b = nullptr, *lnh_g = nullptr, *lnh_b = nullptr, *blm = nullptr;
     int* perm = nullptr;                  // ESM token of each Potts letter
     int* pinv = nullptr;                  // Potts letter of each ESM token (-1: none)
-    float *rope_cos = nullptr, *rope_sin = nullptr;   // [L][16]
+    float *rope_cos = nullptr, *rope_sin = nullptr;   // [L][HD / 2]
     float wt_score = 0.f;
     std::vector<void*> allocs;
     ~TfModel() { for (void* p : allocs) hipFree(p); }
@@ -112,13 +112,14 @@ static int tf_build_model(TfModel* t, int L, const ppde_tf_weights* w) {
     std::vector<int> pinv(TF_VOCAB, -1);
     for (int a = 0; a < 20; ++a) pinv[perm[a]] = a;
     TFUP(pinv, t->pinv);
-    std::vector<float> rc((size_t)L * 16), rs((size_t)L * 16);
+    const int hh = t->HD / 2;
+    std::vector<float> rc((size_t)L * hh), rs((size_t)L * hh);
     for (int p = 0; p < L; ++p)
-        for (int d = 0; d < 16; ++d) {
-            const float inv = 1.0f / powf(10000.0f, (float)(2 * d) / (float)TF_HD);
+        for (int d = 0; d < hh; ++d) {
+            const float inv = 1.0f / powf(10000.0f, (float)(2 * d) / (float)t->HD);
             const float ang = (float)p * inv;            // (fp32 product, as torch.outer of fp32 tensors)
-            rc[(size_t)p * 16 + d] = cosf(ang);
-            rs[(size_t)p * 16 + d] = sinf(ang);
+            rc[(size_t)p * hh + d] = cosf(ang);
+            rs[(size_t)p * hh + d] = sinf(ang);
         }
     TFUP(rc, t->rope_cos);
     TFUP(rs, t->rope_sin);
@@ -188,8 +189,12 @@ static int tf_gemm(hipStream_t s, const half_t* A, const half_t* B, half_t* C, i
 static int tf_ln(hipStream_t s, bool bwd, const half_t* x, half_t* y, const float* gamma, const float* beta, float* mean, float* rstd,
                  int M, int D, const half_t* dy = nullptr, const half_t* gres = nullptr, float out_scale = 1.f) {
     TfLnArgs a{x, y, gamma, beta, mean, rstd, dy, gres, M, D, out_scale};
-    if (bwd) hipLaunchKernelGGL(tf_ln_bwd, dim3((M + 3) / 4), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL(tf_ln_fwd, dim3((M + 3) / 4), dim3(256), 0, s, a);
+    ARGCHK(D % 8 == 0 && D <= TF_LN_MAXD, "layer-norm width");
+    const bool wide = D > 1024;                                      // three 16-byte chunks per lane instead of two
+    if (bwd && wide) hipLaunchKernelGGL(tf_ln_bwd<3>, dim3((M + 3) / 4), dim3(256), 0, s, a);
+    else if (bwd) hipLaunchKernelGGL(tf_ln_bwd<2>, dim3((M + 3) / 4), dim3(256), 0, s, a);
+    else if (wide) hipLaunchKernelGGL(tf_ln_fwd<3>, dim3((M + 3) / 4), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(tf_ln_fwd<2>, dim3((M + 3) / 4), dim3(256), 0, s, a);
     HIPCHK(hipGetLastError());
     return PPDE_OK;
 }
@@ -216,7 +221,7 @@ static thread_local TfEventList* g_tf_fc1_events = nullptr;
 static int tf_eval(const TfModel* t, TfWork* wk, const uint8_t* rows, int Ls, int sh, int n, float* score_out, float* grad_out, hipStream_t s) {
     ARGCHK(n <= wk->n_cap, "transformer workspace too small for this batch");
     const int D = t->D, F = t->F, L = t->L, H = t->H, M = n * L, Mp = (M + 127) & ~127;
-    const float qs = 1.0f / sqrtf((float)TF_HD);
+    const float qs = 1.0f / sqrtf((float)t->HD);
     hipLaunchKernelGGL(tf_embed, dim3(M), dim3(128), 0, s, rows, Ls, sh, L, n, t->perm, t->E16, D, wk->act[0].xin);
     HIPCHK(hipGetLastError());
     for (int l = 0; l < t->layers; ++l) {
@@ -226,8 +231,9 @@ static int tf_eval(const TfModel* t, TfWork* wk, const uint8_t* rows, int Ls, in
         TFRC(tf_ln(s, false, a.xin, wk->ln_out, w.ln1g, w.ln1b, a.mean1, a.rstd1, M, D));
         TFRC(tf_gemm<TF_EPI_BIAS_QSCALE>(s, wk->ln_out, w.Wqkv, a.qkv, Mp, 3 * D, D, w.bqkv, nullptr, nullptr, qs, D));
         TfAttnArgs at{a.qkv, wk->ctx, a.stat, t->rope_cos, t->rope_sin, nullptr, nullptr, n, L, H, D, qs};
-        if (L <= 128) hipLaunchKernelGGL(tf_attn_fwd<128>, dim3(n * H), dim3(64 * TF_ATT_WAVES_F), tf_attn_fwd_lds<128>(), s, at);
-        else hipLaunchKernelGGL(tf_attn_fwd<256>, dim3(n * H), dim3(64 * TF_ATT_WAVES_F), tf_attn_fwd_lds<256>(), s, at);
+        if (t->HD == 64) hipLaunchKernelGGL((tf_attn_fwd<128, 64>), dim3(n * H), dim3(64 * TF_ATT_WAVES_F), (tf_attn_fwd_lds<128, 64>()), s, at);
+        else if (L <= 128) hipLaunchKernelGGL((tf_attn_fwd<128, 32>), dim3(n * H), dim3(64 * TF_ATT_WAVES_F), (tf_attn_fwd_lds<128, 32>()), s, at);
+        else hipLaunchKernelGGL((tf_attn_fwd<256, 32>), dim3(n * H), dim3(64 * TF_ATT_WAVES_F), (tf_attn_fwd_lds<256, 32>()), s, at);
         HIPCHK(hipGetLastError());
         TFRC(tf_gemm<TF_EPI_BIAS_RESID>(s, wk->ctx, w.Wo, a.xmid, Mp, D, D, w.bo, a.xin));
         TFRC(tf_ln(s, false, a.xmid, wk->ln_out, w.ln2g, w.ln2b, a.mean2, a.rstd2, M, D));
@@ -265,8 +271,9 @@ static int tf_eval(const TfModel* t, TfWork* wk, const uint8_t* rows, int Ls, in
         TFRC(tf_ln(s, true, a.xmid, wk->gB, w.ln2g, w.ln2b, a.mean2, a.rstd2, M, D, wk->tmpD, wk->gA));
         TFRC(tf_gemm<TF_EPI_PLAIN>(s, wk->gB, w.WoT, wk->tmpD, Mp, D, D));
         TfAttnArgs at{a.qkv, nullptr, a.stat, t->rope_cos, t->rope_sin, wk->tmpD, wk->dqkv, n, L, H, D, qs};
-        if (L <= 128) hipLaunchKernelGGL(tf_attn_bwd<128>, dim3(n * H), dim3(64 * TF_ATT_WAVES_B), tf_attn_bwd_lds<128>(), s, at);
-        else hipLaunchKernelGGL(tf_attn_bwd<256>, dim3(n * H), dim3(64 * TF_ATT_WAVES_B), tf_attn_bwd_lds<256>(), s, at);
+        if (t->HD == 64) hipLaunchKernelGGL((tf_attn_bwd<128, 64>), dim3(n * H), dim3(64 * TF_ATT_WAVES_B), (tf_attn_bwd_lds<128, 64>()), s, at);
+        else if (L <= 128) hipLaunchKernelGGL((tf_attn_bwd<128, 32>), dim3(n * H), dim3(64 * TF_ATT_WAVES_B), (tf_attn_bwd_lds<128, 32>()), s, at);
+        else hipLaunchKernelGGL((tf_attn_bwd<256, 32>), dim3(n * H), dim3(64 * TF_ATT_WAVES_B), (tf_attn_bwd_lds<256, 32>()), s, at);
         HIPCHK(hipGetLastError());
         TFRC(tf_gemm<TF_EPI_PLAIN>(s, wk->dqkv, w.WqkvT, wk->tmpD, Mp, D, 3 * D));
         TFRC(tf_ln(s, true, a.xin, wk->gA, w.ln1g, w.ln1b, a.mean1, a.rstd1, M, D, wk->tmpD, wk->gB, l == 0 ? TF_TOKEN_DROPOUT_SCALE : 1.f));

@@ -47,7 +47,10 @@ def _read(m, what, layer, shape):
                                                        (128, 2, 128, 4, 256, 3),        # the 128-residue attention kernels, full
                                                        (129, 2, 128, 4, 256, 2),        # the 256-residue kernels, one row past 128
                                                        (237, 3, 256, 8, 512, 3),        # GFP length: two passes over the key halves
-                                                       (256, 2, 128, 4, 256, 2)])       # the longest sequence supported
+                                                       (256, 2, 128, 4, 256, 2),        # the longest sequence supported
+                                                       (24, 2, 256, 4, 512, 4),         # head width 64, toy
+                                                       (128, 2, 256, 4, 512, 2),        # head width 64, full length
+                                                       (104, 33, 1280, 20, 5120, 2)])   # esm2_t33_650M shapes (transformer-L)
 def test_score_and_gradient_vs_oracle(L, layers, dim, heads, ffn, n):
     m, wt, st, _ = _model(L, layers, dim, heads, ffn)
     orc = eo.EsmOracle(st, layers, dim, heads, half_points=True)
