@@ -30,7 +30,8 @@
  *     pieces per wave;
  *   - supervised expert: 1..4 networks of one shape, kernel size 1..8, embedding width F <= 512
  *     for the single-launch kernel (wider or longer networks take the chunked kernels);
- *   - transformer expert: head width 32 or 64, dim and ffn multiples of 128, dim <= 1536, L <= 256 (128 at head width 64);
+ *   - transformer expert: head width 24, 32 or 64, dim a multiple of 8 (<= 1536; padded to a multiple of 128 internally), ffn a
+ *     multiple of 128, L <= 256 (128 at head width 64);
  *   - ppde_pas_length 1..64; chain_offset + n_chains < 2^32.
  */
 #ifndef PPDE_HIP_H
@@ -88,9 +89,9 @@ int ppde_model_set_cnn(ppde_model* m, int n_nets, int C, int K, int F,
  * evaluated on one-hot input, score = sum x * log_softmax(logits) minus the wild type's (nets.py:219-240), under the
  * reference's autocast (fp16 matmuls, fp32 statistics). The reference takes the model from the third-party
  * `esm_one_hot` package + torch hub; here the caller passes ESM-2's parameters (fp32, host), named as in
- * facebookresearch/esm's ESM2: per-layer arrays have n_layers entries. Written for head widths 32 and 64
- * (esm2_t30_150M: dim 640, 20 heads, ffn 2560; esm2_t33_650M: 1280, 20, 5120), dim and ffn multiples of 128, L <= 256
- * (128 at head width 64). Also evaluates the wild
+ * facebookresearch/esm's ESM2: per-layer arrays have n_layers entries. Written for head widths 24, 32 and 64
+ * (esm2_t12_35M: dim 480, 20 heads, ffn 1920; esm2_t30_150M: 640, 20, 2560; esm2_t33_650M: 1280, 20, 5120), ffn a multiple
+ * of 128, L <= 256 (128 at head width 64). Also evaluates the wild
  * type's score. */
 typedef struct {
     const float* embed;                 /* embed_tokens.weight [33][dim] (also the tied LM-head projection) */

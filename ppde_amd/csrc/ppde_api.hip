@@ -468,15 +468,15 @@ int ppde_model_set_lamda(ppde_model* m, float lamda) {
 int ppde_model_set_transformer(ppde_model* m, int n_layers, int dim, int heads, int ffn, const ppde_tf_weights* w) {
     ARGCHK(m && w, "null argument");
     ARGCHK(n_layers >= 1 && n_layers <= 64, "1..64 transformer layers");
-    ARGCHK(heads >= 1 && (dim == heads * 32 || dim == heads * 64),
-           "the attention kernels are written for head widths 32 and 64 (ESM-2 150M: 640 / 20, 650M: 1280 / 20)");
-    ARGCHK(dim % 128 == 0 && ffn % 128 == 0 && dim <= TF_LN_MAXD, "dim and ffn must be multiples of 128, dim <= 1536");
+    ARGCHK(heads >= 1 && (dim == heads * 24 || dim == heads * 32 || dim == heads * 64),
+           "the attention kernels are written for head widths 24, 32 and 64 (ESM-2 35M: 480 / 20, 150M: 640 / 20, 650M: 1280 / 20)");
+    ARGCHK(dim % 8 == 0 && ffn % 128 == 0 && dim <= TF_LN_MAXD, "dim must be a multiple of 8 (<= 1536), ffn a multiple of 128");
     ARGCHK(m->L <= (dim == heads * 64 ? 128 : TF_TP_MAX), "the transformer expert handles sequences of up to 256 residues (128 at head width 64)");
     HIPCHK(hipSetDevice(m->device));
     delete m->tf; m->tf = nullptr;
     delete m->s_tfw; m->s_tfw = nullptr;
     TfModel* t = new TfModel();
-    t->layers = n_layers; t->D = dim; t->H = heads; t->F = ffn; t->HD = dim / heads;
+    t->layers = n_layers; t->Dr = dim; t->D = (dim + 127) & ~127; t->H = heads; t->F = ffn; t->HD = dim / heads;
     int rc = tf_build_model(t, m->L, w);
     if (rc) { delete t; return rc; }
     // wild type's local score (nets.py:188) with the kernels that evaluate every other state

@@ -268,7 +268,8 @@ struct TfLnArgs {
     float* rstd;            // [M]
     const half_t* dy;       // backward: gradient w.r.t. the layer-norm output
     const half_t* gres;     // backward: gradient arriving on the residual path (may be NULL)
-    int M, D;
+    int M, D;               // D = normalised width
+    int ld;                 // row stride in halfs (>= D: the 35M model's 480 columns live in rows of 512)
     float out_scale;        // backward: the sum is rounded to fp16, then multiplied by this (1 = no-op) and rounded again
 };
 __device__ __forceinline__ void tf_load8(const float* p, float (&v)[8]) {
@@ -282,7 +283,7 @@ __global__ __launch_bounds__(256) void tf_ln_fwd(TfLnArgs a) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (row >= a.M) return;
     const int nc = a.D >> 3;
-    const f16x8* xr = (const f16x8*)(a.x + (size_t)row * a.D);
+    const f16x8* xr = (const f16x8*)(a.x + (size_t)row * a.ld);
     float v[TF_LN_MAXC][8];
     float s = 0.f;
 #pragma unroll
@@ -305,7 +306,7 @@ __global__ __launch_bounds__(256) void tf_ln_fwd(TfLnArgs a) {
             for (int e = 0; e < 8; ++e) { const float d = v[i][e] - mean; q += d * d; }
         }
     const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)a.D + 1e-5f);
-    f16x8* yr = (f16x8*)(a.y + (size_t)row * a.D);
+    f16x8* yr = (f16x8*)(a.y + (size_t)row * a.ld);
 #pragma unroll
     for (int i = 0; i < TF_LN_MAXC; ++i) {
         const int c = lane + 64 * i;
@@ -328,9 +329,9 @@ __global__ __launch_bounds__(256) void tf_ln_bwd(TfLnArgs a) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (row >= a.M) return;
     const int nc = a.D >> 3;
-    const f16x8* xr = (const f16x8*)(a.x + (size_t)row * a.D);
-    const f16x8* dr = (const f16x8*)(a.dy + (size_t)row * a.D);
-    const f16x8* rr = a.gres ? (const f16x8*)(a.gres + (size_t)row * a.D) : nullptr;
+    const f16x8* xr = (const f16x8*)(a.x + (size_t)row * a.ld);
+    const f16x8* dr = (const f16x8*)(a.dy + (size_t)row * a.ld);
+    const f16x8* rr = a.gres ? (const f16x8*)(a.gres + (size_t)row * a.ld) : nullptr;
     const float mean = a.mean[row], rstd = a.rstd[row];
     float xh[TF_LN_MAXC][8], gg[TF_LN_MAXC][8], rs[TF_LN_MAXC][8];
     float s1 = 0.f, s2 = 0.f;
@@ -356,7 +357,7 @@ __global__ __launch_bounds__(256) void tf_ln_bwd(TfLnArgs a) {
         }
     }
     const float m1 = wave_sum(s1) / (float)a.D, m2 = wave_sum(s2) / (float)a.D;
-    f16x8* yr = (f16x8*)(a.y + (size_t)row * a.D);
+    f16x8* yr = (f16x8*)(a.y + (size_t)row * a.ld);
 #pragma unroll
     for (int i = 0; i < TF_LN_MAXC; ++i) {
         const int c = lane + 64 * i;
@@ -490,6 +491,86 @@ __device__ __forceinline__ void tf_put_plain(const TfPlainRaw<NTHR, TP, HD>& w, 
         }
     }
 }
+// Head width 24 (esm2_t12_35M). In LDS a head is 32 wide with its two rotary halves at columns 0..11 and 16..27 (columns
+// 12..15 and 28..31 zero): scores, P V and every gradient product are sums over the head width, so a consistent
+// permutation + zero padding of q, k, v, dO changes nothing, the rotary partner of column d' stays d' + 16 as for width
+// 32, and groups of four columns stay groups of four in global memory (tf_gcol). Item = one row (48 bytes, three loads).
+constexpr int tf_lds_width(int HD) { return HD == 24 ? 32 : HD; }
+// global column (within the head) of LDS columns 16 dj + 4 fg .. + 3, or -1 for padding; the rope table column likewise
+template <int HD> __device__ __forceinline__ int tf_gcol(int dj, int fg) { return HD == 24 ? (fg < 3 ? 12 * dj + 4 * fg : -1) : 16 * dj + 4 * fg; }
+template <int HD> __device__ __forceinline__ int tf_rope_col(int dj, int fg) { return HD == 24 ? 4 * fg : 16 * dj + 4 * fg; }
+template <int NTHR, int TP> struct TfRow24 { static constexpr int R = (TP + NTHR - 1) / NTHR; f16x8 a[R], b[R], c[R]; };
+template <int NTHR, int TP> struct TfRope24 { static constexpr int R = (TP + NTHR - 1) / NTHR; float co[R][12], si[R][12]; };
+template <int NTHR, int TP>
+__device__ __forceinline__ void tf_fetch24(const half_t* src, int ld, int L, int tid, TfRow24<NTHR, TP>& w) {
+#pragma unroll
+    for (int r = 0; r < (TP + NTHR - 1) / NTHR; ++r) {
+        const int t = min(tid + r * NTHR, L - 1);
+        w.a[r] = *(const f16x8*)(src + (size_t)t * ld);
+        w.b[r] = *(const f16x8*)(src + (size_t)t * ld + 8);
+        w.c[r] = *(const f16x8*)(src + (size_t)t * ld + 16);
+    }
+}
+template <int NTHR, int TP>
+__device__ __forceinline__ void tf_fetch_rope24(const float* rc, const float* rs, int L, int tid, TfRope24<NTHR, TP>& w) {
+#pragma unroll
+    for (int r = 0; r < (TP + NTHR - 1) / NTHR; ++r) {
+        const int t = min(tid + r * NTHR, L - 1);
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            const float4 c4 = *(const float4*)(rc + t * 12 + 4 * q), s4 = *(const float4*)(rs + t * 12 + 4 * q);
+            w.co[r][4 * q] = c4.x; w.co[r][4 * q + 1] = c4.y; w.co[r][4 * q + 2] = c4.z; w.co[r][4 * q + 3] = c4.w;
+            w.si[r][4 * q] = s4.x; w.si[r][4 * q + 1] = s4.y; w.si[r][4 * q + 2] = s4.z; w.si[r][4 * q + 3] = s4.w;
+        }
+    }
+}
+// the 32-wide LDS image of a 24-wide row v[24]: row-major and / or transposed
+template <bool ROWS, bool TRANSPOSED, int TP>
+__device__ __forceinline__ void tf_put_row24(const half_t (&v)[24], int t, half_t* dst, half_t* dst_t) {
+    if constexpr (ROWS) {
+        f16x8 o[4];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { o[0][e] = v[e]; o[1][e] = e < 4 ? v[8 + e] : (half_t)0; o[2][e] = v[12 + e]; o[3][e] = e < 4 ? v[20 + e] : (half_t)0; }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) *(f16x8*)(dst + t * 32 + 8 * q) = o[q];
+    }
+    if constexpr (TRANSPOSED) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            dst_t[e * (TP + 8) + t] = e < 12 ? v[e] : (half_t)0;
+            dst_t[(16 + e) * (TP + 8) + t] = e < 12 ? v[12 + e] : (half_t)0;
+        }
+    }
+}
+template <bool ROWS, bool TRANSPOSED, int NTHR, int TP>
+__device__ __forceinline__ void tf_put_rot24(const TfRow24<NTHR, TP>& w, const TfRope24<NTHR, TP>& rp, int L, int tid, half_t* dst, half_t* dst_t) {
+#pragma unroll
+    for (int r = 0; r < (TP + NTHR - 1) / NTHR; ++r) {
+        const int t = tid + r * NTHR;
+        if (t >= TP) continue;
+        half_t x[24], y[24];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { x[e] = w.a[r][e]; x[8 + e] = w.b[r][e]; x[16 + e] = w.c[r][e]; }
+#pragma unroll
+        for (int e = 0; e < 12; ++e) {
+            y[e] = t < L ? (half_t)((float)x[e] * rp.co[r][e] - (float)x[12 + e] * rp.si[r][e]) : (half_t)0;
+            y[12 + e] = t < L ? (half_t)((float)x[12 + e] * rp.co[r][e] + (float)x[e] * rp.si[r][e]) : (half_t)0;
+        }
+        tf_put_row24<ROWS, TRANSPOSED, TP>(y, t, dst, dst_t);
+    }
+}
+template <bool TRANSPOSED, int NTHR, int TP>
+__device__ __forceinline__ void tf_put_plain24(const TfRow24<NTHR, TP>& w, int L, int tid, half_t* dst) {
+#pragma unroll
+    for (int r = 0; r < (TP + NTHR - 1) / NTHR; ++r) {
+        const int t = tid + r * NTHR;
+        if (t >= TP) continue;
+        half_t x[24];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { x[e] = t < L ? w.a[r][e] : (half_t)0; x[8 + e] = t < L ? w.b[r][e] : (half_t)0; x[16 + e] = t < L ? w.c[r][e] : (half_t)0; }
+        tf_put_row24<!TRANSPOSED, TRANSPOSED, TP>(x, t, dst, dst);
+    }
+}
 __device__ __forceinline__ float tf_quad_rows_max(float v) { return fmaxf(fmaxf(v, __shfl_xor(v, 16)), fmaxf(__shfl_xor(v, 32), __shfl_xor(v, 48))); }
 __device__ __forceinline__ float tf_quad_rows_sum(float v) { v += __shfl_xor(v, 16); v += __shfl_xor(v, 32); return v; }
 
@@ -506,20 +587,32 @@ __device__ __forceinline__ tf_f32x4 tf_tile_kq(const half_t* krows, const half_t
 }
 
 // LDS: q rows [TP][HD] | k rows [TP][HD] | v transposed [HD][LDP]
-template <int TP, int HD> __host__ __device__ constexpr size_t tf_attn_fwd_lds() { return (size_t)(2 * TP * HD + HD * (TP + 8)) * 2; }
+template <int TP, int HD> __host__ __device__ constexpr size_t tf_attn_fwd_lds() { return (size_t)(2 * TP * tf_lds_width(HD) + tf_lds_width(HD) * (TP + 8)) * 2; }
 
 template <int TP, int HD>
 __global__ __launch_bounds__(64 * TF_ATT_WAVES_F) void tf_attn_fwd(TfAttnArgs a) {
-    constexpr int NKT = TP / 16, LDP = TP + 8, ND = HD / 16;
+    constexpr int HL = tf_lds_width(HD);          // head width in LDS (24 -> 32)
+    constexpr int NKT = TP / 16, LDP = TP + 8, ND = HL / 16;
     extern __shared__ __attribute__((aligned(16))) unsigned char tf_smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.x / a.H, h = blockIdx.x % a.H;
     const int L = a.L, D = a.D, ld = 3 * D;
     half_t* sQ = (half_t*)tf_smem;
-    half_t* sK = sQ + TP * HD;
-    half_t* sVt = sK + TP * HD;                 // [HD][LDP]
+    half_t* sK = sQ + TP * HL;
+    half_t* sVt = sK + TP * HL;                 // [HL][LDP]
     const half_t* base = a.qkv + (size_t)b * L * ld + h * HD;
-    {
+    if constexpr (HD == 24) {
+        constexpr int NT = 64 * TF_ATT_WAVES_F;
+        TfRow24<NT, TP> rq, rk, rv;
+        TfRope24<NT, TP> rp;
+        tf_fetch24(base, ld, L, tid, rq);
+        tf_fetch24(base + D, ld, L, tid, rk);
+        tf_fetch24(base + 2 * D, ld, L, tid, rv);
+        tf_fetch_rope24(a.rope_cos, a.rope_sin, L, tid, rp);
+        tf_put_rot24<true, false>(rq, rp, L, tid, sQ, nullptr);
+        tf_put_rot24<true, false>(rk, rp, L, tid, sK, nullptr);
+        tf_put_plain24<true>(rv, L, tid, sVt);
+    } else {
         constexpr int NT = 64 * TF_ATT_WAVES_F;
         TfRotRaw<NT, TP, HD> rq, rk;
         TfRope<NT, TP, HD> rp;
@@ -543,7 +636,7 @@ __global__ __launch_bounds__(64 * TF_ATT_WAVES_F) void tf_attn_fwd(TfAttnArgs a)
         for (int j = 0; j < NKT; ++j) {
             s[j] = (tf_f32x4){0.f, 0.f, 0.f, 0.f};
             if (j < NK) {
-                s[j] = tf_tile_kq<HD>(sK + (j * 16 + fr) * HD, sQ + (qi * 16 + fr) * HD, fg);   // [key 4fg+r][query fr]
+                s[j] = tf_tile_kq<HL>(sK + (j * 16 + fr) * HL, sQ + (qi * 16 + fr) * HL, fg);   // [key 4fg+r][query fr]
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int key = j * 16 + 4 * fg + r;
@@ -586,7 +679,8 @@ __global__ __launch_bounds__(64 * TF_ATT_WAVES_F) void tf_attn_fwd(TfAttnArgs a)
                 f16x4 ov;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) ov[r] = (half_t)o[dj][r];
-                *(f16x4*)(a.ctx + (size_t)(b * L + q) * D + h * HD + dj * 16 + 4 * fg) = ov;
+                const int col = tf_gcol<HD>(dj, fg);
+                if (col >= 0) *(f16x4*)(a.ctx + (size_t)(b * L + q) * D + h * HD + col) = ov;
             }
         }
     }
@@ -597,11 +691,11 @@ __global__ __launch_bounds__(64 * TF_ATT_WAVES_F) void tf_attn_fwd(TfAttnArgs a)
 //   dQ, dK and the q scaling. The waves of a head take the query tiles in turn; dK and dV are summed over the waves in
 //   a fixed order at the end.
 // LDS: v rows | dO rows | dO^T | k^T (rotated) | q^T (rotated) | k rows | q rows | per wave transpose tiles | row statistics
-template <int TP, int HD> __host__ __device__ constexpr int tf_att_stage() { return 4 * TP * HD + 3 * HD * (TP + 8); }
+template <int TP, int HD> __host__ __device__ constexpr int tf_att_stage() { return 4 * TP * tf_lds_width(HD) + 3 * tf_lds_width(HD) * (TP + 8); }
 #define TF_ATT_TRB 4                 // key tiles turned query-major per batch (two 512-byte tiles each)
 template <int TP, int HD> __host__ __device__ constexpr size_t tf_attn_bwd_lds() {
     const size_t image = (size_t)(tf_att_stage<TP, HD>() + TF_ATT_WAVES_B * TF_ATT_TRB * 512) * 2 + TP * sizeof(float2);
-    const size_t swap = (size_t)TF_ATT_WAVES_B * (4 * 32 / HD) * (HD / 16) * 2 * 1024;   // four waves x half a pass's key tiles x HD/16 x (dK, dV) x 1 KiB
+    const size_t swap = (size_t)TF_ATT_WAVES_B * (4 * 32 / tf_lds_width(HD)) * (tf_lds_width(HD) / 16) * 2 * 1024;   // four waves x half a pass's key tiles x HD/16 x (dK, dV) x 1 KiB
     return image > swap ? image : swap;
 }
 static_assert(tf_attn_bwd_lds<256, 32>() <= 160 * 1024 && tf_attn_bwd_lds<128, 64>() <= 160 * 1024, "one workgroup must fit a CU's LDS");
@@ -627,12 +721,12 @@ __device__ __forceinline__ void tf_part_add(const tf_f32x4* src, tf_f32x4 (&accK
 }
 // wave = 2 HI + LO of four: round 1 swaps with wave ^ 2 (keeps key tiles HI * NKT/2 ..), round 2 with wave ^ 1 (keeps
 // NKT/4 tiles from HI * NKT/2 + LO * NKT/4), then the rotary transpose on dK and the stores of the tiles kept
-template <int HI, int LO, int ND, int NKT>
+template <int HI, int LO, int HD, int ND, int NKT>
 __device__ __forceinline__ void tf_attn_finish(tf_f32x4* red, tf_f32x4 (&accK)[ND][NKT], tf_f32x4 (&accV)[ND][NKT], const TfAttnArgs& a,
                                                half_t* dq_out, int ld, int D, int L, int NK, int jbase) {
     static_assert(TF_ATT_WAVES_B == 4 && NKT % 4 == 0, "two rounds of halving");
     const int lane = threadIdx.x & 63;            // (recomputed: nothing of the prologue stays live across the main loop for this)
-    constexpr int H2 = NKT / 2, H4 = NKT / 4, NDH = ND / 2, HD = 16 * ND;
+    constexpr int H2 = NKT / 2, H4 = NKT / 4, NDH = ND / 2;
     constexpr int W = 2 * HI + LO, SLOT1 = H2 * 2 * ND * 64, SLOT2 = H4 * 2 * ND * 64;     // f32x4 elements per wave and round
     tf_part_store<H2 * (1 - HI), H2>(red + W * SLOT1, accK, accV, lane);
     __syncthreads();
@@ -649,10 +743,12 @@ __device__ __forceinline__ void tf_attn_finish(tf_f32x4* red, tf_f32x4 (&accK)[N
         if (j < NK && key < L) {
 #pragma unroll
             for (int dj = 0; dj < NDH; ++dj) {                            // rotary pairs (d, d + HD/2) = tiles (dj, dj + ND/2)
+                const int c1 = tf_gcol<HD>(dj, fg), c2 = tf_gcol<HD>(dj + NDH, fg), rcol = tf_rope_col<HD>(dj, fg);
+                if (c1 < 0) continue;                                     // (padding columns of a 24-wide head)
                 f16x4 k1, k2, v1, v2;
                 float co[4], si[4];
-                *(float4*)co = *(const float4*)(a.rope_cos + key * (HD / 2) + dj * 16 + 4 * fg);
-                *(float4*)si = *(const float4*)(a.rope_sin + key * (HD / 2) + dj * 16 + 4 * fg);
+                *(float4*)co = *(const float4*)(a.rope_cos + key * (HD / 2) + rcol);
+                *(float4*)si = *(const float4*)(a.rope_sin + key * (HD / 2) + rcol);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const float y1 = (float)(half_t)accK[dj][JB + jj][r], y2 = (float)(half_t)accK[dj + NDH][JB + jj][r];
@@ -661,10 +757,10 @@ __device__ __forceinline__ void tf_attn_finish(tf_f32x4* red, tf_f32x4 (&accK)[N
                     v1[r] = (half_t)accV[dj][JB + jj][r];
                     v2[r] = (half_t)accV[dj + NDH][JB + jj][r];
                 }
-                *(f16x4*)(dq_out + (size_t)key * ld + D + dj * 16 + 4 * fg) = k1;
-                *(f16x4*)(dq_out + (size_t)key * ld + D + HD / 2 + dj * 16 + 4 * fg) = k2;
-                *(f16x4*)(dq_out + (size_t)key * ld + 2 * D + dj * 16 + 4 * fg) = v1;
-                *(f16x4*)(dq_out + (size_t)key * ld + 2 * D + HD / 2 + dj * 16 + 4 * fg) = v2;
+                *(f16x4*)(dq_out + (size_t)key * ld + D + c1) = k1;
+                *(f16x4*)(dq_out + (size_t)key * ld + D + c2) = k2;
+                *(f16x4*)(dq_out + (size_t)key * ld + 2 * D + c1) = v1;
+                *(f16x4*)(dq_out + (size_t)key * ld + 2 * D + c2) = v2;
             }
         }
     }
@@ -678,22 +774,23 @@ __device__ __forceinline__ void tf_attn_finish(tf_f32x4* red, tf_f32x4 (&accK)[N
 // correct first. (HD = 64 with TP = 256 does not fit a CU's LDS.)
 template <int TP, int HD>
 __global__ __launch_bounds__(64 * TF_ATT_WAVES_B, (TP == 128 && HD == 32) ? 2 : 1) void tf_attn_bwd(TfAttnArgs a) {   // (second figure: waves per SIMD)
-    constexpr int NKT = TP / 16, LDP = TP + 8, ND = HD / 16, NDH = ND / 2;
-    constexpr int KH = 8 * 32 / HD, NH = NKT / KH;              // key tiles per pass (128 accumulator registers), passes
+    constexpr int HL = tf_lds_width(HD);          // head width in LDS (24 -> 32)
+    constexpr int NKT = TP / 16, LDP = TP + 8, ND = HL / 16, NDH = ND / 2;
+    constexpr int KH = 8 * 32 / HL, NH = NKT / KH;              // key tiles per pass (128 accumulator registers), passes
     static_assert(NH == 1 || NH == 2, "one or two passes");
     constexpr int TRB = TF_ATT_TRB;
     extern __shared__ __attribute__((aligned(16))) unsigned char tf_smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.x / a.H, h = blockIdx.x % a.H;
     const int L = a.L, D = a.D, ld = 3 * D;
-    half_t* sV = (half_t*)tf_smem;                             // [TP][HD]
-    half_t* sdO = sV + TP * HD;                                // [TP][HD]
-    half_t* sdOt = sdO + TP * HD;                              // [HD][LDP]
-    half_t* sKt = sdOt + HD * LDP;                             // [HD][LDP] rotated k, transposed
-    half_t* sQt = sKt + HD * LDP;                              // [HD][LDP] rotated q, transposed
-    half_t* sK = sQt + HD * LDP;                               // [TP][HD] rotated k
-    half_t* sQ = sK + TP * HD;                                 // [TP][HD] rotated q
-    half_t* sT = sQ + TP * HD + wave * TF_ATT_TRB * 512;       // this wave's transpose tiles: TF_ATT_TRB x (dS, P) of 16 x 16
+    half_t* sV = (half_t*)tf_smem;                             // [TP][HL]
+    half_t* sdO = sV + TP * HL;                                // [TP][HL]
+    half_t* sdOt = sdO + TP * HL;                              // [HL][LDP]
+    half_t* sKt = sdOt + HL * LDP;                             // [HL][LDP] rotated k, transposed
+    half_t* sQt = sKt + HL * LDP;                              // [HL][LDP] rotated q, transposed
+    half_t* sK = sQt + HL * LDP;                               // [TP][HL] rotated k
+    half_t* sQ = sK + TP * HL;                                 // [TP][HL] rotated q
+    half_t* sT = sQ + TP * HL + wave * TF_ATT_TRB * 512;       // this wave's transpose tiles: TF_ATT_TRB x (dS, P) of 16 x 16
     float2* sStat = (float2*)((half_t*)tf_smem + tf_att_stage<TP, HD>() + TF_ATT_WAVES_B * TF_ATT_TRB * 512);   // [TP] softmax row statistics
     const half_t* base = a.qkv + (size_t)b * L * ld + h * HD;
     const half_t* dob = a.dctx + (size_t)b * L * D + h * HD;
@@ -706,8 +803,24 @@ __global__ __launch_bounds__(64 * TF_ATT_WAVES_B, (TP == 128 && HD == 32) ? 2 : 
     const int tr_off = (4 * fg + (fr >> 2)) * 16 + 4 * (fr & 3);
 
     auto pass = [&](auto half_c) {
-        constexpr int HALF = decltype(half_c)::value, J0 = HALF * KH;        // this pass owns key tiles J0 .. J0 + 7
-        {
+        constexpr int HALF = decltype(half_c)::value, J0 = HALF * KH;        // this pass owns key tiles J0 .. J0 + KH - 1
+        if constexpr (HD == 24) {
+            constexpr int NT = 64 * TF_ATT_WAVES_B;
+            TfRow24<NT, TP> rq, rk, rv, ro;
+            TfRope24<NT, TP> rp;
+            tf_fetch24(base + 2 * D, ld, L, tid, rv);
+            tf_fetch24(dob, D, L, tid, ro);
+            tf_fetch24(base + D, ld, L, tid, rk);
+            tf_fetch24(base, ld, L, tid, rq);
+            tf_fetch_rope24(a.rope_cos, a.rope_sin, L, tid, rp);
+            if constexpr (HALF > 0) __syncthreads();                         // the previous pass has read its partial sums
+            tf_put_plain24<false>(rv, L, tid, sV);
+            tf_put_plain24<false>(ro, L, tid, sdO);
+            tf_put_plain24<true>(ro, L, tid, sdOt);
+            tf_put_rot24<true, true>(rk, rp, L, tid, sK, sKt);
+            tf_put_rot24<true, true>(rq, rp, L, tid, sQ, sQt);
+            for (int t = tid; t < TP; t += 64 * TF_ATT_WAVES_B) sStat[t] = t < L ? a.stat[(size_t)(b * a.H + h) * L + t] : make_float2(0.f, 0.f);
+        } else {
             constexpr int NT = 64 * TF_ATT_WAVES_B;
             TfRotRaw<NT, TP, HD> rq, rk;
             TfRope<NT, TP, HD> rp;
@@ -741,9 +854,9 @@ __global__ __launch_bounds__(64 * TF_ATT_WAVES_B, (TP == 128 && HD == 32) ? 2 : 
                 ds[j] = (f16x4){0, 0, 0, 0};
                 pt[j] = (f16x4){0, 0, 0, 0};
                 if (j < NK) {
-                    const tf_f32x4 dp = tf_tile_kq<HD>(sV + (j * 16 + fr) * HD, sdO + (qi * 16 + fr) * HD, fg);   // dP^T [key][query]
+                    const tf_f32x4 dp = tf_tile_kq<HL>(sV + (j * 16 + fr) * HL, sdO + (qi * 16 + fr) * HL, fg);   // dP^T [key][query]
                     // the probabilities again, exactly as the forward rounded them: same product, same exponential, same scale
-                    const tf_f32x4 sc = tf_tile_kq<HD>(sK + (j * 16 + fr) * HD, sQ + (qi * 16 + fr) * HD, fg);
+                    const tf_f32x4 sc = tf_tile_kq<HL>(sK + (j * 16 + fr) * HL, sQ + (qi * 16 + fr) * HL, fg);
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const int key = j * 16 + 4 * fg + r;
@@ -776,16 +889,18 @@ __global__ __launch_bounds__(64 * TF_ATT_WAVES_B, (TP == 128 && HD == 32) ? 2 : 
                 // rotary transpose on (d, d + HD/2) = (o[dj][r], o[dj + ND/2][r]), d = 16 dj + 4 fg + r, then the q scaling
 #pragma unroll
                 for (int dj = 0; dj < NDH; ++dj) {
+                    const int c1 = tf_gcol<HD>(dj, fg), c2 = tf_gcol<HD>(dj + NDH, fg), rcol = tf_rope_col<HD>(dj, fg);
+                    if (c1 < 0) continue;                                 // (padding columns of a 24-wide head)
                     f16x4 o1, o2;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const float co = a.rope_cos[q * (HD / 2) + dj * 16 + 4 * fg + r], si = a.rope_sin[q * (HD / 2) + dj * 16 + 4 * fg + r];
+                        const float co = a.rope_cos[q * (HD / 2) + rcol + r], si = a.rope_sin[q * (HD / 2) + rcol + r];
                         const float y1 = (float)(half_t)o[dj][r], y2 = (float)(half_t)o[dj + NDH][r];
                         o1[r] = (half_t)((float)(half_t)(y1 * co + y2 * si) * a.qscale);
                         o2[r] = (half_t)((float)(half_t)(y2 * co - y1 * si) * a.qscale);
                     }
-                    *(f16x4*)(dq_out + (size_t)q * ld + dj * 16 + 4 * fg) = o1;
-                    *(f16x4*)(dq_out + (size_t)q * ld + HD / 2 + dj * 16 + 4 * fg) = o2;
+                    *(f16x4*)(dq_out + (size_t)q * ld + c1) = o1;
+                    *(f16x4*)(dq_out + (size_t)q * ld + c2) = o2;
                 }
             }
             // dK^T [d][key] += Qr^T (rows d, k = these queries) x dS (k = query on the rows);  dV^T += dO^T x P: the tiles
@@ -834,10 +949,10 @@ __global__ __launch_bounds__(64 * TF_ATT_WAVES_B, (TP == 128 && HD == 32) ? 2 : 
         __syncthreads();
         tf_f32x4* red = (tf_f32x4*)tf_smem;
         switch (wave) {
-            case 0: tf_attn_finish<0, 0>(red, accK, accV, a, dq_out, ld, D, L, NK, J0); break;
-            case 1: tf_attn_finish<0, 1>(red, accK, accV, a, dq_out, ld, D, L, NK, J0); break;
-            case 2: tf_attn_finish<1, 0>(red, accK, accV, a, dq_out, ld, D, L, NK, J0); break;
-            default: tf_attn_finish<1, 1>(red, accK, accV, a, dq_out, ld, D, L, NK, J0); break;
+            case 0: tf_attn_finish<0, 0, HD>(red, accK, accV, a, dq_out, ld, D, L, NK, J0); break;
+            case 1: tf_attn_finish<0, 1, HD>(red, accK, accV, a, dq_out, ld, D, L, NK, J0); break;
+            case 2: tf_attn_finish<1, 0, HD>(red, accK, accV, a, dq_out, ld, D, L, NK, J0); break;
+            default: tf_attn_finish<1, 1, HD>(red, accK, accV, a, dq_out, ld, D, L, NK, J0); break;
         }
     };
     pass(std::integral_constant<int, 0>{});

@@ -9,7 +9,8 @@ struct TfLayerW {
     float *bqkv = nullptr, *bo = nullptr, *b1 = nullptr, *b2 = nullptr, *ln1g = nullptr, *ln1b = nullptr, *ln2g = nullptr, *ln2b = nullptr;
 };
 struct TfModel {
-    int layers = 0, D = 0, H = 0, F = 0, L = 0, HD = TF_HD;     // HD = D / H: 32 or 64
+    int layers = 0, D = 0, H = 0, F = 0, L = 0, HD = TF_HD;     // HD = head width: 24, 32 or 64
+    int Dr = 0;                      // the model's own width; D is Dr padded to a multiple of 128 (480 -> 512) with zero weights
     std::vector<TfLayerW> lw;
     half_t *E16 = nullptr, *E16T = nullptr, *Wd = nullptr, *WdT = nullptr;      // E16 [128][D] (rows >= 33 zero), E16T [D][128]
     float *bd = nullptr, *lnf_g = nullptr, *lnf_b = nullptr, *lnh_g = nullptr, *lnh_b = nullptr, *blm = nullptr;
@@ -60,45 +61,48 @@ static int tf_upload(std::vector<void*>& allocs, const std::vector<T>& h, T** ou
 #define TFUP(vec, dst) do { int rc_ = tf_upload(t->allocs, vec, &(dst)); if (rc_) return rc_; } while (0)
 
 static int tf_build_model(TfModel* t, int L, const ppde_tf_weights* w) {
-    const int D = t->D, F = t->F;
+    // Dr = the model's width, D = Dr padded to a multiple of 128 (the GEMM tiles): padded rows / columns of every weight,
+    // bias and layer-norm parameter are zero, so the padded columns of every activation stay zero
+    const int D = t->D, Dr = t->Dr, F = t->F;
     t->L = L;
     t->lw.resize(t->layers);
+    auto padded = [](const float* v, int n, int n_pad) { std::vector<float> o((size_t)n_pad, 0.f); std::copy(v, v + n, o.begin()); return o; };
     for (int l = 0; l < t->layers; ++l) {
         TfLayerW& x = t->lw[l];
         // q, k, v projections fused: rows [0, D) = q, [D, 2D) = k, [2D, 3D) = v
-        std::vector<float> wqkv((size_t)3 * D * D), bqkv((size_t)3 * D);
-        memcpy(wqkv.data(), w->q_w[l], sizeof(float) * D * D);
-        memcpy(wqkv.data() + (size_t)D * D, w->k_w[l], sizeof(float) * D * D);
-        memcpy(wqkv.data() + (size_t)2 * D * D, w->v_w[l], sizeof(float) * D * D);
-        memcpy(bqkv.data(), w->q_b[l], sizeof(float) * D);
-        memcpy(bqkv.data() + D, w->k_b[l], sizeof(float) * D);
-        memcpy(bqkv.data() + 2 * D, w->v_b[l], sizeof(float) * D);
-        TFUP(tf_to_half(wqkv.data(), 3 * D, D, 3 * D, D, false), x.Wqkv);
-        TFUP(tf_to_half(wqkv.data(), 3 * D, D, 3 * D, D, true), x.WqkvT);
-        TFUP(tf_to_half(w->o_w[l], D, D, D, D, false), x.Wo);
-        TFUP(tf_to_half(w->o_w[l], D, D, D, D, true), x.WoT);
-        TFUP(tf_to_half(w->fc1_w[l], F, D, F, D, false), x.W1);
-        TFUP(tf_to_half(w->fc1_w[l], F, D, F, D, true), x.W1T);
-        TFUP(tf_to_half(w->fc2_w[l], D, F, D, F, false), x.W2);
-        TFUP(tf_to_half(w->fc2_w[l], D, F, D, F, true), x.W2T);
+        std::vector<float> wqkv((size_t)3 * D * Dr, 0.f), bqkv((size_t)3 * D, 0.f);
+        memcpy(wqkv.data(), w->q_w[l], sizeof(float) * Dr * Dr);
+        memcpy(wqkv.data() + (size_t)D * Dr, w->k_w[l], sizeof(float) * Dr * Dr);
+        memcpy(wqkv.data() + (size_t)2 * D * Dr, w->v_w[l], sizeof(float) * Dr * Dr);
+        memcpy(bqkv.data(), w->q_b[l], sizeof(float) * Dr);
+        memcpy(bqkv.data() + D, w->k_b[l], sizeof(float) * Dr);
+        memcpy(bqkv.data() + 2 * D, w->v_b[l], sizeof(float) * Dr);
+        TFUP(tf_to_half(wqkv.data(), 3 * D, Dr, 3 * D, D, false), x.Wqkv);
+        TFUP(tf_to_half(wqkv.data(), 3 * D, Dr, 3 * D, D, true), x.WqkvT);
+        TFUP(tf_to_half(w->o_w[l], Dr, Dr, D, D, false), x.Wo);
+        TFUP(tf_to_half(w->o_w[l], Dr, Dr, D, D, true), x.WoT);
+        TFUP(tf_to_half(w->fc1_w[l], F, Dr, F, D, false), x.W1);
+        TFUP(tf_to_half(w->fc1_w[l], F, Dr, F, D, true), x.W1T);
+        TFUP(tf_to_half(w->fc2_w[l], Dr, F, D, F, false), x.W2);
+        TFUP(tf_to_half(w->fc2_w[l], Dr, F, D, F, true), x.W2T);
         TFUP(bqkv, x.bqkv);
-        TFUP(std::vector<float>(w->o_b[l], w->o_b[l] + D), x.bo);
+        TFUP(padded(w->o_b[l], Dr, D), x.bo);
         TFUP(std::vector<float>(w->fc1_b[l], w->fc1_b[l] + F), x.b1);
-        TFUP(std::vector<float>(w->fc2_b[l], w->fc2_b[l] + D), x.b2);
-        TFUP(std::vector<float>(w->ln1_w[l], w->ln1_w[l] + D), x.ln1g);
-        TFUP(std::vector<float>(w->ln1_b[l], w->ln1_b[l] + D), x.ln1b);
-        TFUP(std::vector<float>(w->ln2_w[l], w->ln2_w[l] + D), x.ln2g);
-        TFUP(std::vector<float>(w->ln2_b[l], w->ln2_b[l] + D), x.ln2b);
+        TFUP(padded(w->fc2_b[l], Dr, D), x.b2);
+        TFUP(padded(w->ln1_w[l], Dr, D), x.ln1g);
+        TFUP(padded(w->ln1_b[l], Dr, D), x.ln1b);
+        TFUP(padded(w->ln2_w[l], Dr, D), x.ln2g);
+        TFUP(padded(w->ln2_b[l], Dr, D), x.ln2b);
     }
-    TFUP(tf_to_half(w->embed, TF_VOCAB, D, TF_VOCAB_PAD, D, false), t->E16);
-    TFUP(tf_to_half(w->embed, TF_VOCAB, D, TF_VOCAB_PAD, D, true), t->E16T);
-    TFUP(tf_to_half(w->head_dense_w, D, D, D, D, false), t->Wd);
-    TFUP(tf_to_half(w->head_dense_w, D, D, D, D, true), t->WdT);
-    TFUP(std::vector<float>(w->head_dense_b, w->head_dense_b + D), t->bd);
-    TFUP(std::vector<float>(w->final_ln_w, w->final_ln_w + D), t->lnf_g);
-    TFUP(std::vector<float>(w->final_ln_b, w->final_ln_b + D), t->lnf_b);
-    TFUP(std::vector<float>(w->head_ln_w, w->head_ln_w + D), t->lnh_g);
-    TFUP(std::vector<float>(w->head_ln_b, w->head_ln_b + D), t->lnh_b);
+    TFUP(tf_to_half(w->embed, TF_VOCAB, Dr, TF_VOCAB_PAD, D, false), t->E16);
+    TFUP(tf_to_half(w->embed, TF_VOCAB, Dr, TF_VOCAB_PAD, D, true), t->E16T);
+    TFUP(tf_to_half(w->head_dense_w, Dr, Dr, D, D, false), t->Wd);
+    TFUP(tf_to_half(w->head_dense_w, Dr, Dr, D, D, true), t->WdT);
+    TFUP(padded(w->head_dense_b, Dr, D), t->bd);
+    TFUP(padded(w->final_ln_w, Dr, D), t->lnf_g);
+    TFUP(padded(w->final_ln_b, Dr, D), t->lnf_b);
+    TFUP(padded(w->head_ln_w, Dr, D), t->lnh_g);
+    TFUP(padded(w->head_ln_b, Dr, D), t->lnh_b);
     std::vector<float> blm(TF_VOCAB_PAD, 0.f);
     for (int k = 0; k < TF_VOCAB; ++k) blm[k] = w->head_bias[k];
     TFUP(blm, t->blm);
@@ -187,8 +191,8 @@ static int tf_gemm(hipStream_t s, const half_t* A, const half_t* B, half_t* C, i
     return PPDE_OK;
 }
 static int tf_ln(hipStream_t s, bool bwd, const half_t* x, half_t* y, const float* gamma, const float* beta, float* mean, float* rstd,
-                 int M, int D, const half_t* dy = nullptr, const half_t* gres = nullptr, float out_scale = 1.f) {
-    TfLnArgs a{x, y, gamma, beta, mean, rstd, dy, gres, M, D, out_scale};
+                 int M, int D, int ld, const half_t* dy = nullptr, const half_t* gres = nullptr, float out_scale = 1.f) {
+    TfLnArgs a{x, y, gamma, beta, mean, rstd, dy, gres, M, D, ld, out_scale};
     ARGCHK(D % 8 == 0 && D <= TF_LN_MAXD, "layer-norm width");
     const bool wide = D > 1024;                                      // three 16-byte chunks per lane instead of two
     if (bwd && wide) hipLaunchKernelGGL(tf_ln_bwd<3>, dim3((M + 3) / 4), dim3(256), 0, s, a);
@@ -228,15 +232,17 @@ static int tf_eval(const TfModel* t, TfWork* wk, const uint8_t* rows, int Ls, in
         const TfLayerW& w = t->lw[l];
         TfLayerAct& a = wk->act[l];
         half_t* xnext = l + 1 < t->layers ? wk->act[l + 1].xin : wk->xlast;
-        TFRC(tf_ln(s, false, a.xin, wk->ln_out, w.ln1g, w.ln1b, a.mean1, a.rstd1, M, D));
+        TFRC(tf_ln(s, false, a.xin, wk->ln_out, w.ln1g, w.ln1b, a.mean1, a.rstd1, M, t->Dr, D));
         TFRC(tf_gemm<TF_EPI_BIAS_QSCALE>(s, wk->ln_out, w.Wqkv, a.qkv, Mp, 3 * D, D, w.bqkv, nullptr, nullptr, qs, D));
         TfAttnArgs at{a.qkv, wk->ctx, a.stat, t->rope_cos, t->rope_sin, nullptr, nullptr, n, L, H, D, qs};
-        if (t->HD == 64) hipLaunchKernelGGL((tf_attn_fwd<128, 64>), dim3(n * H), dim3(64 * TF_ATT_WAVES_F), (tf_attn_fwd_lds<128, 64>()), s, at);
+        if (t->HD == 24 && L <= 128) hipLaunchKernelGGL((tf_attn_fwd<128, 24>), dim3(n * H), dim3(64 * TF_ATT_WAVES_F), (tf_attn_fwd_lds<128, 24>()), s, at);
+        else if (t->HD == 24) hipLaunchKernelGGL((tf_attn_fwd<256, 24>), dim3(n * H), dim3(64 * TF_ATT_WAVES_F), (tf_attn_fwd_lds<256, 24>()), s, at);
+        else if (t->HD == 64) hipLaunchKernelGGL((tf_attn_fwd<128, 64>), dim3(n * H), dim3(64 * TF_ATT_WAVES_F), (tf_attn_fwd_lds<128, 64>()), s, at);
         else if (L <= 128) hipLaunchKernelGGL((tf_attn_fwd<128, 32>), dim3(n * H), dim3(64 * TF_ATT_WAVES_F), (tf_attn_fwd_lds<128, 32>()), s, at);
         else hipLaunchKernelGGL((tf_attn_fwd<256, 32>), dim3(n * H), dim3(64 * TF_ATT_WAVES_F), (tf_attn_fwd_lds<256, 32>()), s, at);
         HIPCHK(hipGetLastError());
         TFRC(tf_gemm<TF_EPI_BIAS_RESID>(s, wk->ctx, w.Wo, a.xmid, Mp, D, D, w.bo, a.xin));
-        TFRC(tf_ln(s, false, a.xmid, wk->ln_out, w.ln2g, w.ln2b, a.mean2, a.rstd2, M, D));
+        TFRC(tf_ln(s, false, a.xmid, wk->ln_out, w.ln2g, w.ln2b, a.mean2, a.rstd2, M, t->Dr, D));
         TfEventList* el = g_tf_fc1_events;
         if (el && el->used + 2 > el->ev.size()) el = nullptr;
         if (el && hipEventRecord(el->ev[el->used++], s) != hipSuccess) return fail(PPDE_ERR_HIP, "event record failed");
@@ -244,9 +250,9 @@ static int tf_eval(const TfModel* t, TfWork* wk, const uint8_t* rows, int Ls, in
         if (el && hipEventRecord(el->ev[el->used++], s) != hipSuccess) return fail(PPDE_ERR_HIP, "event record failed");
         TFRC(tf_gemm<TF_EPI_BIAS_RESID>(s, wk->actf, w.W2, xnext, Mp, D, F, w.b2, a.xmid));
     }
-    TFRC(tf_ln(s, false, wk->xlast, wk->ln_out, t->lnf_g, t->lnf_b, wk->meanf, wk->rstdf, M, D));
+    TFRC(tf_ln(s, false, wk->xlast, wk->ln_out, t->lnf_g, t->lnf_b, wk->meanf, wk->rstdf, M, t->Dr, D));
     TFRC(tf_gemm<TF_EPI_BIAS_GELU>(s, wk->ln_out, t->Wd, wk->head_a, Mp, D, D, t->bd, nullptr, wk->head_y));
-    TFRC(tf_ln(s, false, wk->head_a, wk->head_z, t->lnh_g, t->lnh_b, wk->meanh, wk->rstdh, M, D));
+    TFRC(tf_ln(s, false, wk->head_a, wk->head_z, t->lnh_g, t->lnh_b, wk->meanh, wk->rstdh, M, t->Dr, D));
     TFRC(tf_gemm<TF_EPI_BIAS>(s, wk->head_z, t->E16, wk->logits, Mp, TF_VOCAB_PAD, D, t->blm));
     hipLaunchKernelGGL(tf_score, dim3(n), dim3(256), 0, s, wk->logits, rows, Ls, sh, L, t->perm, t->pinv, score_out,
                        grad_out ? wk->dlogits : (half_t*)nullptr, grad_out ? wk->gdirect : (float*)nullptr);
@@ -255,28 +261,30 @@ static int tf_eval(const TfModel* t, TfWork* wk, const uint8_t* rows, int Ls, in
 
     // ---- backward to the one-hot input
     TFRC(tf_gemm<TF_EPI_PLAIN>(s, wk->dlogits, t->E16T, wk->tmpD, Mp, D, TF_VOCAB_PAD));
-    TFRC(tf_ln(s, true, wk->head_a, wk->gB, t->lnh_g, t->lnh_b, wk->meanh, wk->rstdh, M, D, wk->tmpD));
+    TFRC(tf_ln(s, true, wk->head_a, wk->gB, t->lnh_g, t->lnh_b, wk->meanh, wk->rstdh, M, t->Dr, D, wk->tmpD));
     {
         const size_t cnt = (size_t)M * D;
         hipLaunchKernelGGL(tf_gelu_bwd_ew, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, s, wk->gB, wk->head_y, wk->gA, cnt);
         HIPCHK(hipGetLastError());
     }
     TFRC(tf_gemm<TF_EPI_PLAIN>(s, wk->gA, t->WdT, wk->tmpD, Mp, D, D));
-    TFRC(tf_ln(s, true, wk->xlast, wk->gA, t->lnf_g, t->lnf_b, wk->meanf, wk->rstdf, M, D, wk->tmpD));
+    TFRC(tf_ln(s, true, wk->xlast, wk->gA, t->lnf_g, t->lnf_b, wk->meanf, wk->rstdf, M, t->Dr, D, wk->tmpD));
     for (int l = t->layers - 1; l >= 0; --l) {
         const TfLayerW& w = t->lw[l];
         TfLayerAct& a = wk->act[l];
         TFRC(tf_gemm<TF_EPI_GELU_BWD>(s, wk->gA, w.W2T, wk->dF, Mp, F, D, nullptr, a.hpre));
         TFRC(tf_gemm<TF_EPI_PLAIN>(s, wk->dF, w.W1T, wk->tmpD, Mp, D, F));
-        TFRC(tf_ln(s, true, a.xmid, wk->gB, w.ln2g, w.ln2b, a.mean2, a.rstd2, M, D, wk->tmpD, wk->gA));
+        TFRC(tf_ln(s, true, a.xmid, wk->gB, w.ln2g, w.ln2b, a.mean2, a.rstd2, M, t->Dr, D, wk->tmpD, wk->gA));
         TFRC(tf_gemm<TF_EPI_PLAIN>(s, wk->gB, w.WoT, wk->tmpD, Mp, D, D));
         TfAttnArgs at{a.qkv, nullptr, a.stat, t->rope_cos, t->rope_sin, wk->tmpD, wk->dqkv, n, L, H, D, qs};
-        if (t->HD == 64) hipLaunchKernelGGL((tf_attn_bwd<128, 64>), dim3(n * H), dim3(64 * TF_ATT_WAVES_B), (tf_attn_bwd_lds<128, 64>()), s, at);
+        if (t->HD == 24 && L <= 128) hipLaunchKernelGGL((tf_attn_bwd<128, 24>), dim3(n * H), dim3(64 * TF_ATT_WAVES_B), (tf_attn_bwd_lds<128, 24>()), s, at);
+        else if (t->HD == 24) hipLaunchKernelGGL((tf_attn_bwd<256, 24>), dim3(n * H), dim3(64 * TF_ATT_WAVES_B), (tf_attn_bwd_lds<256, 24>()), s, at);
+        else if (t->HD == 64) hipLaunchKernelGGL((tf_attn_bwd<128, 64>), dim3(n * H), dim3(64 * TF_ATT_WAVES_B), (tf_attn_bwd_lds<128, 64>()), s, at);
         else if (L <= 128) hipLaunchKernelGGL((tf_attn_bwd<128, 32>), dim3(n * H), dim3(64 * TF_ATT_WAVES_B), (tf_attn_bwd_lds<128, 32>()), s, at);
         else hipLaunchKernelGGL((tf_attn_bwd<256, 32>), dim3(n * H), dim3(64 * TF_ATT_WAVES_B), (tf_attn_bwd_lds<256, 32>()), s, at);
         HIPCHK(hipGetLastError());
         TFRC(tf_gemm<TF_EPI_PLAIN>(s, wk->dqkv, w.WqkvT, wk->tmpD, Mp, D, 3 * D));
-        TFRC(tf_ln(s, true, a.xin, wk->gA, w.ln1g, w.ln1b, a.mean1, a.rstd1, M, D, wk->tmpD, wk->gB, l == 0 ? TF_TOKEN_DROPOUT_SCALE : 1.f));
+        TFRC(tf_ln(s, true, a.xin, wk->gA, w.ln1g, w.ln1b, a.mean1, a.rstd1, M, t->Dr, D, wk->tmpD, wk->gB, l == 0 ? TF_TOKEN_DROPOUT_SCALE : 1.f));
     }
     TFRC(tf_gemm<TF_EPI_PLAIN>(s, wk->gA, t->E16, wk->G33, Mp, TF_VOCAB_PAD, D));
     hipLaunchKernelGGL(tf_finish_grad, dim3((M * 20 + 255) / 256), dim3(256), 0, s, wk->G33, wk->gdirect, t->perm, M, grad_out, 0);

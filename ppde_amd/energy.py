@@ -274,9 +274,6 @@ class _HipEnergy(torch.nn.Module):
         checkpoint file must already be there: <hub_dir>/checkpoints/<name>.pt, or next to the protein's other weights."""
         from .weights import load_esm2_state
         name, heads = ESM2_CHECKPOINTS[args.unsupervised_expert]
-        if name.startswith("esm2_t12_"):
-            raise NotImplementedError("transformer-S (esm2_t12_35M: head width 24, dim 480) is not built on the MI355X path: "
-                                      "the attention kernels take head widths 32 and 64 (transformer-M, transformer-L)")
         cands = [os.path.join(getattr(args, "hub_dir", "."), "checkpoints", name + ".pt"), os.path.join(dataset, name + ".pt")]
         path = next((c for c in cands if os.path.exists(c)), None)
         if path is None:

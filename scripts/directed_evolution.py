@@ -5,8 +5,8 @@ Counterpart of the reference's scripts/directed_evolution.py (same flags, same o
 results_path/protein/<sampler>_<signature>_<seed>_<timestamp>/: population.npy [n, L, 20] f32,
 pred_fitness_scores.npy, oracle_fitness_scores.npy, potts_scores.npy, energy_scores.npy,
 energy_history.npy [T+1, n], fitness_history.npy [T+1, n], config.txt). Only the pieces on the PPDE hot path
-exist here: `--sampler PPDE` with `--unsupervised_expert potts | transformer | transformer-M | transformer-L |
-potts+transformer` (the ESM-2 150M / 650M checkpoint must be in <hub_dir>/checkpoints/) and `--energy_function supervised`; the baseline samplers and
+exist here: `--sampler PPDE` with `--unsupervised_expert potts | transformer | transformer-S | transformer-M |
+transformer-L | potts+transformer` (the ESM-2 checkpoint must be in <hub_dir>/checkpoints/) and `--energy_function supervised`; the baseline samplers and
 the MSA-Transformer scoring are out of scope.
 
 Extra flags: --ppde_rng {torch,philox}, --ppde_seed, --ppde_reuse_grad {0,1}, --ppde_shard (with torchrun).
@@ -129,7 +129,7 @@ def build_parser():
     g.add_argument("--energy_lamda", type=float, default=5)
     g.add_argument("--energy_function", type=str, default="product_of_experts", help="product_of_experts, supervised")
     g.add_argument("--unsupervised_expert", type=str, default="potts",
-                   help="potts, transformer (= transformer-M, ESM-2 150M), transformer-L (ESM-2 650M), potts+transformer")
+                   help="potts, transformer (= transformer-M, ESM-2 150M), transformer-S (35M), transformer-L (650M), potts+transformer")
     g.add_argument("--sampler", type=str, default="PPDE")
     g.add_argument("--nmut_threshold", type=int, default=0,
                    help="Enforce a maximum number of mutations to WT; disabled by setting to 0")

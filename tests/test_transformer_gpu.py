@@ -50,7 +50,10 @@ def _read(m, what, layer, shape):
                                                        (256, 2, 128, 4, 256, 2),        # the longest sequence supported
                                                        (24, 2, 256, 4, 512, 4),         # head width 64, toy
                                                        (128, 2, 256, 4, 512, 2),        # head width 64, full length
-                                                       (104, 33, 1280, 20, 5120, 2)])   # esm2_t33_650M shapes (transformer-L)
+                                                       (104, 33, 1280, 20, 5120, 2),    # esm2_t33_650M shapes (transformer-L)
+                                                       (24, 2, 96, 4, 256, 4),          # head width 24 (rows padded 96 -> 128), toy
+                                                       (237, 2, 96, 4, 256, 2),         # head width 24, GFP length
+                                                       (104, 12, 480, 20, 1920, 3)])    # esm2_t12_35M shapes (transformer-S)
 def test_score_and_gradient_vs_oracle(L, layers, dim, heads, ffn, n):
     m, wt, st, _ = _model(L, layers, dim, heads, ffn)
     orc = eo.EsmOracle(st, layers, dim, heads, half_points=True)
@@ -66,11 +69,14 @@ def test_score_and_gradient_vs_oracle(L, layers, dim, heads, ffn, n):
     e, fit, g = m.energy_grad(torch.as_tensor(idx).cuda(), 4)
     # intermediates first: they localise a failure
     M = n * L
-    for name, what, layer, shape, ref in [("x0", 0, 0, (M, dim), tr["xin0"].reshape(M, dim)),
-                                          ("qkv0", 1, 0, (M, 3 * dim), tr["qkv0"].reshape(M, 3 * dim)),
-                                          ("xmid0", 3, 0, (M, dim), tr["xmid0"].reshape(M, dim)),
-                                          ("xlast", 5, 0, (M, dim), tr["xlast"].reshape(M, dim))]:
-        got = _read(m, what, layer, shape)
+    dp = (dim + 127) // 128 * 128                               # device rows are padded to the GEMM tile (480 -> 512), pad columns zero
+    for name, what, layer, width, ref in [("x0", 0, 0, 1, tr["xin0"].reshape(M, dim)),
+                                          ("qkv0", 1, 0, 3, tr["qkv0"].reshape(M, 3 * dim)),
+                                          ("xmid0", 3, 0, 1, tr["xmid0"].reshape(M, dim)),
+                                          ("xlast", 5, 0, 1, tr["xlast"].reshape(M, dim))]:
+        raw = _read(m, what, layer, (M, width, dp))
+        assert not raw[:, :, dim:].any(), name
+        got = raw[:, :, :dim].reshape(M, width * dim)
         err = np.abs(got - ref.numpy())
         assert observed(f"tf{layers}:{name}", err.max(), 2e-2 * (1 + np.abs(ref.numpy()).max())) <= 1.0, name
     lg = _read(m, 6, 0, (M, 128))[:, :33]
