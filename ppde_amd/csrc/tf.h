@@ -33,17 +33,33 @@ typedef float tf_f32x4 __attribute__((ext_vector_type(4)));
 
 // erf by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7, far below the fp16 rounding of every value it feeds): one exp,
 // one reciprocal and a degree-5 polynomial instead of the library's ~40-instruction erff. The GELU epilogues evaluate it
-// 64 times per lane and tile, which made them a quarter of the fc1 GEMM with the library call.
+// 64 times per lane and tile, which made them a quarter of the fc1 GEMM with the library call. Written with explicit
+// fused multiply-adds (the library is built with -ffp-contract=off for the fp32 sampler kernels; here every result is
+// rounded to fp16 and a contraction is free accuracy): half the instructions of the mul + add form.
+//   tf_erf_parts: e = exp(-z^2) and 1 - |erf(z)| = poly(t) * e, t = 1 / (1 + p |z|); GELU' reuses e for the density term
+__device__ __forceinline__ float tf_erfc_abs(float az, float& e) {
+    const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(0.3275911f, az, 1.0f));
+    float poly = __builtin_fmaf(1.061405429f, t, -1.453152027f);
+    poly = __builtin_fmaf(poly, t, 1.421413741f);
+    poly = __builtin_fmaf(poly, t, -0.284496736f);
+    poly = __builtin_fmaf(poly, t, 0.254829592f);
+    e = __expf(-az * az);
+    return poly * t * e;
+}
 __device__ __forceinline__ float tf_erf(float x) {
-    const float ax = fabsf(x);
-    const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * ax);
-    const float poly = ((((1.061405429f * t - 1.453152027f) * t + 1.421413741f) * t - 0.284496736f) * t + 0.254829592f) * t;
-    const float r = 1.0f - poly * __expf(-ax * ax);
+    float e;
+    const float r = 1.0f - tf_erfc_abs(fabsf(x), e);
     return copysignf(r, x);
 }
-__device__ __forceinline__ float tf_gelu(float x) { return x * 0.5f * (1.0f + tf_erf(x * 0.70710678118654752f)); }
-__device__ __forceinline__ float tf_gelu_grad(float x) {
-    return 0.5f * (1.0f + tf_erf(x * 0.70710678118654752f)) + x * 0.3989422804014327f * __expf(-0.5f * x * x);
+__device__ __forceinline__ float tf_gelu(float x) {          // x * Phi(x) = hx + hx * erf(x / sqrt 2), hx = x / 2
+    const float hx = 0.5f * x;
+    return __builtin_fmaf(hx, tf_erf(x * 0.70710678118654752f), hx);
+}
+__device__ __forceinline__ float tf_gelu_grad(float x) {     // Phi(x) + x * phi(x), phi(x) = exp(-x^2 / 2) / sqrt(2 pi): the erf's own exponential
+    float e;
+    const float z = x * 0.70710678118654752f;
+    const float erf_z = copysignf(1.0f - tf_erfc_abs(fabsf(z), e), z);
+    return __builtin_fmaf(x * 0.3989422804014327f, e, __builtin_fmaf(0.5f, erf_z, 0.5f));
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -100,9 +116,10 @@ __global__ __launch_bounds__(64 * NWAVE, 2) void tf_gemm_nt(TfGemmArgs g) {
     // Workgroups with equal (id mod 8) share an XCD (potts.h: xcd_contiguous): each XCD takes a contiguous run of tiles
     // in N-fastest order, so the column tiles of one 128-row panel of A meet in ONE L2 and the panel crosses the
     // fabric once instead of once per XCD.
-    const int tiles_n = g.N >> 7;
-    const int v = xcd_contiguous(blockIdx.x, gridDim.x);
-    const int m0 = (v / tiles_n) << 7, n0 = (v % tiles_n) << 7;
+    // The workgroup is PERSISTENT: the grid is at most two workgroups per CU and each walks its share of the tiles, so the
+    // write-back of one tile (stores are only acknowledged microseconds later, and a wave cannot retire before that) and
+    // the per-workgroup start-up overlap the next tile's k loop instead of holding the CU's slot idle.
+    const int tiles_n = g.N >> 7, tiles_total = (g.M >> 7) * tiles_n;
     const int K = g.K, nk = K / BK;
     const int lr = lane / CH, lc = lane % CH;        // row within a DMA piece, 16-byte chunk of the row
     // XOR swizzle of the 16-byte chunk index by the row, applied to the DMA's SOURCE chunk and to the reads: 128-byte rows
@@ -116,6 +133,14 @@ __global__ __launch_bounds__(64 * NWAVE, 2) void tf_gemm_nt(TfGemmArgs g) {
         const int r = (wave * PPT + i) * RPP + lr;
         voff[i] = (uint32_t)r * (uint32_t)(K * 2) + (uint32_t)((lc ^ SW(r)) << 4);
     }
+    const int fr = lane & 15, fg = lane >> 4;
+    // tiles of this workgroup: XCD x (= id mod 8) owns a contiguous run, its workgroups take the run's tiles in turn
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, wpx = gridDim.x >> 3;
+    const int xq = tiles_total >> 3, xr = tiles_total & 7;
+    const int xbeg = xcd * xq + min(xcd, xr), xcnt = xq + (xcd < xr ? 1 : 0);
+    for (int ti = slot; ti < xcnt; ti += wpx) {
+    const int v = xbeg + ti;
+    const int m0 = (v / tiles_n) << 7, n0 = (v % tiles_n) << 7;
     const half_t* baseA = g.A + (size_t)m0 * K;
     const half_t* baseB = g.B + (size_t)n0 * K;
     auto stage = [&](int buf, int kt) {
@@ -133,7 +158,6 @@ __global__ __launch_bounds__(64 * NWAVE, 2) void tf_gemm_nt(TfGemmArgs g) {
     for (int i = 0; i < MT; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (tf_f32x4){0.f, 0.f, 0.f, 0.f};
-    const int fr = lane & 15, fg = lane >> 4;
     auto compute = [&](int buf) {
         const half_t* a = sA + buf * TILE + (wm * 16 * MT + fr) * BK;
         const half_t* b = sB + buf * TILE + (wn * 64 + fr) * BK;
@@ -160,7 +184,10 @@ __global__ __launch_bounds__(64 * NWAVE, 2) void tf_gemm_nt(TfGemmArgs g) {
 #pragma unroll
         for (int u = 0; u < RCH; ++u) {
             const int c = tid + u * 64 * NWAVE, row = c >> 4, ch = c & 15;
-            rraw[u] = *(const f16x8*)(g.R + (size_t)(m0 + row) * g.N + n0 + ch * 8);
+            const f16x8* rp_ = (const f16x8*)(g.R + (size_t)(m0 + row) * g.N + n0 + ch * 8);
+            // (the pre-activation was written a whole forward pass ago and is read exactly once: streaming it past the caches
+            //  leaves them to the tensors the next kernels read, GELU' 136.0 -> 132.2 us; the residual was written just now)
+            rraw[u] = EPI == TF_EPI_GELU_BWD ? __builtin_nontemporal_load(rp_) : *rp_;
         }
     }
     // ring of STAGES buffers, tiles kt+1 .. kt+STAGES-2 stay in flight across the barrier of iteration kt
@@ -183,12 +210,20 @@ __global__ __launch_bounds__(64 * NWAVE, 2) void tf_gemm_nt(TfGemmArgs g) {
     constexpr int OLD = 136;                                          // padded row length (halfs) of the staged tile
     half_t* sOut = (half_t*)tf_smem;
     static_assert((size_t)128 * OLD * 2 <= tf_gemm_lds<BK, STAGES>(), "the output tile is staged in the operand buffers");
-    auto flush = [&](half_t* dst) {                                   // sOut -> dst tile, coalesced
+    // Outputs of the two write-heavy forward GEMMs (q|k|v: 3 D columns; fc1: two [M][F] tensors) leave with non-temporal
+    // stores: fc1 134.8 -> 118.2 us, q|k|v 74.4 -> 70.5 in a full evaluation, and no reader slows down. Made non-temporal
+    // too, the residual outputs cost the layer norm that reads them next 3 us, and the backward's outputs cost the plain
+    // GEMMs that consume them 4 us each: those stay ordinary stores.
+    constexpr bool NT_OUT = EPI == TF_EPI_BIAS_GELU || EPI == TF_EPI_BIAS_QSCALE;
+    auto flush = [&](half_t* dst, bool nt) {                          // sOut -> dst tile, coalesced
         __syncthreads();
 #pragma unroll
         for (int c = tid; c < 128 * 16; c += 64 * NWAVE) {
             const int row = c >> 4, ch = c & 15;
-            *(f16x8*)(dst + (size_t)(m0 + row) * g.N + n0 + ch * 8) = *(const f16x8*)(sOut + row * OLD + ch * 8);
+            const f16x8 val = *(const f16x8*)(sOut + row * OLD + ch * 8);
+            f16x8* gp = (f16x8*)(dst + (size_t)(m0 + row) * g.N + n0 + ch * 8);
+            if (nt) __builtin_nontemporal_store(val, gp);
+            else *gp = val;
         }
     };
     __syncthreads();                                                  // every wave is done with the operand tiles
@@ -245,14 +280,16 @@ __global__ __launch_bounds__(64 * NWAVE, 2) void tf_gemm_nt(TfGemmArgs g) {
         }
     }
     if constexpr (EPI == TF_EPI_BIAS_GELU) {
-        flush(g.C2);                                                  // the pre-activation
+        flush(g.C2, NT_OUT);                                          // the pre-activation (read again only by the backward)
         __syncthreads();
 #pragma unroll
         for (int i = 0; i < MT; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j) *(f16x4*)(sOut + (wm * 16 * MT + i * 16 + fr) * OLD + wn * 64 + j * 16 + 4 * fg) = second[i][j];
     }
-    flush(g.C);
+    flush(g.C, NT_OUT);
+    __syncthreads();                                                  // the staged tile has been read: the next tile may overwrite it
+    }
 }
 
 // ------------------------------------------------------------------------------------------------------------

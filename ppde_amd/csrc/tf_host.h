@@ -173,7 +173,10 @@ static int tf_gemm(hipStream_t s, const half_t* A, const half_t* B, half_t* C, i
         if (!strcmp(e, "32x3w8")) return 6;
         return TF_GEMM_DEFAULT;
     }();
-    const dim3 grid((M >> 7) * (N >> 7));
+    // persistent workgroups: at most two per CU (tuning knob PPDE_TF_PERSIST=0: one workgroup per tile), a multiple of 8
+    static const bool persist = []() { const char* e = getenv("PPDE_TF_PERSIST"); return !e || atoi(e) != 0; }();
+    const int tiles = (M >> 7) * (N >> 7), tiles8 = (tiles + 7) & ~7;
+    const dim3 grid(persist ? std::min(tiles8, 512) : tiles8);
 #define TF_LAUNCH(BKV, STV) { constexpr size_t lds_ = tf_gemm_lds<BKV, STV>(); hipLaunchKernelGGL((tf_gemm_nt<EPI, BKV, STV, 4>), grid, dim3(256), lds_, s, g); }
 #define TF_LAUNCH8(BKV, STV) { constexpr size_t lds_ = tf_gemm_lds<BKV, STV>(); hipLaunchKernelGGL((tf_gemm_nt<EPI, BKV, STV, 8>), grid, dim3(512), lds_, s, g); }
     switch (variant) {
