@@ -28,7 +28,7 @@ Ptrs many(int count, size_t n) { Ptrs r; for (int i = 0; i < count; ++i) r.store
 #define EXPECT_FAIL(x) do { if ((x) == PPDE_OK) { fprintf(stderr, "expected an error from %s\n", #x); return 99; } } while (0)
 
 // the full sequence; returns the first non-OK status (after releasing everything it created)
-int sequence(int L, int Lp, int win, bool with_tf, bool verbose) {
+int sequence(int L, int Lp, int win, bool with_tf, bool verbose, int tf_dim = 128, int tf_heads = 4) {
     int status = PPDE_OK;
     ppde_model* m = nullptr;
     ppde_chains *c0 = nullptr, *c1 = nullptr, *c2 = nullptr;
@@ -54,7 +54,7 @@ int sequence(int L, int Lp, int win, bool with_tf, bool verbose) {
         TRY(ppde_model_get_wt_hamiltonian(m, &wtH));
     }
     if (with_tf) {
-        const int layers = 2, dim = 128, heads = 4, ffn = 256;
+        const int layers = 2, dim = tf_dim, heads = tf_heads, ffn = 256;
         auto emb = rnd((size_t)33 * dim);
         auto qw = many(layers, (size_t)dim * dim), kw = many(layers, (size_t)dim * dim), vw = many(layers, (size_t)dim * dim), ow = many(layers, (size_t)dim * dim);
         auto qb = many(layers, dim), kb = many(layers, dim), vb = many(layers, dim), ob = many(layers, dim);
@@ -76,7 +76,7 @@ int sequence(int L, int Lp, int win, bool with_tf, bool verbose) {
         TRY(ppde_energy_grad(m, idx.data(), 2, which, e.data(), fit.data(), nullptr, nullptr));   // smaller batch, no gradient
     }
     if (with_tf) {
-        std::vector<float> act((size_t)n * L * 128);
+        std::vector<float> act((size_t)n * L * ((tf_dim + 127) / 128 * 128));
         TRY(ppde_debug_transformer_read(m, 0, 0, act.data(), (int64_t)act.size()));
     }
     {
@@ -179,6 +179,10 @@ int main(int argc, char** argv) {
     const long fallible = hipmock_calls();
     rc = sequence(110, 100, 2, false, true);                                         // chunked CNN path (L >= 100), ring Potts kernel
     if (rc != PPDE_OK) { fprintf(stderr, "long-sequence run failed: %d (%s)\n", rc, ppde_last_error()); return 1; }
+    rc = sequence(40, 40, 0, true, true, 96, 4);                                      // head width 24: rows padded 96 -> 128
+    if (rc != PPDE_OK) { fprintf(stderr, "head-width-24 run failed: %d (%s)\n", rc, ppde_last_error()); return 1; }
+    rc = sequence(40, 40, 0, true, true, 256, 4);                                     // head width 64
+    if (rc != PPDE_OK) { fprintf(stderr, "head-width-64 run failed: %d (%s)\n", rc, ppde_last_error()); return 1; }
     rc = argument_errors();
     if (rc) { fprintf(stderr, "argument_errors: %d\n", rc); return 1; }
     long failures = 0;
