@@ -4,15 +4,15 @@
 // Replaces Transformer.local_score / forward (reference ppde/nets.py:219-240; the model itself is the third-party
 // `esm_one_hot` ESM-2, see oracle/esm_oracle.py for what is restated and why parity is unpinned) and the autograd
 // of it in ProteinProductOfExperts.get_energy_and_grads (ppde/energy.py:110-130; minibatches of 64 there, the whole
-// population at once here: 288 GB of HBM hold every activation of a 256-chain evaluation, ~13 GB).
+// population at once here: 288 GB of HBM hold every activation of a 256-chain evaluation, ~9 GB).
 //
 // Precision follows the reference's torch.cuda.amp.autocast: every matmul takes fp16 operands and accumulates in
 // fp32 on the matrix cores (v_mfma_f32_16x16x32_f16), activations and activation gradients are stored in fp16 where
 // autocast hands fp16 tensors on, softmax / layer norm / log-softmax statistics are fp32.
 //
 // Kernels: tf_gemm_nt (all linear layers, forward and backward, fused bias / residual / GELU / GELU' epilogues),
-// tf_attn_fwd / tf_attn_bwd (one wavefront per (chain, head): rotary, QK^T, softmax, PV and their gradients on the
-// matrix cores), tf_ln_fwd / tf_ln_bwd, tf_embed, tf_score (log-softmax, score, gradient seeds), tf_finish_grad.
+// tf_attn_fwd / tf_attn_bwd (one workgroup of four waves per (chain, head): rotary, QK^T, softmax, PV and their gradients
+// on the matrix cores; instances for sequences up to 128 / 256 residues and head widths 24 / 32 / 64), tf_ln_fwd / tf_ln_bwd, tf_embed, tf_score (log-softmax, score, gradient seeds), tf_finish_grad.
 #pragma once
 #include "common.h"
 #include <type_traits>
@@ -429,7 +429,7 @@ __global__ void tf_embed(const uint8_t* __restrict__ idx, int Ls, int sh, int L,
 // take the 16-query tiles in turn. qkv [M][3D] as the projection wrote it (q already scaled); the rotary embedding is
 // applied while staging q and k.
 // Orientation: every score tile is computed as S^T = K Q^T (v_mfma 16x16x32, k = head width), so a lane holds 4
-// consecutive KEYS of one query: the softmax reduces in-lane + two lane shuffles, P leaves in 8-byte pieces, and
+// consecutive KEYS of one query: the softmax reduces in-lane + two lane shuffles, and
 // the tile is already the B operand (k = key on the rows) of a v_mfma_f32_16x16x16_f16: P V and dS K need no LDS
 // round trip. Products that contract over the QUERY (dK, dV) take the tile through one 512-byte LDS tile and the
 // transposed read ds_read_b64_tr_b16 (lane maps of both instructions: scripts/probes/mfma_probe.hip).
@@ -456,7 +456,7 @@ struct TfAttnArgs {
 
 // Staging of one head's rows. Every global load of the head is issued before the first value is used (the fetch_*
 // half), then rotated / transposed into LDS (the put_* half): staged array by array, each round of dependent loads
-// cost a full memory latency with two wavefronts to hide it. Items past L write zeros, so the [TP] tiles need no
+// cost a full memory latency with only the head's own wavefronts to hide it. Items past L write zeros, so the [TP] tiles need no
 // clearing pass (the 8 pad columns of the transposed images are never read).
 //   rotary item = (t, c < HD/16): dims 8c..8c+7 and their partners HD/2 + 8c..;  plain item = (t, c < HD/8): dims 8c..
 template <int NTHR, int TP, int HD> struct TfRotRaw { static constexpr int R = (HD / 16) * TP / NTHR; f16x8 x1[R], x2[R]; static_assert((HD / 16) * TP % NTHR == 0, "whole rounds"); };
