@@ -1,8 +1,9 @@
 """Random geometries (sequence length, window, kernel size, experts, batch size) through ppde_energy_grad against the
-oracle. Run on the GPU box: python scripts/fuzz_energy_grad.py [seed]. Exits non-zero on a mismatch."""
+oracle. Run on the GPU box: python tests/fuzz_energy_grad.py [seed]. Exits non-zero on a mismatch."""
 import sys, os, numpy as np, torch
-sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "oracle")); sys.path.insert(0, os.path.join(os.getcwd(), "tests"))
-import ppde_oracle as orc
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for _p in (REPO, os.path.join(REPO, "oracle"), os.path.join(REPO, "tests")):
+    sys.path.insert(0, _p)
 from helpers import oracle_energy
 from ppde_amd import synthetic
 from ppde_amd.energy import HipModel

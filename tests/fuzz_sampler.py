@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Random sampler configurations (geometry, path length, mutation cap, paper_results, experts, chain count, gradient
 reuse, graph replay) on the device RNG against the oracle fed with the device's own dumped noise.
-Run on the GPU box: python scripts/fuzz_sampler.py [seed]. Exits non-zero on a mismatch."""
+Run on the GPU box: python tests/fuzz_sampler.py [seed]. Exits non-zero on a mismatch."""
 import os
 import sys
 

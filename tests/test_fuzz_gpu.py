@@ -1,4 +1,4 @@
-"""Short runs of the two fuzzers (scripts/fuzz_energy_grad.py, scripts/fuzz_sampler.py) with fixed seeds: random
+"""Short runs of the two fuzzers (tests/fuzz_energy_grad.py, tests/fuzz_sampler.py) with fixed seeds: random
 geometries / sampler configurations against the oracle. Each runs in its own process, as on the command line."""
 import os
 import subprocess
@@ -13,7 +13,7 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 @pytest.mark.parametrize("script,seed,trials", [("fuzz_energy_grad.py", 21, 14), ("fuzz_sampler.py", 21, 10)])
 def test_fuzz(script, seed, trials):
     env = dict(os.environ, FZ_TRIALS=str(trials))
-    r = subprocess.run([sys.executable, os.path.join(REPO, "scripts", script), str(seed)], env=env, capture_output=True,
+    r = subprocess.run([sys.executable, os.path.join(REPO, "tests", script), str(seed)], env=env, capture_output=True,
                        text=True, timeout=600)
     assert "Memory access fault" not in r.stdout + r.stderr, r.stdout[-2000:] + r.stderr[-2000:]
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]

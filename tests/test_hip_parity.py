@@ -345,7 +345,7 @@ def test_long_replay_stays_on_the_oracle_trajectory():
 def test_masked_entry_winning_the_race_keeps_the_clamp_probability():
     """clamp_probs leaves every masked entry with probability 2^-23, so with a narrow proposal range a masked move wins
     the exponential race now and then; its forward log-probability is log(2^-23 / sum), not that of its unmasked logit
-    (found by scripts/fuzz_sampler.py). Device RNG, oracle fed with the device's noise."""
+    (found by tests/fuzz_sampler.py). Device RNG, oracle fed with the device's noise."""
     from ppde_amd.energy import HipModel
     from ppde_amd.sampler import Chains
     from ppde_amd import synthetic

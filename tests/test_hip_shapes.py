@@ -55,7 +55,7 @@ def test_energy_grad_shapes(L, Lp, i0, with_cnn):
 @pytest.mark.parametrize("L,K", [(50, 3), (150, 3), (278, 3), (120, 7)])
 def test_cnn_other_kernel_size(L, K):
     """kernel sizes other than 5 go through the zero-padded 8-tap instantiation, single-launch and chunked
-    (278 x 3: found by scripts/fuzz_energy_grad.py, the forward chunk read letters of rows it had not staged)"""
+    (278 x 3: found by tests/fuzz_energy_grad.py, the forward chunk read letters of rows it had not staged)"""
     m, wt, J, h, cnn = _model(L, 30, 10, True, 2.0, K=K)
     en = oracle_energy(J, h, 10, wt, cnn, 2.0)
     idx = np.random.default_rng(0).integers(0, 20, (6, L)).astype(np.uint8)
