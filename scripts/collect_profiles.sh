@@ -56,7 +56,10 @@ python3 "$ROOT/scripts/tune_tf_gemm.py" 64x2 64x2w8 32x3 2>&1 | grep -v amdgpu.i
 { echo "# python scripts/probes/sdpa_yardstick.py   (torch scaled_dot_product_attention, fp16, 256 x 20 heads x 104 x 32; compare tf_attn_fwd / tf_attn_bwd in ${TAG}_transformer_kernel_stats.csv, which also apply the rotary embedding)";
   python3 "$ROOT/scripts/probes/sdpa_yardstick.py" 2>&1 | grep -v amdgpu.ids; } > "$P/${TAG}_attention_vendor_yardstick.log" || true
 echo "transformer done"
-# 3c. probes quoted in DESIGN.md
+# 3c. probes quoted in DESIGN.md (built here if the binaries did not travel)
+for pr in xcd_probe mfma_probe; do
+    [ -x "$ROOT/scripts/probes/$pr" ] || /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 "$ROOT/scripts/probes/$pr.hip" -o "$ROOT/scripts/probes/$pr" || true
+done
 (cd "$ROOT" && timeout -k 10 120 scripts/probes/xcd_probe > "$P/${TAG}_xcd_probe.log" 2>&1; timeout -k 10 60 scripts/probes/mfma_probe > "$P/${TAG}_mfma_probe.log" 2>&1) || true
 # 4. in-kernel stamps (diagnostic build; shares, not lengths) and the per-workgroup Potts timelines
 cd "$ROOT"
