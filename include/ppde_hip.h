@@ -31,7 +31,7 @@
  *   - supervised expert: 1..4 networks of one shape, kernel size 1..8, embedding width F <= 512
  *     for the single-launch kernel (wider or longer networks take the chunked kernels);
  *   - transformer expert: head width 24, 32 or 64, dim a multiple of 8 (<= 1536; padded to a multiple of 128 internally), ffn a
- *     multiple of 128, L <= 256 (128 at head width 64);
+ *     multiple of 128, L <= 256;
  *   - ppde_pas_length 1..64; chain_offset + n_chains < 2^32.
  */
 #ifndef PPDE_HIP_H
@@ -91,7 +91,7 @@ int ppde_model_set_cnn(ppde_model* m, int n_nets, int C, int K, int F,
  * `esm_one_hot` package + torch hub; here the caller passes ESM-2's parameters (fp32, host), named as in
  * facebookresearch/esm's ESM2: per-layer arrays have n_layers entries. Written for head widths 24, 32 and 64
  * (esm2_t12_35M: dim 480, 20 heads, ffn 1920; esm2_t30_150M: 640, 20, 2560; esm2_t33_650M: 1280, 20, 5120), ffn a multiple
- * of 128, L <= 256 (128 at head width 64). Also evaluates the wild
+ * of 128, L <= 256. Also evaluates the wild
  * type's score. */
 typedef struct {
     const float* embed;                 /* embed_tokens.weight [33][dim] (also the tied LM-head projection) */

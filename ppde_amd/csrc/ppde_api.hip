@@ -471,7 +471,7 @@ int ppde_model_set_transformer(ppde_model* m, int n_layers, int dim, int heads, 
     ARGCHK(heads >= 1 && (dim == heads * 24 || dim == heads * 32 || dim == heads * 64),
            "the attention kernels are written for head widths 24, 32 and 64 (ESM-2 35M: 480 / 20, 150M: 640 / 20, 650M: 1280 / 20)");
     ARGCHK(dim % 8 == 0 && ffn % 128 == 0 && dim <= TF_LN_MAXD, "dim must be a multiple of 8 (<= 1536), ffn a multiple of 128");
-    ARGCHK(m->L <= (dim == heads * 64 ? 128 : TF_TP_MAX), "the transformer expert handles sequences of up to 256 residues (128 at head width 64)");
+    ARGCHK(m->L <= TF_TP_MAX, "the transformer expert handles sequences of up to 256 residues");
     HIPCHK(hipSetDevice(m->device));
     delete m->tf; m->tf = nullptr;
     delete m->s_tfw; m->s_tfw = nullptr;

@@ -728,14 +728,20 @@ __global__ __launch_bounds__(64 * TF_ATT_WAVES_F) void tf_attn_fwd(TfAttnArgs a)
 //   dQ, dK and the q scaling. The waves of a head take the query tiles in turn; dK and dV are summed over the waves in
 //   a fixed order at the end.
 // LDS: v rows | dO rows | dO^T | k^T (rotated) | q^T (rotated) | k rows | q rows | per wave transpose tiles | row statistics
-template <int TP, int HD> __host__ __device__ constexpr int tf_att_stage() { return 4 * TP * tf_lds_width(HD) + 3 * tf_lds_width(HD) * (TP + 8); }
+// (TP = 256 with head width 64: the three transposed images do not fit a CU's LDS next to the row-major ones; that instance
+//  reads the transposed operands from the row-major tiles with ds_read_b64_tr_b16 instead — bank conflicts and all)
+constexpr bool tf_rows_only(int TP, int HD) { return TP == 256 && HD == 64; }
+template <int TP, int HD> __host__ __device__ constexpr int tf_att_stage() {
+    return 4 * TP * tf_lds_width(HD) + (tf_rows_only(TP, HD) ? 0 : 3 * tf_lds_width(HD) * (TP + 8));
+}
 #define TF_ATT_TRB 4                 // key tiles turned query-major per batch (two 512-byte tiles each)
 template <int TP, int HD> __host__ __device__ constexpr size_t tf_attn_bwd_lds() {
     const size_t image = (size_t)(tf_att_stage<TP, HD>() + TF_ATT_WAVES_B * TF_ATT_TRB * 512) * 2 + TP * sizeof(float2);
     const size_t swap = (size_t)TF_ATT_WAVES_B * (4 * 32 / tf_lds_width(HD)) * (tf_lds_width(HD) / 16) * 2 * 1024;   // four waves x half a pass's key tiles x HD/16 x (dK, dV) x 1 KiB
     return image > swap ? image : swap;
 }
-static_assert(tf_attn_bwd_lds<256, 32>() <= 160 * 1024 && tf_attn_bwd_lds<128, 64>() <= 160 * 1024, "one workgroup must fit a CU's LDS");
+static_assert(tf_attn_bwd_lds<256, 32>() <= 160 * 1024 && tf_attn_bwd_lds<128, 64>() <= 160 * 1024 && tf_attn_bwd_lds<256, 64>() <= 160 * 1024 &&
+              tf_attn_fwd_lds<256, 64>() <= 160 * 1024, "one workgroup must fit a CU's LDS");
 
 // tiles J0 .. J0 + NJ - 1 of a wave's partial sums to / from its LDS slot
 template <int J0, int NJ, int ND, int NKT>
@@ -814,7 +820,8 @@ __global__ __launch_bounds__(64 * TF_ATT_WAVES_B, (TP == 128 && HD == 32) ? 2 : 
     constexpr int HL = tf_lds_width(HD);          // head width in LDS (24 -> 32)
     constexpr int NKT = TP / 16, LDP = TP + 8, ND = HL / 16, NDH = ND / 2;
     constexpr int KH = 8 * 32 / HL, NH = NKT / KH;              // key tiles per pass (128 accumulator registers), passes
-    static_assert(NH == 1 || NH == 2, "one or two passes");
+    static_assert(NH == 1 || NH == 2 || NH == 4, "one, two or four passes");
+    constexpr bool RO = tf_rows_only(TP, HD);                   // no transposed images: transposed operands by ds_read_b64_tr_b16
     constexpr int TRB = TF_ATT_TRB;
     extern __shared__ __attribute__((aligned(16))) unsigned char tf_smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -822,10 +829,10 @@ __global__ __launch_bounds__(64 * TF_ATT_WAVES_B, (TP == 128 && HD == 32) ? 2 : 
     const int L = a.L, D = a.D, ld = 3 * D;
     half_t* sV = (half_t*)tf_smem;                             // [TP][HL]
     half_t* sdO = sV + TP * HL;                                // [TP][HL]
-    half_t* sdOt = sdO + TP * HL;                              // [HL][LDP]
-    half_t* sKt = sdOt + HL * LDP;                             // [HL][LDP] rotated k, transposed
-    half_t* sQt = sKt + HL * LDP;                              // [HL][LDP] rotated q, transposed
-    half_t* sK = sQt + HL * LDP;                               // [TP][HL] rotated k
+    half_t* sdOt = sdO + TP * HL;                              // [HL][LDP]   (the three transposed images: absent if RO)
+    half_t* sKt = sdOt + (RO ? 0 : HL * LDP);                  // [HL][LDP] rotated k, transposed
+    half_t* sQt = sKt + (RO ? 0 : HL * LDP);                   // [HL][LDP] rotated q, transposed
+    half_t* sK = sQt + (RO ? 0 : HL * LDP);                    // [TP][HL] rotated k
     half_t* sQ = sK + TP * HL;                                 // [TP][HL] rotated q
     half_t* sT = sQ + TP * HL + wave * TF_ATT_TRB * 512;       // this wave's transpose tiles: TF_ATT_TRB x (dS, P) of 16 x 16
     float2* sStat = (float2*)((half_t*)tf_smem + tf_att_stage<TP, HD>() + TF_ATT_WAVES_B * TF_ATT_TRB * 512);   // [TP] softmax row statistics
@@ -838,6 +845,18 @@ __global__ __launch_bounds__(64 * TF_ATT_WAVES_B, (TP == 128 && HD == 32) ? 2 : 
     // column fr of rows 4 fg .. 4 fg + 3
     typedef __attribute__((address_space(3))) tf_hfx4* lds_tr_ptr;
     const int tr_off = (4 * fg + (fr >> 2)) * 16 + 4 * (fr & 3);
+    // A operand X^T [d = 16 dj + fr][k = 16 t + 4 fg ..] of the 16x16x16 MFMA: from the transposed image, or (RO) from the
+    // row-major tile X [16 t + ..][16 dj + ..] by the transposed read
+    auto tr_operand = [&](const half_t* img_t, const half_t* rows, int dj, int t) -> f16x4 {
+        if constexpr (!RO) return *(const f16x4*)(img_t + (dj * 16 + fr) * LDP + t * 16 + 4 * fg);
+        else {
+            const tf_hfx4 v = __builtin_amdgcn_ds_read_tr16_b64_v4f16((lds_tr_ptr)(rows + (t * 16 + 4 * fg + (fr >> 2)) * HL + dj * 16 + 4 * (fr & 3)));
+            f16x4 o;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[r] = (half_t)v[r];
+            return o;
+        }
+    };
 
     auto pass = [&](auto half_c) {
         constexpr int HALF = decltype(half_c)::value, J0 = HALF * KH;        // this pass owns key tiles J0 .. J0 + KH - 1
@@ -870,9 +889,9 @@ __global__ __launch_bounds__(64 * TF_ATT_WAVES_B, (TP == 128 && HD == 32) ? 2 : 
             if constexpr (HALF > 0) __syncthreads();                         // the previous pass has read its partial sums
             tf_put_plain<false>(rv, L, tid, sV);
             tf_put_plain<false>(ro, L, tid, sdO);
-            tf_put_plain<true>(ro, L, tid, sdOt);
-            tf_put_rot<true, true>(rk, rp, L, tid, sK, sKt);
-            tf_put_rot<true, true>(rq, rp, L, tid, sQ, sQt);
+            if constexpr (!RO) tf_put_plain<true>(ro, L, tid, sdOt);
+            tf_put_rot<true, !RO>(rk, rp, L, tid, sK, sKt);
+            tf_put_rot<true, !RO>(rq, rp, L, tid, sQ, sQt);
             for (int t = tid; t < TP; t += 64 * TF_ATT_WAVES_B) sStat[t] = t < L ? a.stat[(size_t)(b * a.H + h) * L + t] : make_float2(0.f, 0.f);
         }
         __syncthreads();
@@ -917,7 +936,7 @@ __global__ __launch_bounds__(64 * TF_ATT_WAVES_B, (TP == 128 && HD == 32) ? 2 : 
                         // dQ^T [d][query] += Kr^T (rows d, k = these keys) x dS^T (k = key on the rows: the tile as it stands)
 #pragma unroll
                         for (int dj = 0; dj < ND; ++dj) {
-                            const f16x4 kf = *(const f16x4*)(sKt + (dj * 16 + fr) * LDP + j * 16 + 4 * fg);
+                            const f16x4 kf = tr_operand(sKt, sK, dj, j);
                             o[dj] = __builtin_amdgcn_mfma_f32_16x16x16f16(kf, ds[j], o[dj], 0, 0, 0);
                         }
                     }
@@ -945,8 +964,8 @@ __global__ __launch_bounds__(64 * TF_ATT_WAVES_B, (TP == 128 && HD == 32) ? 2 : 
             f16x4 qfd[ND], ofd[ND];
 #pragma unroll
             for (int dj = 0; dj < ND; ++dj) {
-                qfd[dj] = *(const f16x4*)(sQt + (dj * 16 + fr) * LDP + qi * 16 + 4 * fg);
-                ofd[dj] = *(const f16x4*)(sdOt + (dj * 16 + fr) * LDP + qi * 16 + 4 * fg);
+                qfd[dj] = tr_operand(sQt, sQ, dj, qi);
+                ofd[dj] = tr_operand(sdOt, sdO, dj, qi);
             }
 #pragma unroll
             for (int jb = 0; jb < KH; jb += TRB) {
@@ -993,7 +1012,8 @@ __global__ __launch_bounds__(64 * TF_ATT_WAVES_B, (TP == 128 && HD == 32) ? 2 : 
         }
     };
     pass(std::integral_constant<int, 0>{});
-    if constexpr (NH == 2) pass(std::integral_constant<int, 1>{});
+    if constexpr (NH >= 2) pass(std::integral_constant<int, 1>{});
+    if constexpr (NH == 4) { pass(std::integral_constant<int, 2>{}); pass(std::integral_constant<int, 3>{}); }
 }
 
 // ------------------------------------------------------------------------------------------------------------

@@ -240,7 +240,8 @@ static int tf_eval(const TfModel* t, TfWork* wk, const uint8_t* rows, int Ls, in
         TfAttnArgs at{a.qkv, wk->ctx, a.stat, t->rope_cos, t->rope_sin, nullptr, nullptr, n, L, H, D, qs};
         if (t->HD == 24 && L <= 128) hipLaunchKernelGGL((tf_attn_fwd<128, 24>), dim3(n * H), dim3(64 * TF_ATT_WAVES_F), (tf_attn_fwd_lds<128, 24>()), s, at);
         else if (t->HD == 24) hipLaunchKernelGGL((tf_attn_fwd<256, 24>), dim3(n * H), dim3(64 * TF_ATT_WAVES_F), (tf_attn_fwd_lds<256, 24>()), s, at);
-        else if (t->HD == 64) hipLaunchKernelGGL((tf_attn_fwd<128, 64>), dim3(n * H), dim3(64 * TF_ATT_WAVES_F), (tf_attn_fwd_lds<128, 64>()), s, at);
+        else if (t->HD == 64 && L <= 128) hipLaunchKernelGGL((tf_attn_fwd<128, 64>), dim3(n * H), dim3(64 * TF_ATT_WAVES_F), (tf_attn_fwd_lds<128, 64>()), s, at);
+        else if (t->HD == 64) hipLaunchKernelGGL((tf_attn_fwd<256, 64>), dim3(n * H), dim3(64 * TF_ATT_WAVES_F), (tf_attn_fwd_lds<256, 64>()), s, at);
         else if (L <= 128) hipLaunchKernelGGL((tf_attn_fwd<128, 32>), dim3(n * H), dim3(64 * TF_ATT_WAVES_F), (tf_attn_fwd_lds<128, 32>()), s, at);
         else hipLaunchKernelGGL((tf_attn_fwd<256, 32>), dim3(n * H), dim3(64 * TF_ATT_WAVES_F), (tf_attn_fwd_lds<256, 32>()), s, at);
         HIPCHK(hipGetLastError());
@@ -282,7 +283,8 @@ static int tf_eval(const TfModel* t, TfWork* wk, const uint8_t* rows, int Ls, in
         TfAttnArgs at{a.qkv, nullptr, a.stat, t->rope_cos, t->rope_sin, wk->tmpD, wk->dqkv, n, L, H, D, qs};
         if (t->HD == 24 && L <= 128) hipLaunchKernelGGL((tf_attn_bwd<128, 24>), dim3(n * H), dim3(64 * TF_ATT_WAVES_B), (tf_attn_bwd_lds<128, 24>()), s, at);
         else if (t->HD == 24) hipLaunchKernelGGL((tf_attn_bwd<256, 24>), dim3(n * H), dim3(64 * TF_ATT_WAVES_B), (tf_attn_bwd_lds<256, 24>()), s, at);
-        else if (t->HD == 64) hipLaunchKernelGGL((tf_attn_bwd<128, 64>), dim3(n * H), dim3(64 * TF_ATT_WAVES_B), (tf_attn_bwd_lds<128, 64>()), s, at);
+        else if (t->HD == 64 && L <= 128) hipLaunchKernelGGL((tf_attn_bwd<128, 64>), dim3(n * H), dim3(64 * TF_ATT_WAVES_B), (tf_attn_bwd_lds<128, 64>()), s, at);
+        else if (t->HD == 64) hipLaunchKernelGGL((tf_attn_bwd<256, 64>), dim3(n * H), dim3(64 * TF_ATT_WAVES_B), (tf_attn_bwd_lds<256, 64>()), s, at);
         else if (L <= 128) hipLaunchKernelGGL((tf_attn_bwd<128, 32>), dim3(n * H), dim3(64 * TF_ATT_WAVES_B), (tf_attn_bwd_lds<128, 32>()), s, at);
         else hipLaunchKernelGGL((tf_attn_bwd<256, 32>), dim3(n * H), dim3(64 * TF_ATT_WAVES_B), (tf_attn_bwd_lds<256, 32>()), s, at);
         HIPCHK(hipGetLastError());

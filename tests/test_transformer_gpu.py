@@ -50,6 +50,8 @@ def _read(m, what, layer, shape):
                                                        (256, 2, 128, 4, 256, 2),        # the longest sequence supported
                                                        (24, 2, 256, 4, 512, 4),         # head width 64, toy
                                                        (128, 2, 256, 4, 512, 2),        # head width 64, full length
+                                                       (237, 2, 256, 4, 512, 2),        # head width 64, GFP length (rows-only LDS image, four passes)
+                                                       (256, 2, 128, 2, 256, 2),        # head width 64, the longest sequence
                                                        (104, 33, 1280, 20, 5120, 2),    # esm2_t33_650M shapes (transformer-L)
                                                        (24, 2, 96, 4, 256, 4),          # head width 24 (rows padded 96 -> 128), toy
                                                        (237, 2, 96, 4, 256, 2),         # head width 24, GFP length
