@@ -34,10 +34,19 @@ def main(args, rank, world, local, backend):
     from ppde_amd.encoding import seqs_to_idx
     from ppde_amd.energy import HipModel
     from ppde_amd.sampler import Chains
-    assert world == 1, "the transformer workload is a single-GPU configuration (BASELINE configs[4])"
     assert torch.cuda.is_available(), "bench.py needs a HIP device; there is no CPU fallback for the product path"
     device = f"cuda:{local}"
     torch.cuda.set_device(local)
+    if world > 1:        # BASELINE configs[4] is a one-GPU configuration; more ranks = weak scaling, 256 chains each, no exchange
+        import torch.distributed as dist
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
     steps = args.steps if args.steps != 2000 else 20            # (the defaults of the Potts workload would run for minutes)
     warmup = args.warmup if args.warmup != 200 else 3
     repeats = min(args.repeats, 3)
@@ -57,18 +66,26 @@ def main(args, rank, world, local, backend):
     T = warmup + repeats * steps + 4
 
     def timed(reuse):
-        ch = Chains(m, n, T, args.pas, args.nmut, False, 0, L - 1, 6, 1, reuse_grad=reuse, random_chain=0, use_graph=False, seed=1)
+        ch = Chains(m, n, T, args.pas, args.nmut, False, 0, L - 1, 6, 1, reuse_grad=reuse, random_chain=0, use_graph=False, seed=1,
+                    chain_offset=rank * n)
         ch.init(torch.as_tensor(np.tile(wt, (n, 1))).to(device))
         ch.run(warmup)
         ch.sync()
         dts = []
         for _ in range(repeats):
             torch.cuda.synchronize()
+            barrier()
             t0 = time.perf_counter()
             ch.run(steps)
             ch.sync()
             torch.cuda.synchronize()
-            dts.append(time.perf_counter() - t0)
+            d = time.perf_counter() - t0
+            barrier()
+            if world > 1:
+                t = torch.tensor([d], device=device if backend == "nccl" else "cpu", dtype=torch.float64)
+                torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+                d = float(t.item())
+            dts.append(d)
         res = ch.collect()
         assert np.isfinite(res["energy_history"]).all()
         return float(np.median(dts)), dts
@@ -98,15 +115,16 @@ def main(args, rank, world, local, backend):
 
     out = {
         "metric": f"MCMC steps/sec ({n} chains, UBE4B transformer PoE)",
-        "value": steps / dt, "unit": "steps/s", "n_gpus": 1, "steps": steps, "warmup": warmup,
+        "value": world * steps / dt, "unit": "steps/s", "n_gpus": world, "steps": steps, "warmup": warmup,
         "ms_per_step": dt / steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f16 (fp32 accumulate and statistics, as the reference's autocast)", "data": "synthetic",
         "config": {"workload": f"UBE4B_MOUSE transformer unsupervised expert (ESM-2 shapes: {layers} layers x {D}, {H} heads, ffn {F}; "
                                f"seeded random weights) + supervised CNN (lamda={lam}), L={L}, A=20, {n} chains, pas_length={args.pas}, "
                                "device Philox RNG, all chains start at WT",
-                   "chains_per_gpu": n, "total_chains": n, "parallelism": "1 GPU",
+                   "chains_per_gpu": n, "total_chains": n * world,
+                   "parallelism": "1 GPU" if world == 1 else f"chains sharded x{world}, no per-step collective",
                    "energy_evaluations_per_step": 1 if args.reuse_grad else 2},
-        "chain_steps_per_s": n * steps / dt,
+        "chain_steps_per_s": world * n * steps / dt,
         "timed_blocks": {"repeats": len(dts), "statistic": "median", "ms_per_block": [round(x * 1e3, 3) for x in dts]},
         "graph_captured_in_timed_region": False,
         "roofline": {"kernel": "tf_gemm_nt<bias+GELU> (fc1 shape)", "bound": "mfma", "achieved": gemm_tf, "peak": MFMA_F16_PEAK_TF / 1.0,
@@ -117,9 +135,11 @@ def main(args, rank, world, local, backend):
                      "avg_launch_us_random_operands_back_to_back": us_rand.value},
         "evaluation": {"ms": ev * 1e3, "algorithmic_tflop": fl / 1e12, "tflops": fl / ev / 1e12,
                        "note": "one transformer energy+gradient evaluation of all chains (forward + input gradient, every kernel)"},
-        ("value_reuse_grad" if not args.reuse_grad else "value_reevaluate"): steps / dt_other,
+        ("value_reuse_grad" if not args.reuse_grad else "value_reevaluate"): world * steps / dt_other,
     }
-    if not args.no_cpu_baseline:
+    if world > 1:
+        out["backend"] = backend
+    if world == 1 and not args.no_cpu_baseline:
         sys.path.insert(0, os.path.join(REPO, "oracle"))
         import esm_oracle as eo
         cores = min(os.cpu_count() or 1, 16)
@@ -134,4 +154,7 @@ def main(args, rank, world, local, backend):
                                "sample": f"ONE transformer energy+gradient evaluation of {ns} chains through oracle/esm_oracle.py ({te:.1f} s), "
                                          f"scaled to {n} chains and two evaluations per step; the supervised CNN and the sampler "
                                          "arithmetic are not included (they are < 1 % of the step on the CPU)"}
-    print(json.dumps(out), flush=True)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
