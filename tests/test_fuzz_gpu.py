@@ -1,4 +1,4 @@
-"""Short runs of the two fuzzers (tests/fuzz_energy_grad.py, tests/fuzz_sampler.py) with fixed seeds: random
+"""Short runs of the fuzzers (tests/fuzz_energy_grad.py, tests/fuzz_sampler.py, tests/fuzz_transformer.py) with fixed seeds: random
 geometries / sampler configurations against the oracle. Each runs in its own process, as on the command line."""
 import os
 import subprocess
@@ -10,7 +10,7 @@ pytestmark = pytest.mark.gpu
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("script,seed,trials", [("fuzz_energy_grad.py", 21, 14), ("fuzz_sampler.py", 21, 10)])
+@pytest.mark.parametrize("script,seed,trials", [("fuzz_energy_grad.py", 21, 14), ("fuzz_sampler.py", 21, 10), ("fuzz_transformer.py", 21, 10)])
 def test_fuzz(script, seed, trials):
     env = dict(os.environ, FZ_TRIALS=str(trials))
     r = subprocess.run([sys.executable, os.path.join(REPO, "tests", script), str(seed)], env=env, capture_output=True,
