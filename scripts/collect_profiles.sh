@@ -15,6 +15,12 @@ python3 "$ROOT/bench.py" > "$OUT/prof_${TAG}_bench_stdout.log" 2>&1
 python3 "$ROOT/bench.py" --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline > "$OUT/prof_${TAG}_bench_steps20.log" 2>&1
 grep '^{' "$OUT/prof_${TAG}_bench_stdout.log" > "$P/${TAG}_bench_stdout.log"
 grep '^{' "$OUT/prof_${TAG}_bench_steps20.log" > "$P/${TAG}_bench_steps20_stdout.log"
+# 1b. the multi-rank path with no external launcher, rehearsed on ONE card (all ranks on GPU 0, gloo instead of RCCL:
+#     two RCCL ranks cannot share a device): bench.py starts its own ranks and relays rank 0's line
+PPDE_BENCH_ONE_GPU=1 PPDE_BENCH_BACKEND=gloo python3 "$ROOT/bench.py" --gpus 2 --no-large > "$OUT/prof_${TAG}_gpus2.log" 2>&1 || true
+grep '^{' "$OUT/prof_${TAG}_gpus2.log" > "$P/${TAG}_bench_gpus2_one_card_gloo.log" || true
+PPDE_BENCH_ONE_GPU=1 PPDE_BENCH_BACKEND=gloo python3 "$ROOT/bench.py" --gpus 4 --protein GFP --steps 200 --warmup 20 --no-large > "$OUT/prof_${TAG}_gpus4_gfp.log" 2>&1 || true
+grep '^{' "$OUT/prof_${TAG}_gpus4_gfp.log" > "$P/${TAG}_bench_gpus4_gfp_one_card_gloo.log" || true
 echo "bench done"
 # 2. per-kernel table of the same command (config 2), and of config 3, GFP, UBE4B, 1024 chains
 stats() {   # name, bench args...
