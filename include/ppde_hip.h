@@ -45,6 +45,8 @@ extern "C" {
 
 #define PPDE_ABI_VERSION 1
 #define PPDE_ALPHABET 20
+/* `which` bit 3, see ppde_energy_grad */
+#define PPDE_WHICH_FULL_GRAD 8
 
 typedef enum {
     PPDE_OK = 0,
@@ -149,7 +151,12 @@ int ppde_idx_to_onehot(ppde_model* m, const uint8_t* idx_dev, int n, float* x_de
  * is not NULL, grad_dev [n, L, 20] = d e.sum() / d x. which: bit 0 = Potts expert, bit 1 = supervised expert,
  * bit 2 = transformer expert; 3 = Potts product of experts, 6 = transformer product of experts
  * (`--unsupervised_expert transformer`), 7 = `potts+transformer`. With which == 2, e = fit and grad = d fit/dx
- * (ProteinSupervised, energy.py:153-160); without bit 1, fit = 0. */
+ * (ProteinSupervised, energy.py:153-160); without bit 1, fit = 0.
+ * The gradient follows the reference branch by branch: for the Potts product of experts (3) it is
+ * d(dH + lamda * fit)/dx (energy.py:105-108); with the transformer expert (6, 7) the reference computes fit from x
+ * but differentiates with respect to the minibatch SLICE of x (energy.py:115, :125), so lamda * d fit/dx never
+ * reaches grad_x: grad = d(unsupervised experts)/dx only, while e still holds + lamda * fit (and no CNN backward
+ * runs). Bit 3 (PPDE_WHICH_FULL_GRAD, `args.ppde_full_grad`) opts into d e/dx with the supervised term for 6 / 7. */
 int ppde_energy_grad(ppde_model* m, const uint8_t* idx_dev, int n, int which,
                      float* e_dev, float* fit_dev, float* grad_dev, void* stream);
 
@@ -165,7 +172,7 @@ typedef struct {
     int32_t paper_results;   /* args.paper_results (ppde.py:14,76,148) */
     int32_t min_pos;         /* proposals restricted to residues [min_pos, max_pos] (ppde.py:60-63) */
     int32_t max_pos;
-    int32_t which;           /* experts in the energy, as in ppde_energy_grad */
+    int32_t which;           /* experts in the energy (+ PPDE_WHICH_FULL_GRAD), as in ppde_energy_grad */
     int32_t rng_mode;        /* 0 = noise supplied by the caller per step (parity with a host generator),
                                 1 = counter-based Philox4x32-10 on the device */
     int32_t reuse_grad;      /* 1 = keep energy/gradient of the current state from the previous iteration

@@ -138,3 +138,25 @@ class EsmOracle:
         s = self.score(x)
         g = torch.autograd.grad([s.sum()], x)[0]
         return s.detach(), g
+
+
+class TransformerDelta:
+    """The transformer expert as the product of experts sees it (nets.py:235-240 `Transformer.forward(delta=True)`):
+    local score minus the wild type's, and its gradient on the Potts one-hot. `chunk` evaluates that many chains at a time
+    (the reference's minibatch loop, energy.py:113-127: a chain's numbers do not depend on it beyond matmul blocking)."""
+
+    def __init__(self, esm, wt_idx, chunk=64):
+        self.esm, self.chunk = esm, int(chunk)
+        self.wt_score = float(esm.score_grad(np.asarray(wt_idx, dtype=np.int64).reshape(1, -1))[0][0])
+
+    def energy_grad(self, idx):
+        idx = np.asarray(idx, dtype=np.int64)
+        s, g = zip(*[self.esm.score_grad(idx[i:i + self.chunk]) for i in range(0, idx.shape[0], self.chunk)])
+        return torch.cat(s, 0) - self.wt_score, torch.cat(g, 0)
+
+    def energy(self, idx):
+        idx = torch.as_tensor(np.asarray(idx, dtype=np.int64))
+        with torch.no_grad():
+            x = torch.nn.functional.one_hot(idx, 20).float()
+            s = [self.esm.score(x[i:i + self.chunk]) for i in range(0, x.shape[0], self.chunk)]
+        return torch.cat(s, 0) - self.wt_score

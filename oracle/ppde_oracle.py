@@ -10,7 +10,8 @@ Gibbs-with-gradients / path-auxiliary sampler inner loop and the energy evaluati
                                  + autograd of it at ppde/energy.py:108
   CnnOracle.fit_grad          <- ppde/nets.py:363-376 (OnehotCNN.forward), :434-442 (EnsembleProtein.__call__)
                                  + autograd of it at ppde/energy.py:108
-  EnergyOracle.energy_grad    <- ppde/energy.py:97-108,132 (ProteinProductOfExperts.get_energy[_and_grads], potts branch)
+  EnergyOracle.energy_grad    <- ppde/energy.py:97-132 (ProteinProductOfExperts.get_energy[_and_grads]: potts branch, and the
+                                 transformer / potts+transformer branch with its gradient w.r.t. the minibatch slice)
   AlrOracle.__call__          <- ppde/nets.py:332-347 (AugmentedLinearRegression.forward, the ground-truth model)
   categorical_probs           <- ppde/utils.py:106-111 (safe_logits_to_probs) followed by
                                  torch.distributions.Categorical.__init__ (probs / probs.sum)
@@ -137,25 +138,42 @@ class CnnOracle:
 
 
 class EnergyOracle:
-    """e = Delta-H_potts(x) + lamda * fit(x);  grad = dH/dx + lamda * d fit/dx   (energy.py:97-108)."""
+    """e = unsupervised(x) + lamda * fit(x)   (energy.py:97-132).
 
-    def __init__(self, potts, cnn, lamda):
-        self.potts, self.cnn, self.lamda = potts, cnn, float(lamda)
+    potts branch (`tf is None`, energy.py:105-108):  unsupervised = Delta-H_potts,  grad = dH/dx + lamda * d fit/dx.
+    transformer branches (energy.py:110-130; `tf` = an object with .energy_grad(idx) -> (Delta-score [n], grad [n,L,A]),
+    e.g. esm_oracle.TransformerDelta; `potts` may be None): unsupervised = [Delta-H +] Delta-score (nets.py:311-312),
+    and the gradient is the UNSUPERVISED experts' only: the reference computes fit from x (:104) but differentiates
+    w.r.t. the minibatch slice x_batch (:115, :125), which fit does not depend on through the graph, so
+    lamda * d fit/dx never reaches grad_x. `full_grad=True` adds it (the product's opt-in, not the reference)."""
+
+    def __init__(self, potts, cnn, lamda, tf=None, full_grad=False):
+        self.potts, self.cnn, self.lamda, self.tf, self.full_grad = potts, cnn, float(lamda), tf, bool(full_grad)
+
+    def _unsupervised(self, idx, want_grad):
+        if self.tf is None:
+            return self.potts.energy_grad(idx)
+        dT, gT = self.tf.energy_grad(idx) if want_grad else (self.tf.energy(idx), None)
+        if self.potts is None:
+            return dT, gT
+        dH, gH = self.potts.energy_grad(idx)
+        return dH + dT, (gH + gT if want_grad else None)
 
     def energy(self, idx):
-        dH, _ = self.potts.energy_grad(idx)
+        un, _ = self._unsupervised(idx, False)
         if self.cnn is None:
             fit = torch.zeros(idx.shape[0])
         else:
             fit, _ = self.cnn.fit_grad(idx, want_grad=False)
-        return dH + self.lamda * fit, fit
+        return un + self.lamda * fit, fit
 
     def energy_grad(self, idx):
-        dH, g = self.potts.energy_grad(idx)
+        un, g = self._unsupervised(idx, True)
         if self.cnn is None:
-            return dH, torch.zeros(idx.shape[0]), g
-        fit, gf = self.cnn.fit_grad(idx)
-        return dH + self.lamda * fit, fit, g + self.lamda * gf
+            return un, torch.zeros(idx.shape[0]), g
+        with_fit_grad = self.tf is None or self.full_grad
+        fit, gf = self.cnn.fit_grad(idx, want_grad=with_fit_grad)
+        return un + self.lamda * fit, fit, (g + self.lamda * gf if with_fit_grad else g)
 
 
 # --------------------------------------------------------------------------------------------------
@@ -229,21 +247,24 @@ def forward_logits(grad, idx, wt_idx, min_pos, max_pos, nmut_threshold):
 # --------------------------------------------------------------------------------------------------
 # one MCMC iteration and the full run
 # --------------------------------------------------------------------------------------------------
-def pas_iteration(energy, idx_cur, idx_reject, wt_idx, U, q, u, min_pos, max_pos, nmut_threshold):
+def pas_iteration(energy, idx_cur, idx_reject, wt_idx, U, q, u, min_pos, max_pos, nmut_threshold, keep_probs=False):
     """One path-auxiliary iteration for all chains.
 
     idx_cur     int64 [n, L]  state the iteration starts from
     idx_reject  int64 [n, L]  state a rejected chain falls back to (== idx_cur unless paper_results)
     U           int64 [n]     path lengths;  q fp32 [max_u, n, L*A];  u fp32 [n]
-    Returns a dict with the new state and every intermediate the parity tests look at.
+    Returns a dict with the new state and every intermediate the parity tests look at (keep_probs: also the forward
+    proposal distributions `p_fwd` [max_u, n, L*A], from which a test can read how close a draw was to a tie).
     """
     n, L = idx_cur.shape
     max_u = int(U.max())
     e_x, fit_x, g_x = energy.energy_grad(idx_cur)
     cur = idx_cur.clone()
-    flats, logp_fwd, after = [], [], []
+    flats, logp_fwd, after, p_fwd = [], [], [], []
     for s in range(max_u):
         p_hat = categorical_probs(forward_logits(g_x, cur, wt_idx, min_pos, max_pos, nmut_threshold))
+        if keep_probs:
+            p_fwd.append(p_hat)
         flat = race_sample(p_hat, q[s])
         flats.append(flat)
         logp_fwd.append(log_prob_at(p_hat, flat))
@@ -263,14 +284,17 @@ def pas_iteration(energy, idx_cur, idx_reject, wt_idx, U, q, u, min_pos, max_pos
     log_acc = (e_y - e_x) + log_ratio
     acc = torch.exp(log_acc) >= u
     new_idx = torch.where(acc.reshape(n, 1), cur, idx_reject)
-    return dict(idx=new_idx, energy=torch.where(acc, e_y, e_x), fitness=torch.where(acc, fit_y, fit_x),
-                accepted=acc, log_acc=log_acc, flat=torch.stack(flats, 0), proposal=cur,
-                logp_fwd=torch.stack(logp_fwd, 0), logp_rev=torch.stack(logp_rev, 0),
-                e_x=e_x, e_y=e_y, grad_x=g_x, grad_y=g_y)
+    out = dict(idx=new_idx, energy=torch.where(acc, e_y, e_x), fitness=torch.where(acc, fit_y, fit_x),
+               accepted=acc, log_acc=log_acc, flat=torch.stack(flats, 0), proposal=cur,
+               logp_fwd=torch.stack(logp_fwd, 0), logp_rev=torch.stack(logp_rev, 0),
+               e_x=e_x, e_y=e_y, grad_x=g_x, grad_y=g_y)
+    if keep_probs:
+        out["p_fwd"] = torch.stack(p_fwd, 0)
+    return out
 
 
 def run(energy, idx0, wt_idx, noise, num_steps, min_pos, max_pos, pas_length=2, nmut_threshold=0,
-        paper_results=False, trace=False, record_after_reset=False):
+        paper_results=False, trace=False, record_after_reset=False, keep_probs=False):
     """The whole sampler (ppde.py:24-192) on explicit noise.
 
     noise: callable it -> (U int64 [n], q fp32 [max_u, n, L*A], u fp32 [n]) for iteration `it`.
@@ -292,7 +316,7 @@ def run(energy, idx0, wt_idx, noise, num_steps, min_pos, max_pos, pas_length=2, 
     for it in range(num_steps):
         U, q, u = noise(it)
         out = pas_iteration(energy, cur, x_keep if paper_results else cur, wt_idx, U, q, u,
-                            min_pos, max_pos, thr)
+                            min_pos, max_pos, thr, keep_probs=keep_probs)
         cur = out["idx"].clone()
         e_hist.append(out["energy"])
         f_hist.append(out["fitness"])

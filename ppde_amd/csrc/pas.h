@@ -19,7 +19,9 @@ struct PasArgs {
     // model
     const uint8_t* wt;          // wild-type row in state layout [Ls]
     float wt_H, lamda;
-    int which;                  // bit0 Potts, bit1 CNN
+    int which;                  // experts in the ENERGY: bit0 Potts, bit1 CNN, bit2 transformer
+    int gwhich;                 // experts whose gradient rows feed the proposal (grad_sources() in ppde_api.hip): == which,
+                                // except that the reference's transformer branch leaves lamda * d fit/dx out (energy.py:125)
     // sampler configuration
     int pas, thr, paper, min_pos, max_pos, rng_mode, reuse, rec_after_reset, random_chain, mu_max;
     int mu_cap;                 // sub-steps the supplied noise of this iteration covers (rng_mode 0: max_u[it]; else mu_max)
@@ -179,10 +181,10 @@ __device__ __forceinline__ float4 row_parts_sum(const RowParts& q, int nc, bool 
 __device__ __forceinline__ RowSrc slot_row(const PasArgs& a, int slot, int b) {
     RowSrc r;
     r.nc = 0;
-    r.p = (a.which & 1) ? (const float4*)(a.grad + ((size_t)slot * a.n + b) * a.g.N) : nullptr;
+    r.p = (a.gwhich & 1) ? (const float4*)(a.grad + ((size_t)slot * a.n + b) * a.g.N) : nullptr;
     r.c[0] = r.c[1] = r.c[2] = r.c[3] = nullptr;
-    r.t = (a.which & 4) ? (const float4*)(a.gradT + ((size_t)slot * a.n + b) * a.g.N) : nullptr;
-    if (a.which & 2) {
+    r.t = (a.gwhich & 4) ? (const float4*)(a.gradT + ((size_t)slot * a.n + b) * a.g.N) : nullptr;
+    if (a.gwhich & 2) {
         r.nc = a.n_parts;
 #pragma unroll
         for (int k = 0; k < 4; ++k)
@@ -209,7 +211,7 @@ __device__ __forceinline__ RowSrc current_grad_row(const PasArgs& a, int b) {
 // s_waitcnt lgkmcnt(0) (eight to ten serial scalar round trips before the first vector load).
 __device__ __forceinline__ void args_up_front(const PasArgs& a) {
     asm volatile("" :: "s"(a.g.L), "s"(a.g.N), "s"(a.g.Ls), "s"(a.g.sh), "s"(a.g.Lp), "s"(a.n), "s"(a.b_off), "s"(a.wt),
-                 "s"(a.which), "s"(a.rng_mode), "s"(a.reuse), "s"(a.mu_max), "s"(a.pas), "s"(a.it_base), "s"(a.it_local));
+                 "s"(a.which), "s"(a.gwhich), "s"(a.rng_mode), "s"(a.reuse), "s"(a.mu_max), "s"(a.pas), "s"(a.it_base), "s"(a.it_local));
     asm volatile("" :: "s"(a.cur), "s"(a.grad), "s"(a.epart), "s"(a.gradC), "s"(a.fitC), "s"(a.n_nets), "s"(a.grad_cur),
                  "s"(a.rec), "s"(a.rec_stride), "s"(a.key.chain_lo), "s"(a.key.k0), "s"(a.key.k1));
 }

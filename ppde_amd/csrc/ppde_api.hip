@@ -379,9 +379,22 @@ static int launch_experts_fused(const ppde_model* m, const States& st, int n, co
     return PPDE_OK;
 }
 
+// Experts whose gradient is part of grad_x for an energy `which` (bits 0-2 experts, bit 3 = PPDE_WHICH_FULL_GRAD).
+// Reference: the potts branch differentiates e = dH + lamda * fit w.r.t. x (energy.py:105-108); the transformer /
+// potts+transformer branch computes fit from x but differentiates w.r.t. the SLICE x_batch (energy.py:115, :125), so
+// lamda * d fit/dx never reaches grad_x there: the supervised expert shapes the energy and the accept step, not the
+// proposal. Bit 3 opts into the full gradient instead.
+static int grad_sources(int which) {
+    const int w = which & 7;
+    return ((w & 4) && !(which & PPDE_WHICH_FULL_GRAD)) ? (w & ~2) : w;
+}
+
 static int eval_experts(const ppde_model* m, int which, const States& states, int n, const EvalTargets& t,
                         int want_grad, hipStream_t s, int b_off = 0, int n_sub = -1) {
-    if ((which & 3) == 3 && want_grad && m->has_potts && m->has_cnn) {   // (Potts + CNN in one launch; the transformer follows)
+    const int gw = grad_sources(which);
+    which &= 7;
+    const int cnn_grad = want_grad && (gw & 2);       // (no CNN backward where its gradient is not used)
+    if ((which & 3) == 3 && cnn_grad && m->has_potts && m->has_cnn) {   // (Potts + CNN in one launch; the transformer follows)
         bool done = false;
         int rc = launch_experts_fused(m, states, n, t, m->lamda / (float)m->n_nets, s, b_off, n_sub < 0 ? n : n_sub, &done);
         if (rc) return rc;
@@ -395,7 +408,7 @@ static int eval_experts(const ppde_model* m, int which, const States& states, in
     if (which & 2) {
         ARGCHK(m->has_cnn, "the energy uses the supervised expert but ppde_model_set_cnn was not called");
         float scale = (which == 2 ? 1.0f : m->lamda) / (float)m->n_nets;
-        int rc = launch_cnn(m, states, n, t, want_grad, scale, s, b_off, n_sub);
+        int rc = launch_cnn(m, states, n, t, cnn_grad, scale, s, b_off, n_sub);
         if (rc) return rc;
     }
     if (which & 4) {
@@ -411,7 +424,7 @@ static int eval_experts(const ppde_model* m, int which, const States& states, in
 
 static PasArgs base_pas_args(const ppde_model* m, int which, int n) {
     PasArgs a{};
-    a.g = m->g; a.n = n; a.wt = m->d_wt; a.wt_H = m->wt_H; a.lamda = m->lamda; a.which = which;
+    a.g = m->g; a.n = n; a.wt = m->d_wt; a.wt_H = m->wt_H; a.lamda = m->lamda; a.which = which & 7; a.gwhich = grad_sources(which);
     a.n_nets = m->n_nets; a.n_parts = cnn_parts(m);
     a.tf_wt = m->tf ? m->tf->wt_score : 0.f;
     return a;
@@ -764,7 +777,7 @@ int ppde_idx_to_onehot(ppde_model* m, const uint8_t* idx_dev, int n, float* x_de
 int ppde_energy_grad(ppde_model* m, const uint8_t* idx_dev, int n, int which, float* e_dev, float* fit_dev,
                      float* grad_dev, void* stream) {
     ARGCHK(m && idx_dev && n >= 0, "bad argument");
-    ARGCHK(which >= 1 && which <= 7, "which: bit 0 Potts, bit 1 supervised, bit 2 transformer expert");
+    ARGCHK(which >= 1 && which <= 15 && (which & 7), "which: bit 0 Potts, bit 1 supervised, bit 2 transformer expert, bit 3 full gradient");
     if (n == 0) return PPDE_OK;
     HIPCHK(hipSetDevice(m->device));
     hipStream_t s = (hipStream_t)stream;
@@ -1004,7 +1017,7 @@ int ppde_chains_create(ppde_chains** out, ppde_model* m, const ppde_chain_config
     ARGCHK(cfg->max_steps >= 0, "negative max_steps");
     ARGCHK(cfg->pas_length >= 1 && cfg->pas_length <= 64, "ppde_pas_length out of range");
     ARGCHK(cfg->nmut_threshold >= 0, "negative nmut_threshold");
-    ARGCHK(cfg->which >= 1 && cfg->which <= 7, "which: bit 0 Potts, bit 1 supervised, bit 2 transformer expert");
+    ARGCHK(cfg->which >= 1 && cfg->which <= 15 && (cfg->which & 7), "which: bit 0 Potts, bit 1 supervised, bit 2 transformer expert, bit 3 full gradient");
     ARGCHK(!(cfg->which & 4) || m->tf, "transformer expert not set");
     ARGCHK(!(cfg->which & 4) || cfg->n_streams <= 1, "the transformer expert runs on one stream");
     ARGCHK(cfg->min_pos >= 0 && cfg->max_pos < m->L && cfg->min_pos <= cfg->max_pos, "bad [min_pos, max_pos]");

@@ -21,6 +21,7 @@ from .encoding import idx_to_onehot
 from .weights import PottsParams, load_cnn_states, load_wt
 
 WHICH_POTTS, WHICH_SUPERVISED, WHICH_POE, WHICH_TRANSFORMER = 1, 2, 3, 4
+WHICH_FULL_GRAD = 8     # include/ppde_hip.h PPDE_WHICH_FULL_GRAD
 
 
 def _device_index(device):
@@ -278,7 +279,8 @@ class _HipEnergy(torch.nn.Module):
         path = next((c for c in cands if os.path.exists(c)), None)
         if path is None:
             raise FileNotFoundError(f"ESM-2 checkpoint {name}.pt not found (looked in {cands}); there is no network download here")
-        self.model.set_transformer(load_esm2_state(path), heads)
+        state, file_heads = load_esm2_state(path, with_heads=True)
+        self.model.set_transformer(state, int(file_heads) if file_heads else heads)   # (cfg.model.encoder_attention_heads of the file)
 
     def _setup(self, args, with_potts):
         dataset = os.path.join(args.protein_weights, args.protein)
@@ -335,6 +337,11 @@ class ProteinProductOfExperts(_HipEnergy):
         else:
             raise ValueError(f"unknown unsupervised_expert {ue!r}")
         self.which = self.unsup_which | WHICH_SUPERVISED
+        # energy.py:110-130: with a transformer expert the reference's grad_x leaves lamda * d fit/dx out (it differentiates
+        # w.r.t. the minibatch slice of x, :125, while fit was computed from x, :104); args.ppde_full_grad = True opts into
+        # the gradient of the whole energy instead
+        if (self.unsup_which & WHICH_TRANSFORMER) and getattr(args, "ppde_full_grad", False):
+            self.which |= WHICH_FULL_GRAD
         self.model.set_lamda(self.lamda)
 
     def get_unsupervised_expert(self, x):

@@ -121,7 +121,12 @@ def write_esm2_checkpoint(path, n_layers, dim, heads, ffn, seed=0):
         sd[pre + k] = torch.from_numpy(v)
     sd["encoder.lm_head.weight"] = sd["encoder.sentence_encoder.embed_tokens.weight"]
     os.makedirs(os.path.dirname(path), exist_ok=True)
-    torch.save({"model": sd}, path)
+    # the published files carry the architecture as an argparse.Namespace under cfg.model (facebookresearch/esm reads
+    # cfg.model.encoder_layers / encoder_embed_dim / encoder_attention_heads / token_dropout from it)
+    import argparse
+    cfg = argparse.Namespace(encoder_layers=n_layers, encoder_embed_dim=dim, encoder_attention_heads=heads, token_dropout=True,
+                             arch="roberta_large")
+    torch.save({"cfg": {"model": cfg}, "model": sd}, path)
     return st
 
 

@@ -58,12 +58,21 @@ def load_wt(protein_dir):
     return seqs, seqs_to_idx(seqs)
 
 
-def load_esm2_state(path):
+def load_esm2_state(path, with_heads=False):
     """ESM-2 checkpoint -> state dict with the module's own parameter names (embed_tokens.weight, layers.i..., lm_head...).
-    Accepts the published files ({'model': {...}} with 'encoder.sentence_encoder.' / 'encoder.' prefixes, which
-    facebookresearch/esm strips on load) as well as already stripped dicts."""
-    ck = torch.load(path, map_location="cpu")
+    Accepts the published files ({'cfg': {'model': Namespace}, 'model': {...}} with 'encoder.sentence_encoder.' /
+    'encoder.' prefixes, which facebookresearch/esm strips on load) as well as already stripped dicts.
+    with_heads: also return cfg.model.encoder_attention_heads (None when the file has no cfg)."""
+    import argparse
+    # the published checkpoints pickle an argparse.Namespace next to the tensors: allow exactly that class under the
+    # weights-only unpickler instead of switching it off for a downloaded file
+    with torch.serialization.safe_globals([argparse.Namespace]):
+        ck = torch.load(path, map_location="cpu", weights_only=True)
     sd = ck["model"] if isinstance(ck, dict) and "model" in ck else ck
+    heads = None
+    cfg = ck.get("cfg") if isinstance(ck, dict) else None
+    if isinstance(cfg, dict) and "model" in cfg:
+        heads = getattr(cfg["model"], "encoder_attention_heads", None)
     out = {}
     for k, v in sd.items():
         for pre in ("encoder.sentence_encoder.", "encoder."):
@@ -73,4 +82,4 @@ def load_esm2_state(path):
         if k == "lm_head.weight" or k.endswith("inv_freq") or "contact_head" in k:
             continue                                    # tied to embed_tokens / buffers / unused head
         out[k] = v.detach().cpu().numpy().astype(np.float32)
-    return out
+    return (out, heads) if with_heads else out

@@ -9,7 +9,7 @@ exist here: `--sampler PPDE` with `--unsupervised_expert potts | transformer | t
 transformer-L | potts+transformer` (the ESM-2 checkpoint must be in <hub_dir>/checkpoints/) and `--energy_function supervised`; the baseline samplers and
 the MSA-Transformer scoring are out of scope.
 
-Extra flags: --ppde_rng {torch,philox}, --ppde_seed, --ppde_reuse_grad {0,1}, --ppde_shard (with torchrun).
+Extra flags: --ppde_rng {torch,philox}, --ppde_seed, --ppde_reuse_grad {0,1}, --ppde_shard (with torchrun), --ppde_full_grad.
 """
 import argparse
 import datetime
@@ -153,6 +153,8 @@ def build_parser():
     pp.add_argument("--ppde_seed", type=int, default=None)
     pp.add_argument("--ppde_reuse_grad", type=int, default=1)
     pp.add_argument("--ppde_shard", action="store_true", help="split the chains over the ranks of a torchrun launch")
+    pp.add_argument("--ppde_full_grad", action="store_true",
+                    help="transformer experts only: let lamda * d fit/dx into the proposal gradient (the reference leaves it out)")
     return parser
 
 

@@ -28,6 +28,7 @@ import os
 import sys
 import tempfile
 import types
+import warnings
 
 import numpy as np
 import torch
@@ -61,14 +62,61 @@ def install_stubs():
     esm = types.ModuleType("esm_one_hot")
     esm.pretrained = types.ModuleType("esm_one_hot.pretrained")
     sys.modules["esm_one_hot"], sys.modules["esm_one_hot.pretrained"] = esm, esm.pretrained
+    for ctor in ("esm2_t12_35M_UR50D", "esm2_t30_150M_UR50D", "esm2_t33_650M_UR50D"):
+        setattr(esm.pretrained, ctor, _stub_esm2_constructor)
+
+
+# --- stand-in for the absent third-party `esm_one_hot` (nets.py:11, :176-181) -------------------------------------
+# The reference's transformer expert needs `pretrained.esm2_*()` -> (model, alphabet) with
+#   model(x_onehot [n, L, 33])['logits'],  alphabet.tok_to_idx,  alphabet.get_batch_converter()(pairs) -> (labels, strs,
+#   one-hot tokens [1, L + 2, 33] incl. <cls>/<eos>, which nets.py:186 strips).
+# The stand-in serves the BUILD'S OWN ESM-2 restatement (oracle/esm_oracle.py, fp32: on the CPU `torch.cuda.amp.autocast`
+# is disabled) on seeded synthetic weights, so the ESM arithmetic stays unpinned; what the fixtures pin is the reference's
+# glue around it: nets.py:193-240 (permutation, local_score, Delta against the wild type), :302-312 (PottsTransformer),
+# energy.py:110-130 (minibatch loop, gradient w.r.t. the slice) and PPDE_PAS.run on top.
+STUB_ESM = dict(layers=2, dim=128, heads=4, ffn=256, seed=5)
+
+
+class _StubEsm2(torch.nn.Module):
+    def __init__(self, orc):
+        super().__init__()
+        self.orc = orc
+
+    def forward(self, x):
+        return {"logits": self.orc.logits(x)}
+
+
+class _StubAlphabet:
+    def __init__(self, tokens):
+        self.tok_to_idx = {t: i for i, t in enumerate(tokens)}
+
+    def get_batch_converter(self):
+        def convert(pairs):
+            labels, strs = [p[0] for p in pairs], [p[1] for p in pairs]
+            toks = [[self.tok_to_idx["<cls>"]] + [self.tok_to_idx[c] for c in s] + [self.tok_to_idx["<eos>"]] for s in strs]
+            return labels, strs, torch.nn.functional.one_hot(torch.tensor(toks), len(self.tok_to_idx)).float()
+        return convert
+
+
+def stub_esm_oracle():
+    sys.path.insert(0, os.path.join(REPO, "oracle"))
+    import esm_oracle as eo
+    g = STUB_ESM
+    st = synthetic.make_esm2_state(g["layers"], g["dim"], g["heads"], g["ffn"], seed=g["seed"])
+    return eo, eo.EsmOracle(st, g["layers"], g["dim"], g["heads"], half_points=False)
+
+
+def _stub_esm2_constructor():
+    eo, orc = stub_esm_oracle()
+    return _StubEsm2(orc), _StubAlphabet(eo.ESM_TOKENS)
 
 
 def sha(a):
     return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
 
 
-def ref_args(root, protein, n_chains, lamda, pas=2, nmut=0, paper=False):
-    return argparse.Namespace(energy_lamda=lamda, unsupervised_expert="potts", protein_weights=root,
+def ref_args(root, protein, n_chains, lamda, pas=2, nmut=0, paper=False, unsup="potts"):
+    return argparse.Namespace(energy_lamda=lamda, unsupervised_expert=unsup, protein_weights=root,
                               protein=protein, n_chains=n_chains, device="cpu", ppde_pas_length=pas,
                               nmut_threshold=nmut, paper_results=paper)
 
@@ -122,6 +170,40 @@ def ops_case(root, protein, potts_seed, symmetric, lamda, n, state_seed, out):
     print("wrote", out)
 
 
+def tf_ops_case(root, protein, lamda, state_seed, out):
+    """energy.py:97-132 with `--unsupervised_expert transformer` and `potts+transformer` over the stand-in ESM-2: e, fit,
+    grad_x (which the reference takes w.r.t. the minibatch slice: no lamda * d fit/dx in it), for 70 states so that the
+    minibatch loop (64 chains, energy.py:77, :113-127) runs twice."""
+    from ppde.energy import ProteinProductOfExperts
+    n = 70
+    payload = dict(protein=protein, lamda=lamda, potts_seed=7, **{"esm_" + k: v for k, v in STUB_ESM.items()})
+    for tag, unsup in (("t", "transformer"), ("pt", "potts+transformer")):
+        with quiet(), warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            en = ProteinProductOfExperts(ref_args(root, protein, n, lamda, unsup=unsup))
+            wt_idx = en.wt_onehot[0].argmax(-1).numpy().astype(np.uint8)
+            idx = random_states(wt_idx, n, np.random.default_rng(state_seed), 6)
+            x = to_onehot(idx).requires_grad_()
+            e, fit, g = en.get_energy_and_grads(x)
+            with torch.no_grad():
+                e2, fit2 = en.get_energy(to_onehot(idx))
+                unsup_e = en.get_unsupervised_expert(to_onehot(idx))
+            tfm = en.unsupervised_expert.transformer if unsup == "potts+transformer" else en.unsupervised_expert
+            # what autograd of the WHOLE energy w.r.t. x would be (not what the reference returns): kept to show the two differ
+            xs = to_onehot(idx).requires_grad_()
+            gs = torch.autograd.grad([en.get_supervised_expert(xs).sum()], xs)[0]
+        payload.update({f"{tag}_e": e.detach().numpy(), f"{tag}_fit": fit.detach().numpy(), f"{tag}_grad": g.numpy(),
+                        f"{tag}_e_nograd": e2.numpy(), f"{tag}_fit_nograd": fit2.numpy(), f"{tag}_unsupervised": unsup_e.numpy(),
+                        f"{tag}_wt_score": tfm.wt_score.detach().numpy(), f"{tag}_perm": tfm.potts_to_esm_perm.numpy()})
+        payload.update(idx=idx, wt_idx=wt_idx, supervised_grad=gs.numpy())
+        if unsup == "potts+transformer":
+            potts = en.unsupervised_expert.potts
+            payload.update(win_start=int(potts.index_list[0]), Lp=int(potts.seq_len), J_sha=sha(potts.J.detach().numpy()),
+                           wt_H=potts.wt_H.detach().numpy())
+    np.savez_compressed(out, **payload)
+    print("wrote", out, f"({os.path.getsize(out) / 1e3:.0f} kB)")
+
+
 def file_sha(path):
     with open(path, "rb") as fh:
         return hashlib.sha256(fh.read()).hexdigest()
@@ -149,16 +231,18 @@ def real_case(protein, lamda, n, state_seed, out):
     print("wrote", out, f"({os.path.getsize(out) / 1e3:.0f} kB)")
 
 
-def run_case(root, protein, lamda, n, T, seed, pas, nmut, paper, out, store_q):
-    """One reference sampler run with everything it drew recorded."""
+def run_case(root, protein, lamda, n, T, seed, pas, nmut, paper, out, store_q, unsup="potts"):
+    """One reference sampler run with everything it drew recorded. unsup = 'transformer' / 'potts+transformer': the
+    reference's energy.py:110-130 branch over the stand-in ESM-2 (see install_stubs)."""
     from ppde.energy import ProteinProductOfExperts
     from ppde.nets import AugmentedLinearRegression
     from ppde.protein_samplers.ppde import PPDE_PAS
     sys.path.insert(0, os.path.join(REPO, "oracle"))
     import ppde_oracle as orc
 
-    args = ref_args(root, protein, n, lamda, pas, nmut, paper)
-    with quiet():
+    args = ref_args(root, protein, n, lamda, pas, nmut, paper, unsup)
+    with quiet(), warnings.catch_warnings():
+        warnings.simplefilter("ignore")
         en = ProteinProductOfExperts(args)
         alr = AugmentedLinearRegression(os.path.join(root, protein))
     L = en.wt_onehot.shape[1]
@@ -198,7 +282,8 @@ def run_case(root, protein, lamda, n, T, seed, pas, nmut, paper, out, store_q):
         torch.manual_seed(seed)
         torch.randint, torch.multinomial, torch.rand_like = w_randint, w_multinomial, w_rand_like
         try:
-            with quiet():
+            with quiet(), warnings.catch_warnings():
+                warnings.simplefilter("ignore")           # (torch.cuda.amp.autocast without CUDA warns once per call)
                 return PPDE_PAS(args).run(x0, T, en, min_pos, max_pos, alr, log_every=10)
         finally:
             torch.randint, torch.multinomial, torch.rand_like = o_randint, o_multinomial, o_rand_like
@@ -225,11 +310,16 @@ def run_case(root, protein, lamda, n, T, seed, pas, nmut, paper, out, store_q):
             flat[t, s] = f.numpy()
 
     # pin the oracle on this trajectory right here (the CPU test repeats it from the fixture)
-    potts = en.unsupervised_expert
+    potts = {"potts": en.unsupervised_expert, "potts+transformer": getattr(en.unsupervised_expert, "potts", None)}.get(unsup, alr.potts)
     wt_idx = en.wt_onehot[0].argmax(-1)
     P = orc.PottsOracle(potts.J.detach(), potts.bias.detach(), potts.index_list[0], wt_idx)
     C = orc.CnnOracle([{k: v.detach().numpy() for k, v in s.state_dict().items()} for s in en.supervised_expert.surrogates])
-    eo = orc.EnergyOracle(P, C, lamda)
+    if unsup == "potts":
+        eo = orc.EnergyOracle(P, C, lamda)
+    else:
+        esm_mod, esm_orc = stub_esm_oracle()
+        eo = orc.EnergyOracle(P if unsup == "potts+transformer" else None, C, lamda,
+                              tf=esm_mod.TransformerDelta(esm_orc, wt_idx.numpy(), chunk=min(n, 64)))
     res = orc.run(eo, x0.argmax(-1), wt_idx, lambda t: noise[t], T, min_pos, max_pos, pas, nmut, paper, trace=True)
     res_alias = orc.run(eo, x0.argmax(-1), wt_idx, lambda t: noise[t], T, min_pos, max_pos, pas, nmut, paper,
                         record_after_reset=True)
@@ -238,6 +328,12 @@ def run_case(root, protein, lamda, n, T, seed, pas, nmut, paper, out, store_q):
         mu = int(noise[t][0].max())
         assert np.array_equal(res["traces"][t]["flat"].numpy(), flat[t, :mu]), f"oracle draw mismatch at iter {t}"
     assert np.array_equal(res["best_idx"].numpy(), best_x.argmax(-1).numpy()), "oracle best state mismatch"
+    if unsup != "potts":      # the fixture must discriminate: with lamda * d fit/dx in the proposal gradient the draws differ
+        eo_full = orc.EnergyOracle(eo.potts, C, lamda, tf=eo.tf, full_grad=True)
+        res_full = orc.run(eo_full, x0.argmax(-1), wt_idx, lambda t: noise[t], T, min_pos, max_pos, pas, nmut, paper, trace=True)
+        n_diff = sum(int((res_full["traces"][t]["flat"].numpy() != flat[t, :int(noise[t][0].max())]).sum()) for t in range(T))
+        assert n_diff > 0, "fixture cannot tell the reference's gradient from the full gradient"
+        print(f"  full-gradient oracle differs from the reference in {n_diff} draws (as it must)")
     err = np.abs(res["energy_history"].numpy() - e_hist).max()
     assert err < 1e-4, err
     print(f"  oracle vs reference on this run: draws exact, best states exact, max |dE| = {err:.2e}")
@@ -255,6 +351,8 @@ def run_case(root, protein, lamda, n, T, seed, pas, nmut, paper, out, store_q):
         best_idx_cpu_alias=alias[0].argmax(-1).numpy().astype(np.uint8),
         random_traj_cpu_alias=np.stack([r.argmax(-1) for r in alias[5]]).astype(np.uint8),
         oracle_best=alr(best_x).detach().numpy())
+    if unsup != "potts":
+        payload.update(unsup=unsup, potts_seed=7, **{"esm_" + k: v for k, v in STUB_ESM.items()})
     if store_q:
         payload["q"] = np.concatenate([noise[t][1].numpy() for t in range(T)], 0)  # [sum max_u, n, N]
     np.savez_compressed(out, **payload)
@@ -303,6 +401,19 @@ def main():
         for protein, lam, seed in (("PABP_YEAST_Fields2013", 5.0, 21), ("UBE4B_MOUSE_Klevit2013-nscor_log2_ratio", 0.5, 22),
                                    ("GFP_AEQVI_Sarkisyan2016", 15.0, 23)):
             real_case(protein, lam, 6, seed, os.path.join(HERE, f"real_{protein.split('_')[0].lower()}.npz"))
+        return
+    if only and "tf" in only:
+        with tempfile.TemporaryDirectory() as root:
+            synthetic.write_weights_dir(root, "TOY24", potts_seed=7)
+            # lamda is far above the README's 1-5 on purpose: the synthetic CNN's input gradient is ~1e-2 against ~1e1 for
+            # the stand-in transformer's, and the fixtures must tell "lamda * d fit/dx is in grad_x" from "it is not" well
+            # above the fp16 tolerance of the GPU tests (run_case asserts that the full-gradient oracle does NOT replay)
+            tf_ops_case(root, "TOY24", 300.0, 31, os.path.join(HERE, "ops_tfpoe_toy.npz"))
+            # 72 chains: the reference's minibatch loop runs twice per evaluation (64 + 8)
+            run_case(root, "TOY24", 300.0, 72, 10, 301, 2, 3, False, os.path.join(HERE, "run_tfpoe_toy_t.npz"), store_q=False,
+                     unsup="transformer")
+            run_case(root, "TOY24", 100.0, 8, 20, 302, 2, 0, False, os.path.join(HERE, "run_tfpoe_toy_pt.npz"), store_q=False,
+                     unsup="potts+transformer")
         return
     if only and "script" in only:
         with tempfile.TemporaryDirectory() as root:

@@ -43,6 +43,29 @@ def oracle_energy(J, h, i0, wt_idx, cnn, lamda):
     return orc.EnergyOracle(P, C, lamda)
 
 
+def esm_from_fixture(fx, half_points):
+    """(state dict, geometry, EsmOracle) of the stand-in ESM-2 a transformer fixture was generated on (make_golden.py
+    STUB_ESM). half_points=False is the arithmetic the reference ran on the CPU (autocast is disabled there); True rounds
+    to fp16 where autocast on a GPU would, which is what the HIP path computes."""
+    import esm_oracle as eo
+    g = {k: int(fx["esm_" + k]) for k in ("layers", "dim", "heads", "ffn", "seed")}
+    st = synthetic.make_esm2_state(g["layers"], g["dim"], g["heads"], g["ffn"], seed=g["seed"])
+    return st, g, eo.EsmOracle(st, g["layers"], g["dim"], g["heads"], half_points=half_points)
+
+
+def oracle_energy_from_fixture(fx, half_points=False, full_grad=False, unsup=None):
+    """The oracle's energy function for any ops_* / run_* fixture (Potts PoE, or the transformer branches)."""
+    import esm_oracle as eo
+    J, h, i0, wt_idx, cnn = model_from_fixture(fx)
+    unsup = unsup or (str(fx["unsup"]) if "unsup" in fx else "potts")
+    lam = float(fx["lamda"])
+    if unsup == "potts":
+        return oracle_energy(J, h, i0, wt_idx, cnn, lam)
+    P = orc.PottsOracle(J, h, i0, torch.as_tensor(wt_idx.astype(np.int64))) if unsup == "potts+transformer" else None
+    _, _, esm = esm_from_fixture(fx, half_points)
+    return orc.EnergyOracle(P, orc.CnnOracle(cnn), lam, tf=eo.TransformerDelta(esm, wt_idx), full_grad=full_grad)
+
+
 def fixture_noise(fx, n, N, pas, T):
     """Per-iteration (U, q, u) of a run fixture: stored q when present, else re-drawn from the seed."""
     U_all, u_all = torch.as_tensor(fx["U"]), torch.as_tensor(fx["u"])
@@ -59,3 +82,44 @@ def fixture_noise(fx, n, N, pas, T):
                abs(float(out[t][1].double().sum()) - float(fx["q_sum"][t])) < 1e-9 * abs(float(fx["q_sum"][t]))
                for t in range(T))
     return out, same
+
+
+def device_noise(ch, T, pas):
+    """(U, q, u) per iteration as the device RNG (rng_mode 1) of chains `ch` draws them, for feeding the oracle."""
+    noise = []
+    for t in range(T):
+        qs = [ch.philox_dump(t, s) for s in range(2 * pas - 1)]
+        noise.append((qs[-1][2].cpu().long(), torch.stack([q[0].cpu() for q in qs], 0), qs[-1][1].cpu()))
+    return noise
+
+
+def compare_runs_up_to_near_ties(tr, ref, noise, gap_tol, acc_tol):
+    """Chain by chain, a device run (its trace `tr`) against an oracle run `ref` (orc.run(..., trace=True,
+    keep_probs=True)) on the same noise, for energies that agree only to a floating-point tolerance (fp16 transformer):
+    draws and accept bits must be EQUAL up to a chain's first difference, and that difference must be a near-tie of the
+    oracle's own decision -- the device's pick within a relative gap `gap_tol` of the winner of the exponential race, or
+    |log_acc - log u| <= acc_tol for an accept bit. A chain is not compared after it has parted (chains are independent).
+    Returns (number of chains equal to the end, [(chain, iteration, what, margin), ...]); raises on a real difference."""
+    T, n = tr["accepted"].shape
+    parted, notes = np.zeros(n, bool), []
+    for t in range(T):
+        U, q, u = noise[t]
+        out = ref["traces"][t]
+        for s in range(int(U.max())):
+            live = (~parted) & (s < U.numpy())
+            d = tr["flat"][t, s]
+            o = out["flat"][s].numpy()
+            for b in np.nonzero(live & (d != o))[0]:
+                v = out["p_fwd"][s][b] / q[s][b]
+                gap = 1.0 - float(v[int(d[b])] / v.max())
+                assert gap <= gap_tol, f"chain {b} iteration {t} sub-step {s}: device drew {int(d[b])}, oracle {int(o[b])}, race gap {gap:.3e}"
+                parted[b] = True
+                notes.append((int(b), t, f"draw {s}", gap))
+        live = ~parted
+        da, oa = tr["accepted"][t].astype(bool), out["accepted"].numpy()
+        for b in np.nonzero(live & (da != oa))[0]:
+            margin = abs(float(out["log_acc"][b]) - float(torch.log(u[b])))
+            assert margin <= acc_tol, f"chain {b} iteration {t}: accept bit differs, |log_acc - log u| = {margin:.3e}"
+            parted[b] = True
+            notes.append((int(b), t, "accept", margin))
+    return int((~parted).sum()), notes, ~parted

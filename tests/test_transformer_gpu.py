@@ -97,10 +97,11 @@ def test_score_and_gradient_vs_oracle(L, layers, dim, heads, ffn, n):
 
 @pytest.mark.parametrize("L,win", [(24, (4, 16)), (237, (0, 237))])      # toy; GFP length (ring Potts, chunked CNN, 256-residue attention)
 def test_product_of_experts_with_transformer_and_sampler(L, win):
-    """which = 6 (transformer + supervised CNN) and 7 (potts + transformer + CNN): energies / gradients are the sums of
-    the experts', and a sampler run on the device RNG replays against the oracle fed the device's noise."""
-    import ppde_oracle as porc
-    from helpers import oracle_energy
+    """which = 6 (transformer + supervised CNN) and 7 (potts + transformer + CNN): the energy is the sum of the experts'
+    terms; the gradient is the UNSUPERVISED experts' only, as the reference's transformer branch yields (energy.py:125
+    differentiates w.r.t. the minibatch slice), and with PPDE_WHICH_FULL_GRAD (bit 3) the sum over all experts. A sampler
+    run on the device RNG gives the same trajectory with and without gradient reuse. (Oracle replays of which = 6 / 7 runs:
+    test_tfpoe_device_rng_run_vs_oracle, test_tfpoe_sampler_replays_reference_run.)"""
     from ppde_amd.sampler import Chains
     layers, dim, heads, ffn, lam = 2, 128, 4, 256, 2.0
     m, wt, st, cnn = _model(L, layers, dim, heads, ffn, with_cnn=True, potts=win)
@@ -112,10 +113,14 @@ def test_product_of_experts_with_transformer_and_sampler(L, win):
     e1, _, g1 = m.energy_grad(x, 1)
     e6, f6, g6 = m.energy_grad(x, 6)
     e7, f7, g7 = m.energy_grad(x, 7)
+    _, _, g6f = m.energy_grad(x, 6 | 8)
+    _, _, g7f = m.energy_grad(x, 7 | 8)
     tol = 1e-5 * (1 + float(e4.abs().max()) + float(e1.abs().max()))
     assert torch.allclose(e6, e4 + lam * f2, atol=tol) and torch.allclose(f6, f2, atol=0)
-    assert torch.allclose(g6, g4 + lam * g2, atol=tol)
-    assert torch.allclose(e7, e4 + e1 + lam * f2, atol=2 * tol) and torch.allclose(g7, g4 + g1 + lam * g2, atol=2 * tol)
+    assert torch.equal(g6, g4)                                  # no lamda * d fit/dx in the reference's grad_x
+    assert torch.allclose(g6f, g4 + lam * g2, atol=tol)
+    assert torch.allclose(e7, e4 + e1 + lam * f2, atol=2 * tol)
+    assert torch.allclose(g7, g4 + g1, atol=2 * tol) and torch.allclose(g7f, g4 + g1 + lam * g2, atol=2 * tol)
     # sampler, device RNG, 10 iterations, both evaluation policies give the same trajectory
     n, T = 6, 10
     res = []
@@ -131,6 +136,161 @@ def test_product_of_experts_with_transformer_and_sampler(L, win):
     assert (res[0]["energy_history"][1:] != res[0]["energy_history"][0]).any()
 
 
+# ---- the reference's transformer branches (energy.py:110-130) ---------------------------------------------------
+# Fixtures: the REFERENCE's ProteinProductOfExperts / PPDE_PAS.run over a stand-in for the absent esm_one_hot that serves
+# this repository's own ESM-2 restatement in fp32 (tests/golden/make_golden.py). They pin the glue (what is summed into
+# the energy, what the gradient is taken of, minibatching, the sampler on top); the ESM arithmetic stays unpinned, and
+# the HIP path computes it in fp16 where the CPU reference had fp32, hence the tolerances: scores 2e-3 * (1 + |s|),
+# gradients 3e-2 * max|g|; draws / accept bits equal except on flagged near-ties of the oracle's own decision.
+def _tfpoe_model(fx, unsup):
+    from helpers import esm_from_fixture, model_from_fixture
+    from ppde_amd.energy import HipModel
+    J, h, i0, wt_idx, cnn = model_from_fixture(fx)
+    st, g, _ = esm_from_fixture(fx, True)
+    m = HipModel(wt_idx, "cuda:0")
+    if unsup == "potts+transformer":
+        m.set_potts(J, h, i0)
+    m.set_cnn(cnn)
+    m.set_transformer(st, g["heads"])
+    m.set_lamda(float(fx["lamda"]))
+    return m, wt_idx
+
+
+def _score_tol(fx, tag, lam, fit):
+    raw = np.abs(fx[f"{tag}_unsupervised"]) + abs(float(np.ravel(fx[f"{tag}_wt_score"])[0]))
+    return 2 * 2e-3 * (1 + raw) + 5e-6 * lam * (1 + np.abs(fit))
+
+
+@pytest.mark.parametrize("tag,unsup,which", [("t", "transformer", 6), ("pt", "potts+transformer", 7)])
+def test_tfpoe_energy_grad_vs_reference_fixture(tag, unsup, which):
+    from helpers import load
+    fx = load("ops_tfpoe_toy.npz")
+    lam = float(fx["lamda"])
+    m, wt_idx = _tfpoe_model(fx, unsup)
+    x = torch.as_tensor(fx["idx"]).cuda()
+    wt_s = float(np.ravel(fx[f"{tag}_wt_score"])[0])
+    assert observed(f"tfpoe_{tag}:wt_score", abs(m.transformer_wt_score - wt_s), 2e-3 * (1 + abs(wt_s))) <= 1.0
+    e, fit, g = m.energy_grad(x, which)
+    assert np.abs(fit.cpu().numpy() - fx[f"{tag}_fit"]).max() <= 5e-6
+    assert observed(f"tfpoe_{tag}:e", np.abs(e.cpu().numpy() - fx[f"{tag}_e"]), _score_tol(fx, tag, lam, fx[f"{tag}_fit"])) <= 1.0
+    gref = fx[f"{tag}_grad"]
+    gtol = 3e-2 * np.abs(gref).max()
+    assert observed(f"tfpoe_{tag}:grad", np.abs(g.cpu().numpy() - gref).max(), gtol) <= 1.0
+    # ... and the tolerance tells the reference's gradient from the gradient of the whole energy
+    sup = lam * fx["supervised_grad"]
+    assert np.abs(g.cpu().numpy() - (gref + sup)).max() > 5 * gtol
+    _, _, gf = m.energy_grad(x, which | 8)                      # the opt-in: + lamda * d fit/dx
+    assert np.abs(gf.cpu().numpy() - (gref + sup)).max() <= gtol + 2e-6 * lam
+    e_un, f_un, g_un = m.energy_grad(x, which & ~2)             # get_unsupervised_expert
+    assert observed(f"tfpoe_{tag}:unsupervised", np.abs(e_un.cpu().numpy() - fx[f"{tag}_unsupervised"]), _score_tol(fx, tag, 0.0, 0.0)) <= 1.0
+    assert float(f_un.abs().max()) == 0.0 and torch.equal(g_un, g)
+    e_ng, f_ng, _ = m.energy_grad(x, which, want_grad=False)    # get_energy
+    assert torch.equal(e_ng, e) and torch.equal(f_ng, fit)
+
+
+@pytest.mark.parametrize("name", ["run_tfpoe_toy_t.npz", "run_tfpoe_toy_pt.npz"])
+@pytest.mark.parametrize("reuse", [True, False])
+def test_tfpoe_sampler_replays_reference_run(name, reuse):
+    """The REFERENCE's PPDE_PAS.run with `--unsupervised_expert transformer` (72 chains: two minibatches per evaluation) and
+    `potts+transformer`, replayed by the HIP path on the reference's noise."""
+    import ppde_oracle as porc
+    from helpers import compare_runs_up_to_near_ties, fixture_noise, load, oracle_energy_from_fixture
+    from ppde_amd.sampler import Chains
+    fx = load(name)
+    unsup = str(fx["unsup"])
+    which = 6 if unsup == "transformer" else 7
+    m, wt_idx = _tfpoe_model(fx, unsup)
+    lam, n, T, pas = float(fx["lamda"]), int(fx["n"]), int(fx["T"]), int(fx["pas"])
+    L = wt_idx.shape[0]
+    noise, same = fixture_noise(fx, n, L * 20, pas, T)
+    if not same:
+        pytest.skip("this host's torch CPU exponential_ stream differs from the one the fixture was drawn on")
+    kw = dict(num_steps=T, min_pos=int(fx["min_pos"]), max_pos=int(fx["max_pos"]), pas_length=pas, nmut_threshold=int(fx["nmut"]),
+              paper_results=bool(fx["paper"]))
+    # the fp32 oracle replays the fixture exactly (tests/test_oracle_golden.py); its proposal rows say how close each of
+    # the reference's decisions was to a tie
+    ref = porc.run(oracle_energy_from_fixture(fx), np.tile(wt_idx.astype(np.int64), (n, 1)), wt_idx, lambda t: noise[t],
+                   trace=True, keep_probs=True, **kw)
+    assert np.array_equal(ref["accepted"].numpy(), fx["accepted"])
+    ch = Chains(m, n, T, pas, int(fx["nmut"]), bool(fx["paper"]), int(fx["min_pos"]), int(fx["max_pos"]), which, 0,
+                reuse_grad=reuse, trace=True, random_chain=int(fx["random_idx"]))
+    ch.init(torch.as_tensor(np.tile(wt_idx, (n, 1))).cuda())
+    for U, q, u in noise:
+        ch.run(1, (U.to(torch.int32).reshape(1, -1), q, u.reshape(1, -1), [int(q.shape[0])]))
+    tr, res = ch.trace(), ch.collect()
+    n_same, notes, same_mask = compare_runs_up_to_near_ties(tr, ref, noise, gap_tol=5e-2, acc_tol=5e-2)
+    print(f"[parity] {name} reuse={reuse}: {n_same}/{n} chains on the reference's trajectory to the end; near-ties: {notes}")
+    assert n_same >= n - max(1, n // 10)
+    eh, fh = fx["energy_history"][:, same_mask], fx["fitness_history"][:, same_mask]
+    assert np.abs(res["fitness_history"][:, same_mask] - fh).max() <= 5e-6
+    tol = 2 * 2e-3 * (1 + np.abs(eh - lam * fh) + abs(m.transformer_wt_score)) + 5e-6 * lam * (1 + np.abs(fh))
+    assert observed(f"{name}:energy_history", np.abs(res["energy_history"][:, same_mask] - eh), tol) <= 1.0
+    assert np.array_equal(res["best_idx"][same_mask], fx["best_idx"][same_mask])
+    if same_mask[int(fx["random_idx"])]:
+        assert np.array_equal(res["random_traj"], fx["random_traj"])
+
+
+@pytest.mark.parametrize("which", [6, 7, 6 | 8])
+def test_tfpoe_device_rng_run_vs_oracle(which):
+    """A which = 6 / 7 sampler run on the device RNG against the oracle (fp16 rounding points, energy.py:110-130 glue incl.
+    the reference's gradient; 6 | 8: the opt-in full gradient) fed the device's own noise."""
+    import ppde_oracle as porc
+    from helpers import compare_runs_up_to_near_ties, device_noise, load, oracle_energy_from_fixture
+    from ppde_amd.sampler import Chains
+    fx = load("ops_tfpoe_toy.npz")
+    unsup = "potts+transformer" if which & 1 else "transformer"
+    m, wt_idx = _tfpoe_model(fx, unsup)
+    n, T, pas, nmut, L = 24, 12, 2, 4, wt_idx.shape[0]
+    lo, hi = (int(fx["win_start"]), int(fx["win_start"]) + int(fx["Lp"]) - 1)
+    ch = Chains(m, n, T, pas, nmut, False, lo, hi, which, 1, trace=True, random_chain=0, seed=77, use_graph=False)
+    ch.init(torch.as_tensor(np.tile(wt_idx, (n, 1))).cuda())
+    ch.run(T)
+    tr, res = ch.trace(), ch.collect()
+    noise = device_noise(ch, T, pas)
+    en = oracle_energy_from_fixture(fx, half_points=True, full_grad=bool(which & 8), unsup=unsup)
+    ref = porc.run(en, np.tile(wt_idx.astype(np.int64), (n, 1)), wt_idx, lambda t: noise[t], T, lo, hi, pas, nmut, False,
+                   trace=True, keep_probs=True)
+    n_same, notes, same_mask = compare_runs_up_to_near_ties(tr, ref, noise, gap_tol=5e-2, acc_tol=5e-2)
+    print(f"[parity] which={which}: {n_same}/{n} chains on the oracle's trajectory to the end; near-ties: {notes}")
+    assert n_same >= n - max(1, n // 10)
+    eh = ref["energy_history"].numpy()[:, same_mask]
+    fh = ref["fitness_history"].numpy()[:, same_mask]
+    lam = float(fx["lamda"])
+    tol = 2 * 2e-3 * (1 + np.abs(eh - lam * fh) + abs(m.transformer_wt_score)) + 5e-6 * lam * (1 + np.abs(fh))
+    assert observed(f"tfpoe_run{which}:energy_history", np.abs(res["energy_history"][:, same_mask] - eh), tol) <= 1.0
+    assert np.array_equal(res["best_idx"][same_mask], ref["best_idx"].numpy()[same_mask])
+    assert 0.02 < tr["accepted"].mean() < 0.98
+
+
+def test_tfpoe_ube4b_150m_shapes_vs_combined_oracle():
+    """One which = 6 evaluation at BASELINE config 5's shapes (UBE4B length, esm2_t30_150M geometry, 3 CNNs) against the
+    combined oracle: e = Delta-score + lamda * fit, grad = d Delta-score / dx."""
+    import ppde_oracle as porc
+    name = [k for k in synthetic.PROTEINS if k.startswith("UBE4B")][0]
+    wt = seqs_to_idx([synthetic.PROTEINS[name][1]])[0]
+    L, layers, dim, heads, ffn, lam, n = wt.shape[0], 30, 640, 20, 2560, 3.0, 4
+    from ppde_amd.energy import HipModel
+    st = synthetic.make_esm2_state(layers, dim, heads, ffn, seed=0)
+    cnn = [synthetic.make_cnn_state(L, s) for s in range(3)]
+    m = HipModel(wt, "cuda:0")
+    m.set_cnn(cnn)
+    m.set_transformer(st, heads)
+    m.set_lamda(lam)
+    rng = np.random.default_rng(8)
+    idx = np.tile(wt, (n, 1))
+    for b in range(1, n):
+        pos = rng.choice(L, size=2 * b, replace=False)
+        idx[b, pos] = rng.integers(0, 20, len(pos))
+    en = porc.EnergyOracle(None, porc.CnnOracle(cnn), lam, tf=eo.TransformerDelta(eo.EsmOracle(st, layers, dim, heads, half_points=True), wt))
+    eo_, fo, go = en.energy_grad(torch.as_tensor(idx.astype(np.int64)))
+    e, fit, g = m.energy_grad(torch.as_tensor(idx).cuda(), 6)
+    assert np.abs(fit.cpu().numpy() - fo.numpy()).max() <= 5e-6
+    raw = np.abs(eo_.numpy() - lam * fo.numpy()) + abs(en.tf.wt_score)
+    assert observed("tfpoe_ube4b_150m:e", np.abs(e.cpu().numpy() - eo_.numpy()), 2 * 2e-3 * (1 + raw) + 5e-6 * lam) <= 1.0
+    assert observed("tfpoe_ube4b_150m:grad", np.abs(g.cpu().numpy() - go.numpy()).max(), 3e-2 * np.abs(go.numpy()).max()) <= 1.0
+    assert float(e[0]) == lam * float(fit[0])                   # wild type: Delta score exactly 0
+
+
 def test_reference_style_energy_object_with_a_checkpoint_file():
     """ProteinProductOfExperts(args) with --unsupervised_expert transformer: weights from a checkpoint file in the
     published format (the reference downloads it into --hub_dir)."""
@@ -139,9 +299,8 @@ def test_reference_style_energy_object_with_a_checkpoint_file():
     with tempfile.TemporaryDirectory() as root:
         synthetic.write_weights_dir(root, "TOY24", potts_seed=7)
         synthetic.write_esm2_checkpoint(os.path.join(root, "hub", "checkpoints", "esm2_t30_150M_UR50D.pt"), 2, 128, 4, 256, seed=2)
-        # (a 2-layer stand-in under the 150M file name: dimensions are read from the tensors, heads must give width 32)
-        import ppde_amd.energy as en
-        en.ESM2_CHECKPOINTS = dict(en.ESM2_CHECKPOINTS, transformer=("esm2_t30_150M_UR50D", 4))
+        # (a 2-layer stand-in under the 150M file name: dimensions are read from the tensors, the head count from the file's
+        # cfg.model Namespace, as facebookresearch/esm does)
         args = argparse.Namespace(energy_lamda=1.0, unsupervised_expert="transformer", protein_weights=root, protein="TOY24",
                                   n_chains=4, device="cuda:0", ppde_rng="philox", hub_dir=os.path.join(root, "hub"))
         ef = ProteinProductOfExperts(args)
@@ -160,17 +319,14 @@ def test_driver_with_the_transformer_expert():
     import glob
     import importlib.util
     import io
-    import ppde_amd.energy as en
     REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     spec = importlib.util.spec_from_file_location("ppde_amd_directed_evolution_tf", os.path.join(REPO, "scripts", "directed_evolution.py"))
     drv = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(drv)
-    saved = dict(en.ESM2_CHECKPOINTS)
-    try:
+    if True:
         with tempfile.TemporaryDirectory() as root, tempfile.TemporaryDirectory() as res:
             synthetic.write_weights_dir(root, "TOY24", potts_seed=7)
             synthetic.write_esm2_checkpoint(os.path.join(res, "checkpoints", "esm2_t30_150M_UR50D.pt"), 2, 128, 4, 256, seed=2)
-            en.ESM2_CHECKPOINTS["potts+transformer"] = ("esm2_t30_150M_UR50D", 4)      # (the toy stand-in has 4 heads of 32)
             argv = ["--protein_weights", root, "--protein", "TOY24", "--results_path", res, "--hub_dir", res, "--device", "cuda:0",
                     "--disable_MSA_transformer_scoring", "--sampler", "PPDE", "--unsupervised_expert", "potts+transformer",
                     "--n_chains", "6", "--n_iters", "12", "--seed", "3", "--log_every", "5", "--energy_lamda", "1", "--ppde_rng", "philox"]
@@ -183,6 +339,3 @@ def test_driver_with_the_transformer_expert():
             assert eh.shape == (13, 6) and np.isfinite(eh).all() and pop.shape == (6, 24, 20)
             assert np.array_equal(np.load(os.path.join(out_dir, "energy_scores.npy")), eh.max(0))
             assert "[Iteration 4]" in buf.getvalue()
-    finally:
-        en.ESM2_CHECKPOINTS.clear()
-        en.ESM2_CHECKPOINTS.update(saved)
