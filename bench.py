@@ -173,7 +173,10 @@ def main():
     if args.workload == "transformer":
         import bench_transformer
         return bench_transformer.main(args, rank, world, local, backend)
-    if world > 1:
+    # PPDE_BENCH_FORCE_DIST=1 (with PPDE_COLLECTIVES_AT_WORLD_1=1): a ONE-rank process group, so that a one-GPU box executes
+    # the RCCL branch (init, barrier, all_reduce, the population gather) before an 8-GPU node ever sees it
+    dist_on = world > 1 or bool(os.environ.get("PPDE_BENCH_FORCE_DIST"))
+    if dist_on:
         import torch.distributed as dist
         torch.cuda.set_device(local)
         if backend == "nccl":
@@ -193,7 +196,7 @@ def main():
     T = args.warmup + args.repeats * args.steps + IN_SITU
 
     def barrier():
-        if world > 1:
+        if dist_on:
             torch.distributed.barrier()
 
     def timed_run(reuse, repeats):
@@ -212,7 +215,7 @@ def main():
             torch.cuda.synchronize()
             dt = time.perf_counter() - t0
             barrier()
-            if world > 1:
+            if dist_on:
                 t = torch.tensor([dt], device=device if backend == "nccl" else "cpu", dtype=torch.float64)
                 torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
                 dt = float(t.item())
@@ -242,7 +245,7 @@ def main():
     # final population collect: one all_gather of best states / energies / histories, outside the
     # timed region, timed on its own
     gather_ms, rccl_ranks = None, None
-    if world > 1:
+    if dist_on:
         ones = torch.ones(1, device=device if backend == "nccl" else "cpu")
         torch.distributed.all_reduce(ones)
         rccl_ranks = int(ones.item())
@@ -309,14 +312,14 @@ def main():
         }
         if roofline_large:
             out["roofline_large"] = roofline_large
-        if world > 1:
+        if dist_on:
             out["rccl_ranks"] = rccl_ranks
             out["backend"] = backend
             out["population_gather_ms"] = gather_ms
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, wt, J, h, i0, Lp, cnn, n)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist_on:
         torch.distributed.destroy_process_group()
 
 

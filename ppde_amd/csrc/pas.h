@@ -494,6 +494,7 @@ __device__ __forceinline__ void propose_body(const PasArgs& a, const RowLds& lds
     for (int r = 0; r < GPT; ++r) q[r] = pp.q0[r];
 
     int pend_l = 0, pend_k = 0;                      // the last move, not yet applied to lds.St
+    const bool exact_race = a.rng_mode == 0;
     for (int s = 0; s < Ub; ++s) {
         const bool capped = dist >= a.thr;
         // ---- logits z = (g - g[current letter]) / 2 with the forward masks (ppde.py:98-104)
@@ -527,8 +528,15 @@ __device__ __forceinline__ void propose_body(const PasArgs& a, const RowLds& lds
             float4 p;
             p.x = clampp(e[r].x * c); p.y = clampp(e[r].y * c); p.z = clampp(e[r].z * c); p.w = clampp(e[r].w * c);
             s3 += p.x; s3 += p.y; s3 += p.z; s3 += p.w;
-            const float vx = p.x * __builtin_amdgcn_rcpf(q[r].x), vy = p.y * __builtin_amdgcn_rcpf(q[r].y);
-            const float vz = p.z * __builtin_amdgcn_rcpf(q[r].z), vw = p.w * __builtin_amdgcn_rcpf(q[r].w);
+            // race value p / q (torch.multinomial: arg-max of probs / q with an IEEE division). Replaying the reference's
+            // noise (rng_mode 0) keeps the division, so a near-tie resolves as it does there; on the device RNG, where no
+            // bit parity with torch is claimed, the ~1-ulp reciprocal saves four divisions per thread and sub-step.
+            float vx, vy, vz, vw;
+            if (exact_race) { vx = p.x / q[r].x; vy = p.y / q[r].y; vz = p.z / q[r].z; vw = p.w / q[r].w; }
+            else {
+                vx = p.x * __builtin_amdgcn_rcpf(q[r].x); vy = p.y * __builtin_amdgcn_rcpf(q[r].y);
+                vz = p.z * __builtin_amdgcn_rcpf(q[r].z); vw = p.w * __builtin_amdgcn_rcpf(q[r].w);
+            }
             if (vx > bv) { bv = vx; bi = 4 * g4; bp = p.x; }
             if (vy > bv) { bv = vy; bi = 4 * g4 + 1; bp = p.y; }
             if (vz > bv) { bv = vz; bi = 4 * g4 + 2; bp = p.z; }

@@ -64,6 +64,10 @@ class HipModel:
         Lp = int(J.shape[0])
         if J.shape != (Lp, Lp, 20, 20) or h.shape != (Lp, 20):
             raise ValueError(f"Potts shapes {J.shape} / {h.shape}; expected [Lp,Lp,20,20] / [Lp,20]")
+        # couplings change under whoever shares this model through the registry below: drop the entry (it is re-made by
+        # register_potts_model when these ARE a potts.pkl's couplings)
+        for k in [k for k, r in _POTTS_MODELS.items() if r() is self]:
+            del _POTTS_MODELS[k]
         _hip.check(self.lib.ppde_model_set_potts(self.handle, _hip.ptr(J), _hip.ptr(h), Lp, int(win_start)))
         self.has_potts, self.win_start, self.Lp = True, int(win_start), Lp
 
@@ -183,6 +187,7 @@ def _potts_key(dataset, device_index):
 
 
 def register_potts_model(dataset, model, params):
+    params.J = None                  # uploaded (90 MB for a GFP-sized window); consumers read index_list / reg_coef / wtseqs only
     model._potts_params = params
     _POTTS_MODELS[_potts_key(dataset, model.device_index)] = weakref.ref(model)
 

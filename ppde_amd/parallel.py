@@ -5,14 +5,27 @@ per-step communication: the device RNG is keyed by the GLOBAL chain index, so a 
 depend on how many ranks there are. The only collective is the final population collect (all_gather over
 RCCL/xGMI on GPUs; gloo in the CPU tests).
 """
+import os
+
 import torch
 import torch.distributed as dist
+
+# PPDE_COLLECTIVES_AT_WORLD_1=1: run the collectives below even in a process group of ONE rank (where they are the
+# identity). It lets a one-GPU box execute the RCCL path end to end -- library load, communicator set-up, host -> device
+# staging, all_gather / broadcast, the way back -- before an 8-GPU node ever sees it (tests/test_host_gpu.py).
+FORCE_AT_WORLD_1 = bool(os.environ.get("PPDE_COLLECTIVES_AT_WORLD_1"))
 
 
 def world():
     if dist.is_available() and dist.is_initialized():
         return dist.get_rank(), dist.get_world_size()
     return 0, 1
+
+
+def active():
+    """True when the collectives below actually communicate: more than one rank, or forced at world size 1."""
+    _, ws = world()
+    return ws > 1 or (FORCE_AT_WORLD_1 and dist.is_available() and dist.is_initialized())
 
 
 def shard_range(n, rank, world_size):
@@ -25,7 +38,7 @@ def shard_range(n, rank, world_size):
 def all_gather_rows(t, n_global, dim=0):
     """Concatenate per-rank shards (unequal sizes allowed) along `dim` on every rank."""
     rank, ws = world()
-    if ws == 1:
+    if not active():
         return t
     sizes = [shard_range(n_global, r, ws) for r in range(ws)]
     mx = max(hi - lo for lo, hi in sizes)
@@ -42,8 +55,7 @@ def all_gather_rows(t, n_global, dim=0):
 
 
 def broadcast_from(t, src):
-    rank, ws = world()
-    if ws > 1:
+    if active():
         home = t.device
         if dist.get_backend() == "nccl" and t.device.type != "cuda":
             t = t.cuda()
@@ -55,8 +67,7 @@ def broadcast_from(t, src):
 def agree_from_rank0(values):
     """Rank 0's integers on every rank (random chain index, default seed): ranks that were seeded differently must
     still record the same chain and draw the same Philox stream."""
-    rank, ws = world()
-    if ws == 1:
+    if not active():
         return [int(v) for v in values]
     t = torch.tensor([int(v) for v in values], dtype=torch.int64)
     return [int(v) for v in broadcast_from(t, 0).tolist()]

@@ -30,7 +30,7 @@ from . import _hip
 from .base_sampler import BaseSampler
 from .encoding import idx_to_onehot
 from .noise import draw_chunk
-from .parallel import agree_from_rank0, all_gather_rows, broadcast_from, shard_range, world
+from .parallel import active as collectives_active, agree_from_rank0, all_gather_rows, broadcast_from, shard_range, world
 
 
 class Chains:
@@ -179,12 +179,15 @@ class PPDE_PAS(BaseSampler):
         min_pos, max_pos = int(min_pos), int(max_pos)
         random_idx = np.random.randint(0, n_global)                       # ppde.py:37 (same numpy RNG consumption)
         rank, ws = world() if self.shard else (0, 1)
+        comm = self.shard and collectives_active()        # (ws > 1, or the one-rank rehearsal of the RCCL path)
         lo, hi = shard_range(n_global, rank, ws)
         n = hi - lo
         idx0 = model.onehot_to_idx(initial_population)
-        seed = self.seed if self.seed is not None else torch.initial_seed()
-        if ws > 1:      # one recorded chain and one Philox key for the whole job, whatever each rank's host RNG state is
-            random_idx, seed = agree_from_rank0([random_idx, seed & (2 ** 63 - 1)])
+        # (63 bits whatever the rank count: the key travels through an int64 tensor when ranks agree on it, and a run's
+        # Philox streams must not depend on how many ranks there are)
+        seed = (self.seed if self.seed is not None else torch.initial_seed()) & (2 ** 63 - 1)
+        if comm:        # one recorded chain and one Philox key for the whole job, whatever each rank's host RNG state is
+            random_idx, seed = agree_from_rank0([random_idx, seed])
         chains = Chains(model, n, num_steps, self.ppde_pas_length, self.nmut_threshold, self.paper_results, min_pos,
                         max_pos, energy_function.which, 0 if self.rng == "torch" else 1, self.reuse_grad, self.cpu_alias,
                         self.trace, random_idx - lo if lo <= random_idx < hi else -1, self.use_graph, seed, lo,
@@ -193,7 +196,7 @@ class PPDE_PAS(BaseSampler):
         chains.init(idx0[lo:hi])
 
         def gathered(a):
-            return all_gather_rows(torch.as_tensor(a), n_global).numpy() if ws > 1 else np.asarray(a)
+            return all_gather_rows(torch.as_tensor(a), n_global).numpy() if comm else np.asarray(a)
 
         def log(i, first=False):
             pk = chains.peek()
@@ -238,9 +241,9 @@ class PPDE_PAS(BaseSampler):
         dev = initial_population.device
         best_idx = gathered(res["best_idx"])
         best_x = torch.from_numpy(idx_to_onehot(best_idx)).float().to(dev)
-        e_hist = all_gather_rows(torch.from_numpy(res["energy_history"]), n_global, dim=1).numpy() if ws > 1 else res["energy_history"]
-        f_hist = all_gather_rows(torch.from_numpy(res["fitness_history"]), n_global, dim=1).numpy() if ws > 1 else res["fitness_history"]
-        if ws > 1:
+        e_hist = all_gather_rows(torch.from_numpy(res["energy_history"]), n_global, dim=1).numpy() if comm else res["energy_history"]
+        f_hist = all_gather_rows(torch.from_numpy(res["fitness_history"]), n_global, dim=1).numpy() if comm else res["fitness_history"]
+        if comm:
             owner = [r for r in range(ws) if shard_range(n_global, r, ws)[0] <= random_idx < shard_range(n_global, r, ws)[1]][0]
             rt = torch.from_numpy(res["random_traj"]) if res["random_traj"] is not None else torch.zeros(num_steps + 1, L, dtype=torch.uint8)
             rtraj = broadcast_from(rt, owner).numpy()

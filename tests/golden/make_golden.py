@@ -231,6 +231,19 @@ def real_case(protein, lamda, n, state_seed, out):
     print("wrote", out, f"({os.path.getsize(out) / 1e3:.0f} kB)")
 
 
+def real_cnn_weights(protein, out):
+    """The VALUES of the shipped supervised-CNN checkpoints of one protein (weights/<protein>/onehot_cnn_seed={0,1,2}.pt,
+    data files, 340 kB for PABP) as a fixture, so that the GPU box -- which never sees /root/reference -- can run the
+    HIP CNN kernel on TRAINED weights against what the reference computed from them (real_<protein>.npz)."""
+    from ppde_amd.weights import load_cnn_states
+    src = os.path.join("/root/reference/weights", protein)
+    states = load_cnn_states(src)
+    payload = {f"net{k}.{name}": v for k, sd in enumerate(states) for name, v in sd.items()}
+    payload["file_sha"] = np.array([file_sha(os.path.join(src, f"onehot_cnn_seed={k}.pt")) for k in range(len(states))])
+    np.savez_compressed(out, **payload)
+    print("wrote", out, f"({os.path.getsize(out) / 1e3:.0f} kB)")
+
+
 def run_case(root, protein, lamda, n, T, seed, pas, nmut, paper, out, store_q, unsup="potts"):
     """One reference sampler run with everything it drew recorded. unsup = 'transformer' / 'potts+transformer': the
     reference's energy.py:110-130 branch over the stand-in ESM-2 (see install_stubs)."""
@@ -401,6 +414,9 @@ def main():
         for protein, lam, seed in (("PABP_YEAST_Fields2013", 5.0, 21), ("UBE4B_MOUSE_Klevit2013-nscor_log2_ratio", 0.5, 22),
                                    ("GFP_AEQVI_Sarkisyan2016", 15.0, 23)):
             real_case(protein, lam, 6, seed, os.path.join(HERE, f"real_{protein.split('_')[0].lower()}.npz"))
+        return
+    if only and "realcnn" in only:
+        real_cnn_weights("PABP_YEAST_Fields2013", os.path.join(HERE, "real_pabp_cnn.npz"))
         return
     if only and "tf" in only:
         with tempfile.TemporaryDirectory() as root:

@@ -123,3 +123,11 @@ def compare_runs_up_to_near_ties(tr, ref, noise, gap_tol, acc_tol):
             parted[b] = True
             notes.append((int(b), t, "accept", margin))
     return int((~parted).sum()), notes, ~parted
+
+
+def real_pabp_cnn_states():
+    """The shipped (TRAINED) PABP supervised-CNN weights as frozen in tests/golden/real_pabp_cnn.npz: a list of three state
+    dicts with the reference's parameter names, and the SHA-256 of the files they were read from."""
+    fx = load("real_pabp_cnn.npz")
+    names = ("encoder.weight", "encoder.bias", "embedding.0.weight", "embedding.0.bias", "decoder.weight", "decoder.bias")
+    return [{k: fx[f"net{i}.{k}"] for k in names} for i in range(3)], [str(x) for x in fx["file_sha"]]

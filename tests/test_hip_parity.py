@@ -74,6 +74,49 @@ def test_energy_grad_vs_reference_fixture(name):
     assert float(e_wt[0]) == 0.0
 
 
+def test_trained_cnn_weights_through_the_hip_kernels():
+    """The HIP CNN kernel on the TRAINED PABP weights (tests/golden/real_pabp_cnn.npz, the shipped checkpoints' values)
+    against the outputs the REFERENCE computed from those files (real_pabp.npz): which = 2 (ProteinSupervised) and
+    which = 3 (Potts product of experts, lamda = 5, synthetic couplings). Trained networks have saturated / dead features
+    and exact ties at the max over positions that seeded-uniform weights never show."""
+    from helpers import real_pabp_cnn_states
+    fx = load("real_pabp.npz")
+    cnn, _ = real_pabp_cnn_states()
+    J, h = synthetic.make_potts(int(fx["Lp"]), seed=int(fx["potts_seed"]))
+    lam = float(fx["lamda"])
+    m = hip_model(J, h, int(fx["win_start"]), fx["wt_idx"], cnn, lam)
+    idx = torch.as_tensor(fx["idx"]).cuda()
+    e2, f2, g2 = m.energy_grad(idx, 2)
+    ftol = 4e-6 * np.maximum(1.0, np.abs(fx["supervised"]))
+    assert observed("real_pabp:supervised", np.abs(f2.cpu().numpy() - fx["supervised"]), ftol) <= 1.0
+    assert np.array_equal(e2.cpu().numpy(), f2.cpu().numpy())
+    gs = max(1.0, float(np.abs(fx["supervised_grad"]).max()))
+    assert observed("real_pabp:supervised_grad", np.abs(g2.cpu().numpy() - fx["supervised_grad"]).max(), 2e-6 * gs) <= 1.0
+    e, fit, g = m.energy_grad(idx, 3)
+    assert observed("real_pabp:fit", np.abs(fit.cpu().numpy() - fx["fit"]), ftol) <= 1.0
+    assert observed("real_pabp:e", np.abs(e.cpu().numpy() - fx["e"]), e_tol(fx["e"], lam) + 4e-6 * lam * np.maximum(1.0, np.abs(fx["fit"]))) <= 1.0
+    assert observed("real_pabp:grad", np.abs(g.cpu().numpy() - fx["grad"]).max(), 2e-6 * max(1.0, lam) * max(1.0, float(np.abs(fx["grad"]).max()))) <= 1.0
+    # and a short sampler run on them against the oracle (device RNG, oracle fed the device's noise)
+    from helpers import device_noise
+    from ppde_amd.sampler import Chains
+    n, T, pas, i0, Lp = 16, 25, 2, int(fx["win_start"]), int(fx["Lp"])
+    wt = fx["wt_idx"]
+    ch = Chains(m, n, T, pas, 6, False, i0, i0 + Lp - 1, 3, 1, trace=True, random_chain=0, seed=31, use_graph=False)
+    ch.init(torch.as_tensor(np.tile(wt, (n, 1))).cuda())
+    ch.run(T)
+    tr, res = ch.trace(), ch.collect()
+    noise = device_noise(ch, T, pas)
+    ref = orc.run(oracle_energy(J, h, i0, wt, cnn, lam), np.tile(wt.astype(np.int64), (n, 1)), wt, lambda t: noise[t], T, i0, i0 + Lp - 1,
+                  pas, 6, False, trace=True)
+    for t in range(T):
+        U = noise[t][0].numpy()
+        for s in range(int(U.max())):
+            act = s < U
+            assert np.array_equal(tr["flat"][t, s][act], ref["traces"][t]["flat"][s].numpy()[act]), (t, s)
+    assert np.array_equal(tr["accepted"].astype(bool), ref["accepted"].numpy())
+    assert np.array_equal(res["best_idx"], ref["best_idx"].numpy())
+
+
 @pytest.mark.parametrize("n", [1, 3, 64, 65, 128, 200, 600])
 def test_energy_grad_vs_oracle_batch_sizes(n):
     """Ragged batch sizes through every chain-group instantiation; also checks batch-independence bit for bit."""

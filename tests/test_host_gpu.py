@@ -99,3 +99,74 @@ def test_one_device_copy_of_the_couplings():
         s = proteins_potts_score(x, os.path.join(root, "TOY24"))
         assert float(s.abs().max()) == 0.0
         assert torch.isfinite(alr(x)).all()
+
+
+_RCCL_ONE_RANK = r"""
+import os, sys
+sys.path.insert(0, sys.argv[1])
+import numpy as np
+import torch
+import torch.distributed as dist
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+from ppde_amd import parallel, synthetic
+from ppde_amd.encoding import seqs_to_idx
+assert parallel.active() and dist.get_backend() == "nccl"
+# host tensor -> device staging -> all_gather over RCCL -> back to the host, along both axes, three dtypes
+for t, dim in ((torch.arange(12, dtype=torch.uint8).reshape(3, 4), 0), (torch.randn(5, 3), 1), (torch.arange(7, dtype=torch.int32), 0)):
+    out = parallel.all_gather_rows(t, t.shape[dim], dim=dim)
+    assert out.device.type == "cpu" and out.dtype == t.dtype and torch.equal(out, t), (t.dtype, dim)
+assert torch.equal(parallel.broadcast_from(torch.full((3,), 4.0), 0), torch.full((3,), 4.0))
+assert parallel.agree_from_rank0([123, 2 ** 62 + 5]) == [123, 2 ** 62 + 5]
+ones = torch.ones(1, device="cuda:0")
+dist.all_reduce(ones)
+dist.barrier()
+assert float(ones) == 1.0
+# the sampler's sharded collect (PPDE_PAS.run(..., ppde_shard=True)) through the same path == the plain run
+import argparse
+from ppde_amd.energy import HipModel
+from ppde_amd.sampler import PPDE_PAS
+_, seq, (i0, Lp) = synthetic.PROTEINS["TOY24"]
+wt = seqs_to_idx([seq])[0]
+J, h = synthetic.make_potts(Lp, seed=7)
+class E:                      # minimal energy-function shell around a HipModel
+    which = 1
+E.model = HipModel(wt, "cuda:0"); E.model.set_potts(J, h, i0)
+x0 = torch.nn.functional.one_hot(torch.as_tensor(np.tile(wt, (9, 1))).long(), 20).float()
+res = []
+for shard in (False, True):
+    a = argparse.Namespace(ppde_pas_length=2, nmut_threshold=3, paper_results=False, ppde_rng="philox", ppde_seed=11, ppde_shard=shard)
+    np.random.seed(1)
+    res.append(PPDE_PAS(a).run(x0, 30, E, i0, i0 + Lp - 1, lambda x: torch.zeros(x.shape[0]), log_every=10))
+assert torch.equal(res[0][0], res[1][0]) and all(np.array_equal(p, q) for p, q in zip(res[0][1:5], res[1][1:5]))
+assert all(np.array_equal(p, q) for p, q in zip(res[0][5], res[1][5]))
+dist.destroy_process_group()
+print("rccl one-rank ok")
+"""
+
+
+def test_rccl_path_executes_on_one_gpu():
+    """A process group of ONE rank on the nccl (= RCCL) backend with the world-size-1 shortcut switched off: RCCL loads,
+    builds a communicator and moves the population collect's buffers (host -> device staging -> all_gather / broadcast ->
+    host), and `bench.py --gpus 1` runs its nccl branch (init, barrier, all_reduce, timed gather). Every other multi-rank
+    test uses gloo; this is the only place the RCCL code path runs before an 8-GPU node sees it."""
+    import json
+    import subprocess
+    import sys
+    REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29547", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
+               PPDE_COLLECTIVES_AT_WORLD_1="1", HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="4")
+    with tempfile.NamedTemporaryFile("w", suffix=".py", delete=False) as fh:
+        fh.write(_RCCL_ONE_RANK)
+        path = fh.name
+    try:
+        r = subprocess.run([sys.executable, path, REPO], capture_output=True, text=True, timeout=420, env=env)
+        assert r.returncode == 0 and "rccl one-rank ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+    finally:
+        os.unlink(path)
+    env.update(MASTER_PORT="29548", PPDE_BENCH_FORCE_DIST="1")
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "1", "--steps", "20", "--warmup", "5", "--repeats", "2",
+                        "--no-cpu-baseline", "--no-large"], capture_output=True, text=True, timeout=420, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["backend"] == "nccl" and line["rccl_ranks"] == 1 and line["population_gather_ms"] > 0 and line["value"] > 0

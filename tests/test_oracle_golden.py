@@ -124,6 +124,26 @@ def test_transformer_product_of_experts_glue():
         assert np.abs(full.numpy() - (fx[f"{tag}_grad"] + lam * fx["supervised_grad"])).max() <= 2e-5 * max(1.0, gmax)
 
 
+def test_trained_cnn_weights_fixture():
+    """tests/golden/real_pabp_cnn.npz holds the VALUES of the shipped PABP CNN checkpoints (the files real_pabp.npz was
+    generated on, by hash); the oracle on them reproduces the reference's frozen outputs. Runs everywhere (no reference
+    mount needed), and is what the GPU test of the HIP CNN kernel on trained weights stands on."""
+    from helpers import real_pabp_cnn_states
+    from ppde_amd import synthetic
+    fx = load("real_pabp.npz")
+    cnn, shas = real_pabp_cnn_states()
+    ref = {str(f): str(h) for f, h in zip(fx["files"], fx["file_sha"])}
+    assert shas == [ref[f"onehot_cnn_seed={k}.pt"] for k in range(3)]
+    J, h = synthetic.make_potts(int(fx["Lp"]), seed=int(fx["potts_seed"]))
+    lam = float(fx["lamda"])
+    en = oracle_energy(J, h, int(fx["win_start"]), fx["wt_idx"], cnn, lam)
+    idx = torch.as_tensor(fx["idx"].astype(np.int64))
+    e, fit, g = en.energy_grad(idx)
+    assert np.all(np.abs(fit.numpy() - fx["fit"]) <= 4e-6 * np.maximum(1.0, np.abs(fx["fit"])))
+    assert np.all(np.abs(e.numpy() - fx["e"]) <= etol(fx["e"]) + 4e-6 * lam * np.maximum(1.0, np.abs(fx["fit"])))
+    assert np.abs(g.numpy() - fx["grad"]).max() <= 2e-6 * max(1.0, lam) * max(1.0, float(np.abs(fx["grad"]).max()))
+
+
 def test_wild_type_delta_is_zero():
     fx = load("ops_toy24_lam5.npz")
     J, h, i0, wt_idx, cnn = model_from_fixture(fx)
