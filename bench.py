@@ -38,6 +38,7 @@ sys.path.insert(0, REPO)
 
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 MFMA_BF16_PEAK_TF = 2500.0   # dense bf16/f16 MFMA peak (MI355X_MICROARCH.md)
+MFMA_F32_PEAK_TF = 157.3     # dense fp32 matrix peak (MI355X_MICROARCH.md)
 
 
 def parse():
@@ -61,6 +62,7 @@ def parse():
     p.add_argument("--graph", type=int, default=1, help="replay iterations from hipGraphs captured at init")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-large", action="store_true", help="skip the GFP-sized Potts kernel timing (roofline_large)")
+    p.add_argument("--no-also", action="store_true", help="skip the short config-3 / config-5 measurements (`also`) of the default N = 1 run")
     p.add_argument("--cpu-seconds", type=float, default=15.0)
     p.add_argument("--tf-layers", type=int, default=30)
     p.add_argument("--tf-dim", type=int, default=640)
@@ -119,6 +121,71 @@ def load_traffic(key):
     if not ent:
         return None, None
     return ent.get("hbm_bytes_per_launch"), f"profiles/potts_pmc.json[{key}] ({ent.get('collected', 'earlier rocprofv3 --pmc passes')}); a constant read from that file, not measured by this run"
+
+
+def cnn_useful_flops(n, L, nets=3, K=5):
+    """forward contraction 2*n*T*C*F per network (T = L-K+1 rows, C = L channels, F = 2L features) and the
+    routed input-gradient contraction 2*n*T*C*(K*20)."""
+    T, C, F = L - K + 1, L, 2 * L
+    return nets * 2.0 * n * T * C * (F + K * 20)
+
+
+def also_config3(args, device, rank):
+    """BASELINE configs[2] (PABP Potts + supervised CNN, lamda = 5, 128 chains) in a few short blocks, for the N = 1 line."""
+    import torch
+    from ppde_amd.sampler import Chains
+    from bench_transformer import rocprof_frac
+    m, wt, J, h, i0, Lp, cnn = build_model("potts+cnn", device, "PABP")
+    n, L, steps, warm, reps = 128, wt.shape[0], 200, 40, 3
+    out = {}
+    for reuse in (False, True):
+        ch = Chains(m, n, warm + reps * steps + 8, args.pas, args.nmut, False, i0, i0 + Lp - 1, 3, 1, reuse_grad=reuse, random_chain=0,
+                    use_graph=True, seed=1, chain_offset=rank * n)
+        ch.init(torch.as_tensor(np.tile(wt, (n, 1))).to(device))
+        ch.run(warm)
+        ch.sync()
+        dts = []
+        for _ in range(reps):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            ch.run(steps)
+            ch.sync()
+            torch.cuda.synchronize()
+            dts.append(time.perf_counter() - t0)
+        dt = float(np.median(dts))
+        if not reuse:
+            us = ch.time_experts(200)
+            fl = cnn_useful_flops(n, L)
+            out.update(value=steps / dt, unit="steps/s", ms_per_step=dt / steps * 1e3, steps=steps, warmup=warm,
+                       timed_blocks={"repeats": reps, "statistic": "median", "ms_per_block": [round(x * 1e3, 3) for x in dts]},
+                       workload=f"PABP_YEAST Potts + supervised CNN product of experts (lamda=5), L={L}, L'={Lp}, {n} chains, "
+                                f"pas_length={args.pas}, device Philox RNG, hipGraph replay", dtype="f32",
+                       roofline={"kernel": "k_experts (Potts tiles + 3-network CNN forward/backward in one launch)", "bound": "mfma",
+                                 "achieved": fl / (us * 1e-6) / 1e12, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
+                                 "frac": fl / (us * 1e-6) / 1e12 / MFMA_F32_PEAK_TF, "traffic": None,
+                                 "algorithmic_flops_per_launch": fl, "avg_launch_us": us, "launches_timed": 200,
+                                 "rocprof": rocprof_frac("config3", "k_experts", fl, MFMA_F32_PEAK_TF * 1e12)})
+            assert np.isfinite(ch.collect()["energy_history"]).all()
+        else:
+            out["value_reuse_grad"] = steps / dt
+        del ch
+    if not args.no_cpu_baseline:
+        a2 = argparse.Namespace(**{**vars(args), "cpu_seconds": 8.0})
+        out["cpu_baseline"] = cpu_baseline(a2, wt, J, h, i0, Lp, cnn, n)
+    return out
+
+
+def also_config5(args, rank, local):
+    """BASELINE configs[4] (UBE4B transformer product of experts, 256 chains) in a few short blocks, for the N = 1 line."""
+    import bench_transformer
+    a5 = argparse.Namespace(**{**vars(args), "chains": 128, "reuse_grad": 0})
+    d = bench_transformer.measure(a5, rank, 1, local, "nccl", steps=4, warmup=1, repeats=3, with_cpu=False if args.no_cpu_baseline else "sample",
+                                  other_policy=False)
+    keep = ("value", "unit", "ms_per_step", "steps", "warmup", "timed_blocks", "dtype", "roofline", "evaluation", "cpu_baseline")
+    out = {k: d[k] for k in keep if k in d}
+    out["workload"] = d["config"]["workload"]
+    out["evaluation_ms"] = d["evaluation"]["ms"]
+    return out
 
 
 def cpu_baseline(args, wt, J, h, i0, Lp, cnn, n):
@@ -239,6 +306,10 @@ def main():
     achieved = alg_bytes / (pk_us * 1e-6) / 1e9
     traffic, traffic_source = load_traffic(args.protein)
 
+    from bench_transformer import rocprof_frac
+    tag = {("potts", "PABP"): "config2", ("potts+cnn", "PABP"): "config3", ("potts", "GFP"): "gfp", ("potts", "UBE4B"): "ube4b"}.get((args.workload, args.protein))
+    rocprof = rocprof_frac(tag, "potts_energy_grad_kernel", alg_bytes, HBM_PEAK_GBS * 1e9) if tag and n == 128 else None
+
     res = ch.collect()
     assert np.isfinite(res["energy_history"]).all()
 
@@ -307,7 +378,8 @@ def main():
                                          "resident in the 256 MB Infinity Cache (MALL) between launches, so this is fabric "
                                          "traffic, not DRAM traffic",
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_us": pk_us, "launches_timed": 500,
-                         "avg_launch_us_event_pair_per_launch_in_situ": pk_situ_us},
+                         "avg_launch_us_event_pair_per_launch_in_situ": pk_situ_us,
+                         "rocprof": rocprof},
             ("value_reuse_grad" if not args.reuse_grad else "value_reevaluate"): world * args.steps / dt_other,
         }
         if roofline_large:
@@ -318,6 +390,16 @@ def main():
             out["population_gather_ms"] = gather_ms
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, wt, J, h, i0, Lp, cnn, n)
+        # BASELINE configs[2] and configs[4] under the same clock: a few short median-of-3 blocks each (N = 1 default workload only)
+        if world == 1 and not dist_on and args.workload == "potts" and args.protein == "PABP" and n == 128 and not args.no_also:
+            del m
+            also = {"config3": also_config3(args, device, rank)}
+            if out.get("cpu_baseline") and also["config3"].get("cpu_baseline"):
+                out["cpu_baseline"]["value_with_cnn"] = also["config3"]["cpu_baseline"]["value"]
+                out["cpu_baseline"]["sample"] += (" With the supervised CNN evaluated as the reference does (timed for also.config3, lamda = 5: "
+                                                  "the same work as lamda = 0): value_with_cnn.")
+            also["config5"] = also_config5(args, rank, local)
+            out["also"] = also
         print(json.dumps(out), flush=True)
     if dist_on:
         torch.distributed.destroy_process_group()

@@ -27,7 +27,9 @@ def eval_flops(n, L, layers, D, F):
     return layers * (2 * lin + att_f * 3.5) + 2 * head + 2.0 * M * 33 * D
 
 
-def main(args, rank, world, local, backend):
+def measure(args, rank, world, local, backend, steps, warmup, repeats, with_cpu, other_policy=True):
+    """-> the bench dict of BASELINE configs[4] (`python bench.py --workload transformer` prints it; the default N = 1 run of
+    bench.py embeds a short version as `also.config5`)."""
     import torch
     sys.path.insert(0, REPO)
     from ppde_amd import _hip, synthetic
@@ -47,9 +49,6 @@ def main(args, rank, world, local, backend):
     def barrier():
         if world > 1:
             torch.distributed.barrier()
-    steps = args.steps if args.steps != 2000 else 20            # (the defaults of the Potts workload would run for minutes)
-    warmup = args.warmup if args.warmup != 200 else 3
-    repeats = min(args.repeats, 3)
     n = args.chains if args.chains != 128 else 256
     name = [k for k in synthetic.PROTEINS if k.startswith("UBE4B")][0]
     _, seq, _ = synthetic.PROTEINS[name]
@@ -91,7 +90,7 @@ def main(args, rank, world, local, backend):
         return float(np.median(dts)), dts
 
     dt, dts = timed(bool(args.reuse_grad))
-    dt_other, _ = timed(not bool(args.reuse_grad))
+    dt_other = timed(not bool(args.reuse_grad))[0] if other_policy else None
     # dominant kernel: tf_gemm_nt at the fc1 shape (bias + GELU epilogue), timed IN SITU: a HIP event pair around every fc1
     # launch of one real evaluation (what rocprofv3's per-kernel average of the same command sees). The same kernel on
     # pseudo-random operands, launched back to back, is reported beside it: random fp16 data toggles more of the matrix
@@ -123,7 +122,8 @@ def main(args, rank, world, local, backend):
                                "device Philox RNG, all chains start at WT",
                    "chains_per_gpu": n, "total_chains": n * world,
                    "parallelism": "1 GPU" if world == 1 else f"chains sharded x{world}, no per-step collective",
-                   "energy_evaluations_per_step": 1 if args.reuse_grad else 2},
+                   "energy_evaluations_per_step": 1 if args.reuse_grad else 2,
+                   "proposal_gradient": "unsupervised expert only, as the reference's transformer branch (energy.py:125): no CNN backward"},
         "chain_steps_per_s": world * n * steps / dt,
         "timed_blocks": {"repeats": len(dts), "statistic": "median", "ms_per_block": [round(x * 1e3, 3) for x in dts]},
         "graph_captured_in_timed_region": False,
@@ -135,25 +135,59 @@ def main(args, rank, world, local, backend):
                      "avg_launch_us_random_operands_back_to_back": us_rand.value},
         "evaluation": {"ms": ev * 1e3, "algorithmic_tflop": fl / 1e12, "tflops": fl / ev / 1e12,
                        "note": "one transformer energy+gradient evaluation of all chains (forward + input gradient, every kernel)"},
-        ("value_reuse_grad" if not args.reuse_grad else "value_reevaluate"): world * steps / dt_other,
     }
+    if dt_other:
+        out["value_reuse_grad" if not args.reuse_grad else "value_reevaluate"] = world * steps / dt_other
+    stats = rocprof_frac("transformer", "tf_gemm_nt<3,", 2.0 * M * F * D, MFMA_F16_PEAK_TF * 1e12)       # <3, ...> = the bias + GELU epilogue (fc1)
+    if stats:
+        out["roofline"]["rocprof"] = stats
     if world > 1:
         out["backend"] = backend
-    if world == 1 and not args.no_cpu_baseline:
+    if world == 1 and with_cpu:
         sys.path.insert(0, os.path.join(REPO, "oracle"))
         import esm_oracle as eo
         cores = min(os.cpu_count() or 1, 16)
         torch.set_num_threads(cores)
         orc = eo.EsmOracle(st, layers, D, H, half_points=True)
-        ns = 4
+        ns = min(n, 64 if with_cpu == "minibatch" else 8)        # 64 = one minibatch of the reference's loop (energy.py:77, :113-127)
         idx = np.tile(wt.astype(np.int64), (ns, 1))
         t0 = time.perf_counter()
         orc.score_grad(idx)
         te = time.perf_counter() - t0
         out["cpu_baseline"] = {"value": 1.0 / (2 * te * n / ns), "unit": "MCMC steps/s", "cores": int(torch.get_num_threads()), "kind": "port",
-                               "sample": f"ONE transformer energy+gradient evaluation of {ns} chains through oracle/esm_oracle.py ({te:.1f} s), "
-                                         f"scaled to {n} chains and two evaluations per step; the supervised CNN and the sampler "
-                                         "arithmetic are not included (they are < 1 % of the step on the CPU)"}
+                               "sample": f"ONE transformer energy+gradient evaluation of {ns} chains ("
+                                         + ("one minibatch of the reference's loop, energy.py:113-127" if ns == 64 else "a bounded sample")
+                                         + f") through oracle/esm_oracle.py ({te:.1f} s), scaled to {n} chains and two evaluations per "
+                                         "step; the supervised CNN and the sampler arithmetic are not included (< 1 % of the step on the CPU)"}
+    del m
+    return out
+
+
+def rocprof_frac(tag, kernel_substr, work_per_launch, peak=None):
+    """Average duration of a kernel from the newest committed profiles/rNN_<tag>_kernel_stats.csv (rocprofv3 --kernel-trace
+    --stats of the same bench command, scripts/collect_profiles.sh), and the roofline fraction it gives: a constant read
+    from that file, printed next to the live event-pair figure so that the line reproduces from profiles/."""
+    import csv
+    import glob
+    files = sorted(glob.glob(os.path.join(REPO, "profiles", f"r[0-9][0-9]_{tag}_kernel_stats.csv")))
+    if not files:
+        return None
+    rows = [r for r in csv.DictReader(open(files[-1])) if kernel_substr in r["Name"]]
+    if not rows:
+        return None
+    r = max(rows, key=lambda r: float(r["TotalDurationNs"]))
+    us = float(r["AverageNs"]) / 1e3
+    out = {"file": "profiles/" + os.path.basename(files[-1]), "kernel": r["Name"], "launches": int(r["Calls"]), "avg_launch_us": us}
+    if work_per_launch and peak:
+        out["frac_rocprof"] = work_per_launch / (us * 1e-6) / peak
+    return out
+
+
+def main(args, rank, world, local, backend):
+    import torch
+    steps = args.steps if args.steps != 2000 else 20            # (the defaults of the Potts workload would run for minutes)
+    warmup = args.warmup if args.warmup != 200 else 3
+    out = measure(args, rank, world, local, backend, steps, warmup, min(args.repeats, 3), False if args.no_cpu_baseline else "minibatch")
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -237,6 +237,11 @@ int ppde_chains_philox_dump(ppde_chains* c, int it, int s, float* q_dev, float* 
  * the launches recorded since the last reset, measured with HIP events on the chains' stream. */
 int ppde_chains_time_potts_kernel(ppde_chains* c, int reps, float* avg_us);
 
+/* The same for ALL experts of the chains' energy (cfg.which, with gradients), e.g. the fused Potts + CNN launch of the
+ * Potts product of experts: `reps` evaluations of the current states into the proposal slot between one HIP event
+ * pair on the chains' stream; average microseconds per evaluation. */
+int ppde_chains_time_experts(ppde_chains* c, int reps, float* avg_us);
+
 /* The same kernel timed IN SITU: runs `iters` real iterations (eagerly, on the chains' stream) with a HIP event
  * pair around every Potts energy+gradient launch and returns the mean event-to-event time in microseconds and
  * the number of launches timed. The iterations count towards steps_done. rng_mode 1 only. */

@@ -66,6 +66,7 @@ SIGNATURES = {
     "ppde_chains_graph_stats": (_i, [_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "ppde_chains_philox_dump": (_i, [_p, _i, _i, _p, _p, _p]),
     "ppde_chains_time_potts_kernel": (_i, [_p, _i, C.POINTER(_f)]),
+    "ppde_chains_time_experts": (_i, [_p, _i, C.POINTER(_f)]),
     "ppde_chains_time_potts_in_situ": (_i, [_p, _i, C.POINTER(_f), C.POINTER(_i)]),
 }
 

@@ -1372,6 +1372,26 @@ int ppde_chains_time_potts_in_situ(ppde_chains* c, int iters, float* avg_us, int
     return PPDE_OK;
 }
 
+int ppde_chains_time_experts(ppde_chains* c, int reps, float* avg_us) {
+    ARGCHK(c && c->initialised && avg_us && reps >= 1, "bad argument");
+    HIPCHK(hipSetDevice(c->m->device));
+    EventPair ev;
+    HIPCHK(hipEventCreate(&ev.a));
+    HIPCHK(hipEventCreate(&ev.b));
+    // current states into the proposal slot, exactly as the evaluation inside an iteration launches it
+    int rc = eval_experts(c->m, c->cfg.which, cur_states(c), c->n, chain_targets(c, 1), 1, c->stream);   // warm
+    if (rc) return rc;
+    HIPCHK(hipEventRecord(ev.a, c->stream));
+    for (int i = 0; i < reps; ++i)
+        if ((rc = eval_experts(c->m, c->cfg.which, cur_states(c), c->n, chain_targets(c, 1), 1, c->stream))) return rc;
+    HIPCHK(hipEventRecord(ev.b, c->stream));
+    HIPCHK(hipEventSynchronize(ev.b));
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, ev.a, ev.b));
+    *avg_us = ms * 1000.f / reps;
+    return PPDE_OK;
+}
+
 int ppde_chains_time_potts_kernel(ppde_chains* c, int reps, float* avg_us) {
     ARGCHK(c && c->initialised && avg_us && reps >= 1, "bad argument");
     ARGCHK(c->cfg.which & 1, "no Potts expert in this energy");

@@ -138,6 +138,12 @@ class Chains:
         _hip.check(self.lib.ppde_chains_time_potts_in_situ(self.handle, int(iters), C.byref(v), C.byref(k)))
         return v.value, k.value
 
+    def time_experts(self, reps=100):
+        """Mean duration (us) of one evaluation of all experts of the energy (current states -> proposal slot)."""
+        v = C.c_float()
+        _hip.check(self.lib.ppde_chains_time_experts(self.handle, int(reps), C.byref(v)))
+        return v.value
+
     def time_potts_kernel(self, reps=200):
         v = C.c_float()
         _hip.check(self.lib.ppde_chains_time_potts_kernel(self.handle, int(reps), C.byref(v)))

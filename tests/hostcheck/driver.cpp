@@ -71,7 +71,8 @@ int sequence(int L, int Lp, int win, bool with_tf, bool verbose, int tf_dim = 12
     }
     TRY(ppde_idx_to_onehot(m, idx.data(), n, onehot.data(), nullptr));
     TRY(ppde_onehot_to_idx(m, onehot.data(), n, back.data(), nullptr));
-    for (int which = 1; which <= (with_tf ? 7 : 3); ++which) {
+    for (int which = 1; which <= (with_tf ? 15 : 3); ++which) {      // (8..15: PPDE_WHICH_FULL_GRAD on top of 0..7)
+        if (!(which & 7)) continue;
         TRY(ppde_energy_grad(m, idx.data(), n, which, e.data(), fit.data(), grad.data(), nullptr));
         TRY(ppde_energy_grad(m, idx.data(), 2, which, e.data(), fit.data(), nullptr, nullptr));   // smaller batch, no gradient
     }
@@ -119,6 +120,7 @@ int sequence(int L, int Lp, int win, bool with_tf, bool verbose, int tf_dim = 12
         TRY(ppde_chains_graph_stats(c, &cap, &cap_run, &rep, &eag));
         float us = 0.f; int launches = 0;
         TRY(ppde_chains_time_potts_kernel(c, 3, &us));
+        TRY(ppde_chains_time_experts(c, 2, &us));
         if (cfg.which == 3 && streams == 1) TRY(ppde_chains_time_potts_in_situ(c, 2, &us, &launches));
         std::vector<float> qd((size_t)n * N), ud(n);
         std::vector<int32_t> Ud(n);
