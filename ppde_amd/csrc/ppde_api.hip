@@ -85,6 +85,7 @@ struct ppde_model {
     TfModel* tf = nullptr;
     TfWork* s_tfw = nullptr;
     float *s_gradT = nullptr, *s_tfE = nullptr;
+    int s_tf_n = 0;                  // chains s_gradT / s_tfE are sized for
     // chunk maxima of the long-sequence CNN path, sized for `cnn_scratch_n` chains
     float* cnn_cmax = nullptr;
     int* cnn_carg = nullptr;
@@ -488,6 +489,7 @@ int ppde_model_set_transformer(ppde_model* m, int n_layers, int dim, int heads, 
     HIPCHK(hipSetDevice(m->device));
     delete m->tf; m->tf = nullptr;
     delete m->s_tfw; m->s_tfw = nullptr;
+    hipFree(m->s_gradT); hipFree(m->s_tfE); m->s_gradT = m->s_tfE = nullptr; m->s_tf_n = 0;
     TfModel* t = new TfModel();
     t->layers = n_layers; t->Dr = dim; t->D = (dim + 127) & ~127; t->H = heads; t->F = ffn; t->HD = dim / heads;
     int rc = tf_build_model(t, m->L, w);
@@ -792,16 +794,21 @@ int ppde_energy_grad(ppde_model* m, const uint8_t* idx_dev, int n, int which, fl
     EvalTargets t{m->s_grad, m->s_epart, m->s_gradC, m->s_fitC, 0};
     if (which & 4) {
         ARGCHK(m->tf, "no transformer expert");
-        if (!m->s_tfw || m->s_tfw->n_cap < n) {
+        if (!m->s_tfw || m->s_tfw->n_cap < std::min(n, tf_chunk_cap(m->tf))) {      // activations: one chunk of chains
             delete m->s_tfw; m->s_tfw = nullptr;
-            hipFree(m->s_gradT); hipFree(m->s_tfE); m->s_gradT = m->s_tfE = nullptr;
             m->s_tfw = new TfWork();
-            if ((rc = tf_alloc_work(m->tf, m->s_tfw, n)) != PPDE_OK || dalloc(&m->s_gradT, (size_t)n * g.N) != hipSuccess ||
-                dalloc(&m->s_tfE, (size_t)n) != hipSuccess) {          // leave no half-built workspace behind
+            if ((rc = tf_alloc_work(m->tf, m->s_tfw, n)) != PPDE_OK) {                 // leave no half-built workspace behind
                 delete m->s_tfw; m->s_tfw = nullptr;
-                hipFree(m->s_gradT); hipFree(m->s_tfE); m->s_gradT = m->s_tfE = nullptr;
-                return rc ? rc : fail(PPDE_ERR_HIP, "device allocation failed for the transformer workspace");
+                return rc;
             }
+        }
+        if (m->s_tf_n < n) {                                                         // gradient rows and scores: all n chains
+            hipFree(m->s_gradT); hipFree(m->s_tfE); m->s_gradT = m->s_tfE = nullptr; m->s_tf_n = 0;
+            if (dalloc(&m->s_gradT, (size_t)n * g.N) != hipSuccess || dalloc(&m->s_tfE, (size_t)n) != hipSuccess) {
+                hipFree(m->s_gradT); hipFree(m->s_tfE); m->s_gradT = m->s_tfE = nullptr;
+                return fail(PPDE_ERR_HIP, "device allocation failed for the transformer gradient rows");
+            }
+            m->s_tf_n = n;
         }
         t.gradT = m->s_gradT; t.tfE = m->s_tfE; t.tfw = m->s_tfw;
     }

@@ -130,8 +130,26 @@ static int tf_build_model(TfModel* t, int L, const ppde_tf_weights* w) {
     return PPDE_OK;
 }
 
-static int tf_alloc_work(const TfModel* t, TfWork* wk, int n) {
+// Activation bytes one chain keeps between the forward and the backward pass (every layer's input, q|k|v, post-attention
+// stream and fc1 pre-activation in fp16 + statistics), and the chains a workspace holds under the memory budget: the
+// reference bounds the same memory by evaluating 64 chains at a time (8 for transformer-L; energy.py:77, :113-127); here the
+// budget is PPDE_TF_WORK_GB (default 48 GiB of the 288: 256 chains of UBE4B on esm2_t30_150M take 9.3 GiB, on esm2_t33_650M
+// 20 GiB) and larger populations are evaluated in chunks of that many chains (tf_eval): same numbers, chain by chain.
+static size_t tf_bytes_per_chain(const TfModel* t) {
+    const size_t D = t->D, F = t->F, L = t->L, H = t->H;
+    const size_t per_layer = L * ((D + 3 * D + D + F) * sizeof(half_t) + 4 * sizeof(float)) + H * L * sizeof(float2);
+    const size_t shared = L * ((9 * D + 2 * F + 3 * TF_VOCAB_PAD) * sizeof(half_t) + (4 + 20) * sizeof(float));
+    return t->layers * per_layer + shared;
+}
+static int tf_chunk_cap(const TfModel* t) {
+    static const double gb = []() { const char* e = getenv("PPDE_TF_WORK_GB"); const double v = e ? atof(e) : 0.0; return v > 0.0 ? v : 48.0; }();
+    const double cap = gb * 1073741824.0 / (double)tf_bytes_per_chain(t);
+    return cap < 1.0 ? 1 : cap > 1048576.0 ? 1048576 : (int)cap;
+}
+
+static int tf_alloc_work(const TfModel* t, TfWork* wk, int n_chains) {
     const int D = t->D, F = t->F, L = t->L;
+    const int n = std::min(n_chains, tf_chunk_cap(t));               // larger populations go through in chunks (tf_eval)
     wk->n_cap = n;
     const int M = n * L, Mp = (M + 127) & ~127;
     wk->M_pad = Mp;
@@ -154,7 +172,12 @@ static int tf_alloc_work(const TfModel* t, TfWork* wk, int n) {
     A(&wk->gA, (size_t)Mp * D); A(&wk->gB, (size_t)Mp * D); A(&wk->dF, (size_t)Mp * F); A(&wk->dqkv, (size_t)Mp * 3 * D); A(&wk->tmpD, (size_t)Mp * D);
     A(&wk->meanf, (size_t)Mp); A(&wk->rstdf, (size_t)Mp); A(&wk->meanh, (size_t)Mp); A(&wk->rstdh, (size_t)Mp);
     A(&wk->gdirect, (size_t)Mp * 20);
-    if (!ok) return fail(PPDE_ERR_HIP, "device allocation failed for the transformer workspace");
+    if (!ok) {
+        char msg[256];
+        snprintf(msg, sizeof(msg), "device allocation failed for the transformer workspace (%d chains x %.1f MiB of activations; "
+                 "PPDE_TF_WORK_GB lowers the chunk evaluated at a time)", n, (double)tf_bytes_per_chain(t) / 1048576.0);
+        return fail(PPDE_ERR_HIP, msg);
+    }
     return PPDE_OK;
 }
 
@@ -225,7 +248,7 @@ static thread_local TfEventList* g_tf_fc1_events = nullptr;
 
 // One evaluation: scores of n chains (state rows) into score_out [n], and, when grad_out is not NULL, the gradient of
 // the scores w.r.t. the Potts one-hot input into grad_out rows [n][L*20] (fp32).
-static int tf_eval(const TfModel* t, TfWork* wk, const uint8_t* rows, int Ls, int sh, int n, float* score_out, float* grad_out, hipStream_t s) {
+static int tf_eval_chunk(const TfModel* t, TfWork* wk, const uint8_t* rows, int Ls, int sh, int n, float* score_out, float* grad_out, hipStream_t s) {
     ARGCHK(n <= wk->n_cap, "transformer workspace too small for this batch");
     const int D = t->D, F = t->F, L = t->L, H = t->H, M = n * L, Mp = (M + 127) & ~127;
     const float qs = 1.0f / sqrtf((float)t->HD);
@@ -294,5 +317,17 @@ static int tf_eval(const TfModel* t, TfWork* wk, const uint8_t* rows, int Ls, in
     TFRC(tf_gemm<TF_EPI_PLAIN>(s, wk->gA, t->E16, wk->G33, Mp, TF_VOCAB_PAD, D));
     hipLaunchKernelGGL(tf_finish_grad, dim3((M * 20 + 255) / 256), dim3(256), 0, s, wk->G33, wk->gdirect, t->perm, M, grad_out, 0);
     HIPCHK(hipGetLastError());
+    return PPDE_OK;
+}
+
+// n chains through a workspace of wk->n_cap chains: chunk after chunk on the same stream (the reference's minibatch loop,
+// energy.py:113-127). A chain's numbers do not depend on the chunk it sits in (tested), so this is what one pass would give.
+static int tf_eval(const TfModel* t, TfWork* wk, const uint8_t* rows, int Ls, int sh, int n, float* score_out, float* grad_out, hipStream_t s) {
+    ARGCHK(wk->n_cap >= 1, "no transformer workspace");
+    for (int b0 = 0; b0 < n; b0 += wk->n_cap) {
+        const int nb = std::min(wk->n_cap, n - b0);
+        TFRC(tf_eval_chunk(t, wk, rows + (size_t)b0 * Ls, Ls, sh, nb, score_out + b0,
+                           grad_out ? grad_out + (size_t)b0 * t->L * 20 : nullptr, s));
+    }
     return PPDE_OK;
 }

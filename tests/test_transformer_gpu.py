@@ -291,6 +291,49 @@ def test_tfpoe_ube4b_150m_shapes_vs_combined_oracle():
     assert float(e[0]) == lam * float(fit[0])                   # wild type: Delta score exactly 0
 
 
+_CHUNKED = r"""
+import sys
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[1] + "/tests"); sys.path.insert(0, sys.argv[1] + "/oracle")
+import numpy as np, torch
+from test_transformer_gpu import _model
+from ppde_amd.sampler import Chains
+m, wt, st, cnn = _model(24, 2, 128, 4, 256, with_cnn=True)
+m.set_lamda(2.0)
+idx = np.random.default_rng(4).integers(0, 20, (13, 24)).astype(np.uint8)
+e, f, g = m.energy_grad(torch.as_tensor(idx).cuda(), 6)
+ch = Chains(m, 13, 8, 2, 3, False, 0, 23, 6, 1, random_chain=0, seed=5)
+ch.init(torch.as_tensor(np.tile(wt, (13, 1))).cuda()); ch.run(8)
+np.savez(sys.argv[2], e=e.cpu().numpy(), g=g.cpu().numpy(), eh=ch.collect()["energy_history"])
+"""
+
+
+def test_populations_beyond_the_workspace_budget_run_in_chunks():
+    """The reference bounds the transformer's activation memory by minibatching (64 chains, energy.py:77, :113-127); here a
+    workspace holds as many chains as PPDE_TF_WORK_GB allows and larger populations go through chunk by chunk. A child
+    process with a 1 MiB budget (5 toy chains per chunk: 13 chains = 5 + 5 + 3) gives the bits of the one-pass evaluation."""
+    import subprocess
+    import sys
+    from ppde_amd.sampler import Chains
+    REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with tempfile.TemporaryDirectory() as d:
+        out = os.path.join(d, "chunked.npz")
+        script = os.path.join(d, "chunked.py")
+        open(script, "w").write(_CHUNKED)
+        r = subprocess.run([sys.executable, script, REPO, out], capture_output=True, text=True, timeout=300,
+                           env=dict(os.environ, PPDE_TF_WORK_GB="0.001"))
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+        got = np.load(out)
+    m, wt, st, cnn = _model(24, 2, 128, 4, 256, with_cnn=True)
+    m.set_lamda(2.0)
+    idx = np.random.default_rng(4).integers(0, 20, (13, 24)).astype(np.uint8)
+    e, f, g = m.energy_grad(torch.as_tensor(idx).cuda(), 6)
+    ch = Chains(m, 13, 8, 2, 3, False, 0, 23, 6, 1, random_chain=0, seed=5)
+    ch.init(torch.as_tensor(np.tile(wt, (13, 1))).cuda())
+    ch.run(8)
+    assert np.array_equal(got["e"], e.cpu().numpy()) and np.array_equal(got["g"], g.cpu().numpy())
+    assert np.array_equal(got["eh"], ch.collect()["energy_history"])
+
+
 def test_reference_style_energy_object_with_a_checkpoint_file():
     """ProteinProductOfExperts(args) with --unsupervised_expert transformer: weights from a checkpoint file in the
     published format (the reference downloads it into --hub_dir)."""
