@@ -456,18 +456,13 @@ __device__ __forceinline__ void race_variates(const PasArgs& a, int b, int it, i
         }
     }
 }
-// Path length and the first sub-steps' variates: issued at kernel entry, behind the row's global loads. On the device RNG
-// the variates of sub-steps 1 and 2 are drawn here too (when the path is that long): a Philox call + four logarithms per
-// thread is ~40 % of a sub-step's vector instructions (the 32-bit multiplies are quarter rate), and the ~1 us the row
-// takes to arrive is otherwise idle; inside the loop they sat on the critical path (stamps: 1.24 us for the race phase of
-// a sub-step that draws the next variates, 0.76 us for one that does not).
-#define PAS_QPRE 3
+// Path length and first sub-step's variates: issued at kernel entry, behind the row's global loads
 template <int GPT>
 struct ProposePrefetch {
     int Ub;
     int Uraw;                   // path length as drawn / supplied, before the clamp
     int dist;                   // mutation count of the current state (from the chain record)
-    float4 q0[GPT], q1[GPT], q2[GPT];
+    float4 q0[GPT];
 };
 template <int GPT>
 __device__ __forceinline__ ProposePrefetch<GPT> propose_prefetch(const PasArgs& a, int b, int it) {
@@ -478,11 +473,6 @@ __device__ __forceinline__ ProposePrefetch<GPT> propose_prefetch(const PasArgs& 
     p.Ub = min(max(p.Ub, 1), min(a.mu_max, a.mu_cap));
     p.dist = rec_of(a, b + opaque_zero())->dist_cur;
     race_variates<GPT>(a, b, it, 0, p.q0);
-    if (a.rng_mode != 0) {                              // (caller-supplied noise: the later rows are loaded inside the loop)
-        const int Ub = __builtin_amdgcn_readfirstlane(p.Ub);
-        if (Ub > 1) race_variates<GPT>(a, b, it, 1, p.q1);
-        if (Ub > 2) race_variates<GPT>(a, b, it, 2, p.q2);
-    }
     return p;
 }
 
@@ -521,10 +511,9 @@ __device__ __forceinline__ void propose_body(const PasArgs& a, const RowLds& lds
             if (tid == 0) flag_error(a.err_flag, 1);
             m = 0.f; S1 = 1.f;
         }
-        // next sub-step's race variates (state independent): drawn at kernel entry for sub-steps < PAS_QPRE on the device
-        // RNG, here otherwise (the Philox + log chains then overlap with pass 2)
+        // next sub-step's race variates: state independent, so the Philox + log chains overlap with pass 2
         float4 qn[GPT];
-        if (s + 1 < Ub && (exact_race || s + 1 >= PAS_QPRE)) race_variates<GPT>(a, b, it, s + 1, qn);
+        if (s + 1 < Ub) race_variates<GPT>(a, b, it, s + 1, qn);
         // ---- softmax -> clamp (ppde/utils.py:106-111): p = clamp(exp(z - m) / S1), exp(z - m) = e * exp(m_w - m); the
         //      exponential race arg-max of p / q (torch.multinomial) and the clamped row sum S3 in one pass + one
         //      barrier. Each thread keeps its best entry (value, flat index, probability; strict > in index order: the
@@ -618,9 +607,8 @@ __device__ __forceinline__ void propose_body(const PasArgs& a, const RowLds& lds
             if (a.tr_flat) a.tr_flat[((size_t)it * a.mu_max + s) * a.n + b] = win;
         }
         if (s + 1 < Ub) {
-            const bool pre = !exact_race && s + 1 < PAS_QPRE;
 #pragma unroll
-            for (int r = 0; r < GPT; ++r) q[r] = pre ? (s == 0 ? pp.q1[r] : pp.q2[r]) : qn[r];
+            for (int r = 0; r < GPT; ++r) q[r] = qn[r];
         }
         PPDE_STAMP(a.dbg, 13 + 4 * min(s, 1), stamp);
     }
