@@ -166,10 +166,13 @@ struct EvalTargets {
     TfWork* tfw = nullptr;
 };
 
-// chain groups (of 64) per Potts workgroup. Measured with this round's kernel (scripts/tune_potts.py, random states):
-// 128 chains: 1 group 5.08 us, 2 groups 4.66, 4 groups 5.63; 256 chains: 7.11 / 5.96 / 6.04. Beyond that (round 1's
-// kernel, 512 / 1024 chains): 4 groups 11.3 / 18.7 us, 2 groups 11.4 / 17.7.
-static int potts_ng_for(int n) { return n <= 64 ? 1 : n <= 256 ? 2 : 4; }
+// chain groups (of 64) per Potts workgroup. Measured with this round's kernel (scripts/tune_potts.py, us per launch, wild-type /
+// random states): 128 chains: 1 group 5.08, 2 groups 4.66, 4 groups 5.63; 512 chains: 8.7 / 7.8 / 9.0; 1024: 13.0 / 12.1 / 13.8;
+// 2048: 21.8 / 20.3 / 22.9 (random states +1 to +3 us). Beyond ~512 chains the kernel is bound by the gather itself, not by
+// the stream: 80 rows x 16 B per chain and tile are 524 MB of LDS reads per launch at 1024 chains (6.7 us at the chip's
+// 128 B/clk/CU) next to 5 vector instructions per row (8.4 us); walking several chain blocks per workgroup on one resident
+// slab (one stream of the couplings per tile instead of one per block) was built and measured equal (13.8 us at 1024).
+static int potts_ng_for(int n) { return n <= 64 ? 1 : 2; }
 
 
 // When set, every Potts launch is bracketed by a pair of events taken from this pool (in-situ timing).
