@@ -90,6 +90,13 @@ __device__ __forceinline__ void tf_glds16(const void* sbase, uint32_t voff, uint
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff), "s"(sbase), "s"(lds_base) : "memory");
 }
 
+// a pointer every lane agrees on, as a value the compiler KNOWS to be wave-uniform (an "s" asm operand must live in SGPRs)
+__device__ __forceinline__ const half_t* tf_uniform(const half_t* p) {
+    const uint64_t v = (uint64_t)(uintptr_t)p;
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+    return (const half_t*)(uintptr_t)(((uint64_t)hi << 32) | lo);
+}
+
 // BK = k depth of one staged tile (32 or 64 halfs), STAGES = LDS buffers (prefetch distance STAGES - 1).
 template <int BK, int STAGES>
 __host__ __device__ constexpr size_t tf_gemm_lds() {
@@ -289,6 +296,293 @@ __global__ __launch_bounds__(64 * NWAVE, 2) void tf_gemm_nt(TfGemmArgs g) {
     }
     flush(g.C, NT_OUT);
     __syncthreads();                                                  // the staged tile has been read: the next tile may overwrite it
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// The same product on 256 x TN tiles (TN = 256 or 128), one 8-wave workgroup per CU (waves 4 x 2, each 64 x TN/2).
+//
+// Why larger tiles: the k loop of the 128 x 128 kernel is bound by the L2 -> LDS fill, not by the matrix pipe. A
+// 128 x 128 x 64 step moves 32 KB for 2.1 MFLOP (64 flop/B) and the kernel levels off at 0.85-0.89 PFLOP/s whatever the
+// epilogue, even at K = 2560 where the epilogue is amortised over 40 steps. A 256 x 256 step moves 64 KB for 8.4 MFLOP
+// (128 flop/B): measured with the epilogue switched off, this kernel's k loop runs at 1.7-1.9 PFLOP/s.
+//
+// Why wave roles: with one workgroup per CU nothing else hides the epilogue, and on gfx950 stores count in the same
+// in-order vmcnt queue as loads and LDS-DMA: a wave that has stored its part of tile i cannot wait for the first operands
+// of tile i + 1 without also waiting for those stores to be ACKNOWLEDGED (microseconds under write pressure; the first
+// version of this kernel lost everything the k loop had gained there: 108 us against 46 us without the epilogue at
+// N = 2560, K = 640). So the vector-memory work is split by wave: waves 0-3 ("loaders") issue every LDS-DMA and every
+// global load (operands, the next tile's first operands during the epilogue, the epilogue's second operand, the bias),
+// waves 4-7 ("storers") issue every global store and never wait on vmcnt: their stores drain while the next tile's k loop
+// runs. All eight waves do the MFMAs and the epilogue arithmetic; hand-overs go through LDS and s_barrier.
+//
+// Epilogues without a second input (bias, q scaling, GELU, plain): the next tile's first operands are requested into
+// stage 0 before the arithmetic, the output leaves through the two stage-1 buffers, 128 rows per round. Epilogues with a
+// second input (residual, GELU'): that [256 x TN] tile is fetched by LDS-DMA into the (then free) operand buffers, combined
+// IN PLACE by the lane that owns each element in the accumulator layout, and stored from there; no priming (no LDS left).
+// Staged rows are TN halfs apart (a multiple of 64 banks): the 16-byte chunk index is XOR-ed with the row (mod 16), which
+// spreads accumulator-layout accesses (16 rows x 8 bytes) and row-wise accesses (16 chunks of a row) over all banks.
+// Requirements (the host pads / dispatches): M % 256 == 0, N % TN == 0, K % 128 == 0 (an even number of k steps).
+//
+// STATUS: opt-in (PPDE_TF_BIG=1), not the default. Measured (in-kernel cycle stamps): one tile of the
+// fc1 shape takes ~27 000 cycles in the k loop (2 700 per k step against 2 048 of MFMAs: 76 % of the pipe) plus ~9 000 in the
+// plain epilogue (two LDS rounds of ~3 700) at a clock of ~1.8 GHz under this load; over a whole GEMM that is level with the
+// 128 x 128 kernel at N = 2560 (105 / 150 us plain / GELU against 105 / 149) and behind it at N = 1920 and N = 640, and a
+// full evaluation takes 35.0 ms with it against 32.2 ms. Same k order per output element: the bits equal the 128 x 128 kernel's.
+// ------------------------------------------------------------------------------------------------------------
+template <int TN>
+__host__ __device__ constexpr size_t tf_gemm_big_lds() { return (size_t)2 * (256 + TN) * 64 * 2 + TN * 4; }   // operands + the tile's bias
+
+// workgroup barrier that orders LDS accesses only: __syncthreads() also drains the vector-memory queue (vmcnt(0)), i.e. it
+// would make the storer waves wait for every output store to be acknowledged
+__device__ __forceinline__ void tf_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+template <int EPI, int TN>
+__global__ __launch_bounds__(512, 1) void tf_gemm_big(TfGemmArgs g) {
+    static_assert(TN == 256 || TN == 128, "column tile");
+    constexpr int BK = 64, TM = 256;
+    constexpr int NJ = TN / 32;                      // 16-column tiles per wave (a wave owns 64 rows x TN/2 columns)
+    constexpr int TILE_A = TM * BK, TILE_B = TN * BK; // halfs per staged operand tile
+    constexpr int PA = (TM / 8) / 4, PB = (TN / 8) / 4;   // 1-KiB DMA pieces (8 rows of 128 B) per LOADER wave and k step
+    constexpr bool HAS_R = EPI == TF_EPI_BIAS_RESID || EPI == TF_EPI_GELU_BWD;
+    constexpr bool HAS_BIAS = EPI != TF_EPI_PLAIN && EPI != TF_EPI_GELU_BWD;
+    extern __shared__ __attribute__((aligned(16))) unsigned char tf_smem[];
+    half_t* sA = (half_t*)tf_smem;                   // [2][256][64]
+    half_t* sB = sA + 2 * TILE_A;                    // [2][TN][64]
+    float* sBias = (float*)(sB + 2 * TILE_B);        // [TN]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool loader = wave < 4;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int tiles_n = g.N / TN, tiles_total = (g.M >> 8) * tiles_n;
+    const int K = g.K, nk = K / BK;
+    const int lr = lane >> 3, lc = lane & 7;
+    uint32_t voffA[PA], voffB[PB];                   // per-lane source offsets, 16-byte chunk XOR-swizzled by the row (as tf_gemm_nt)
+#pragma unroll
+    for (int i = 0; i < PA; ++i) { const int r = ((wave & 3) * PA + i) * 8 + lr; voffA[i] = (uint32_t)r * (uint32_t)(K * 2) + (uint32_t)((lc ^ (r & 7)) << 4); }
+#pragma unroll
+    for (int i = 0; i < PB; ++i) { const int r = ((wave & 3) * PB + i) * 8 + lr; voffB[i] = (uint32_t)r * (uint32_t)(K * 2) + (uint32_t)((lc ^ (r & 7)) << 4); }
+    const int fr = lane & 15, fg = lane >> 4;
+    // persistent: XCD x (= workgroup id mod 8) owns a contiguous run of tiles in N-fastest order (one 256-row panel of A
+    // serves its column tiles from one L2), its workgroups take the run's tiles in turn
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, wpx = gridDim.x >> 3;
+    const int xq = tiles_total >> 3, xr = tiles_total & 7;
+    const int xbeg = xcd * xq + min(xcd, xr), xcnt = xq + (xcd < xr ? 1 : 0);
+    auto stage = [&](int buf, const half_t* ka_, const half_t* kb_) {   // loader waves only
+        const half_t* ka = tf_uniform(ka_);
+        const half_t* kb = tf_uniform(kb_);
+#pragma unroll
+        for (int i = 0; i < PA; ++i) tf_glds16(ka, voffA[i], (uint32_t)(uintptr_t)(sA + buf * TILE_A + (wave * PA + i) * 512));
+#pragma unroll
+        for (int i = 0; i < PB; ++i) tf_glds16(kb, voffB[i], (uint32_t)(uintptr_t)(sB + buf * TILE_B + (wave * PB + i) * 512));
+    };
+    auto tile_bases = [&](int ti, const half_t*& bA, const half_t*& bB, int& m0, int& n0) {
+        const int v = xbeg + ti;
+        m0 = (v / tiles_n) << 8; n0 = (v % tiles_n) * TN;
+        bA = g.A + (size_t)m0 * K; bB = g.B + (size_t)n0 * K;
+    };
+    // staged output / second-operand tile: element (row, col) of a [rows][TN] image at `base`
+    auto qat = [&](half_t* base, int row, int col) { return base + row * TN + ((((col >> 3) ^ (row & 15))) << 3) + (col & 7); };
+    constexpr int CPR = TN / 8;                                       // 16-byte chunks per output row
+    bool primed = false;                             // the current tile's first operands were requested during the previous epilogue
+    for (int ti = slot; ti < xcnt; ti += wpx) {
+    const half_t *baseA, *baseB;
+    int m0, n0;
+    tile_bases(ti, baseA, baseB, m0, n0);
+    tf_f32x4 acc[4][NJ];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) acc[i][j] = (tf_f32x4){0.f, 0.f, 0.f, 0.f};
+    // The MFMAs of a k step run as four units of 4 x NJ/2 tiles: (half step 0 | 1) x (left | right half of the wave's columns).
+    // While a unit's MFMAs run, the LDS reads of the NEXT unit's operands are in flight (two register sets each for the A and
+    // the B fragments, 64 VGPRs in all; whole half steps in two sets would be 96 and spill next to 128 accumulators).
+    // Why: all eight waves leave the k step's barrier together; without this they all read (192 KB per k step through the CU's
+    // 128 B/clk LDS port) and then all multiply, and the k loop took the SUM, ~3600 cycles per step against 2048 of MFMAs.
+    constexpr int NH = NJ / 2;
+    f16x8 fa[2][4], fb[2][NH];
+    auto ldA = [&](int set, int buf, int sh) {
+        const half_t* a = sA + buf * TILE_A + (wm * 64 + fr) * BK;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) fa[set][i] = *(const f16x8*)(a + i * 16 * BK + (((sh * 4 + fg) ^ (fr & 7)) << 3));
+    };
+    auto ldB = [&](int set, int buf, int sh, int gh) {
+        const half_t* b = sB + buf * TILE_B + (wn * (TN / 2) + gh * (TN / 4) + fr) * BK;
+#pragma unroll
+        for (int j = 0; j < NH; ++j) fb[set][j] = *(const f16x8*)(b + j * 16 * BK + (((sh * 4 + fg) ^ (fr & 7)) << 3));
+    };
+    auto mfmas = [&](int aset, int bset, int gh) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < NH; ++j)
+                acc[i][gh * NH + j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[bset][j], fa[aset][i], acc[i][gh * NH + j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    if (loader) {
+        if (!primed) stage(0, baseA, baseB);
+        if constexpr (HAS_BIAS) {                                     // the tile's bias row -> LDS (visible behind the first barrier)
+            if (tid < TN / 4) ((float4*)sBias)[tid] = *(const float4*)(g.bias + n0 + 4 * tid);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // k tile 0 has landed (the storers never wait on vmcnt)
+    }
+    tf_lds_barrier();
+    if (loader && nk > 1) stage(1, baseA + BK, baseB + BK);
+    ldA(0, 0, 0); ldB(0, 0, 0, 0);
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        ldB(1, buf, 0, 1); __builtin_amdgcn_sched_barrier(0);
+        mfmas(0, 0, 0);
+        ldA(1, buf, 1); ldB(0, buf, 1, 0); __builtin_amdgcn_sched_barrier(0);
+        mfmas(0, 1, 1);
+        ldB(1, buf, 1, 1); __builtin_amdgcn_sched_barrier(0);
+        mfmas(1, 0, 0);
+        if (kt + 1 < nk) {
+            if (loader) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // k tile kt + 1 has landed ...
+            tf_lds_barrier();                                         // ... for every wave, and every wave holds the rest of k tile kt in registers
+            if (loader && kt + 2 < nk) stage(buf, baseA + (size_t)(kt + 2) * BK, baseB + (size_t)(kt + 2) * BK);
+            ldA(0, buf ^ 1, 0); ldB(0, buf ^ 1, 0, 0); __builtin_amdgcn_sched_barrier(0);
+        }
+        mfmas(1, 1, 1);
+    }
+    tf_lds_barrier();                                                 // every wave is done with the operand tiles
+    primed = false;
+    // lane indices of the epilogue behind a zero the compiler cannot see through: its address arithmetic is invariant over the
+    // persistent tile loop and would otherwise be hoisted above the k loop, where it costs spills next to 128 accumulators
+    const int oz = opaque_zero();
+    const int fre = fr + oz, fge = fg + oz, tide = tid + oz;
+    constexpr bool NT_OUT = EPI == TF_EPI_BIAS_GELU || EPI == TF_EPI_BIAS_QSCALE;
+    if constexpr (!HAS_R) {
+        // ---- no second input. nk is even: the last k step used stage 1, stage 0 is free -> the next tile's first operands
+        //      land there while the arithmetic runs and the output leaves through the two stage-1 buffers
+        if (ti + wpx < xcnt) {
+            if (loader) {
+                const half_t *nA, *nB;
+                int nm0, nn0;
+                tile_bases(ti + wpx, nA, nB, nm0, nn0);
+                stage(0, nA, nB);
+            }
+            primed = true;
+        }
+        // results packed IN PLACE into the accumulator registers (two halfs per float: [0], [1] = the output, [2], [3] = the
+        // activation of the GELU epilogue): no second register array next to 128 accumulators
+        auto pack2 = [](half_t a, half_t b) { f16x2 p; p[0] = a; p[1] = b; return __builtin_bit_cast(float, p); };
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const int nl = wn * (TN / 2) + j * 16 + 4 * fge;
+                const float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+                half_t o[4];
+                if constexpr (EPI == TF_EPI_PLAIN) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o[r] = (half_t)v[r];
+                } else {
+                    const float4 b4 = *(const float4*)(sBias + nl);
+                    const float bb[4] = {b4.x, b4.y, b4.z, b4.w};
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o[r] = (half_t)(v[r] + bb[r]);
+                    if constexpr (EPI == TF_EPI_BIAS_QSCALE) {
+                        if (n0 + nl < g.qcols) {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) o[r] = (half_t)((float)o[r] * g.alpha);
+                        }
+                    } else if constexpr (EPI == TF_EPI_BIAS_GELU) {
+                        half_t a4[4];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) a4[r] = (half_t)tf_gelu((float)o[r]);
+                        acc[i][j][2] = pack2(a4[0], a4[1]); acc[i][j][3] = pack2(a4[2], a4[3]);
+                    }
+                }
+                acc[i][j][0] = pack2(o[0], o[1]); acc[i][j][1] = pack2(o[2], o[3]);
+            }
+        }
+        // quarter slots: TN = 256: stage 1 of A and stage 1 of B (32 KB each); TN = 128: the two halves of stage 1 of A
+        half_t* Q0 = sA + TILE_A;
+        half_t* Q1 = TN == 256 ? sB + TILE_B : sA + TILE_A + 64 * TN;
+        constexpr int FCH = 128 * CPR / 256;                          // chunks of a 128-row round per storer thread
+        auto round_out = [&](const int which, half_t* dst, int rd) {  // which: 0 = the output, 1 = the GELU activation
+            if ((wm >> 1) == rd) {                                    // the four waves that own rows [128 rd, 128 rd + 128)
+                half_t* Q = (wm & 1) ? Q1 : Q0;
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j)
+                        *(float2*)qat(Q, i * 16 + fre, wn * (TN / 2) + j * 16 + 4 * fge) = make_float2(acc[i][j][2 * which], acc[i][j][2 * which + 1]);
+            }
+            tf_lds_barrier();
+            if (!loader) {
+                const int st = tide - 256;
+#pragma unroll
+                for (int u = 0; u < FCH; ++u) {
+                    const int c = st + u * 256, row = c / CPR, ch = c % CPR;          // row 0..127 of the round
+                    const f16x8 val8 = *(const f16x8*)qat(row < 64 ? Q0 : Q1, row & 63, ch * 8);
+                    f16x8* gp = (f16x8*)(dst + (size_t)(m0 + 128 * rd + row) * g.N + n0 + ch * 8);
+                    if (NT_OUT) __builtin_nontemporal_store(val8, gp);
+                    else *gp = val8;
+                }
+            }
+            tf_lds_barrier();                                         // the slots have been read: the next round may overwrite them
+        };
+        if constexpr (EPI == TF_EPI_BIAS_GELU) {
+            round_out(0, g.C2, 0); round_out(0, g.C2, 1);             // the pre-activation (read again only by the backward)
+            round_out(1, g.C, 0); round_out(1, g.C, 1);
+        } else {
+            round_out(0, g.C, 0); round_out(0, g.C, 1);
+        }
+    } else {
+        // ---- second input (residual / pre-activation): its tile comes by LDS-DMA into the operand buffers (free now), 1 KiB
+        //      per instruction, the SOURCE chunk permuted so that the image is XOR-swizzled; combined in place; stored from there
+        half_t* sT = sA;                                              // [256][TN] image (TN = 256: all 128 KB of operand LDS)
+        if (loader) {
+            constexpr int RPP = 1024 / (TN * 2);                      // rows per 1-KiB piece (2 or 4)
+            constexpr int NP = 256 / RPP / 4;                         // pieces per loader wave (32 or 16)
+            const int prow = lane / CPR, pch = lane % CPR;            // row within the piece, physical chunk
+#pragma unroll 2
+            for (int u = 0; u < NP; ++u) {                            // (rolled: 32 address pairs at once would spill)
+                const int piece = wave * NP + u, row = piece * RPP + prow;
+                const half_t* src = g.R + (size_t)(m0 + row) * g.N + n0 + ((pch ^ (row & 15)) << 3);
+                asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(src), "s"((uint32_t)(uintptr_t)(sT + piece * 512)) : "memory");
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        tf_lds_barrier();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const int nl = wn * (TN / 2) + j * 16 + 4 * fge;
+                half_t* at = qat(sT, wm * 64 + i * 16 + fre, nl);
+                const f16x4 rv = *(const f16x4*)at;
+                const float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+                f16x4 o;
+                if constexpr (EPI == TF_EPI_GELU_BWD) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o[r] = (half_t)((float)(half_t)v[r] * tf_gelu_grad((float)rv[r]));
+                } else {
+                    const float4 b4 = *(const float4*)(sBias + nl);
+                    const float bb[4] = {b4.x, b4.y, b4.z, b4.w};
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o[r] = (half_t)((float)(half_t)(v[r] + bb[r]) + (float)rv[r]);
+                }
+                *(f16x4*)at = o;
+            }
+        }
+        tf_lds_barrier();
+        if (!loader) {
+            const int st = tide - 256;
+            constexpr int FCH = 256 * CPR / 256;
+#pragma unroll 8
+            for (int u = 0; u < FCH; ++u) {
+                const int c = st + u * 256, row = c / CPR, ch = c % CPR;
+                const f16x8 val8 = *(const f16x8*)qat(sT, row, ch * 8);
+                f16x8* gp = (f16x8*)(g.C + (size_t)(m0 + row) * g.N + n0 + ch * 8);
+                if (NT_OUT) __builtin_nontemporal_store(val8, gp);
+                else *gp = val8;
+            }
+        }
+        tf_lds_barrier();                                             // the image has been read: the next tile's operands may land
+    }
     }
 }
 

@@ -151,7 +151,7 @@ static int tf_alloc_work(const TfModel* t, TfWork* wk, int n_chains) {
     const int D = t->D, F = t->F, L = t->L;
     const int n = std::min(n_chains, tf_chunk_cap(t));               // larger populations go through in chunks (tf_eval)
     wk->n_cap = n;
-    const int M = n * L, Mp = (M + 127) & ~127;
+    const int M = n * L, Mp = (M + 255) & ~255;                        // (whole 256-row GEMM tiles)
     wk->M_pad = Mp;
     bool ok = true;
     auto A = [&](auto** p, size_t count) {
@@ -187,6 +187,22 @@ static int tf_gemm(hipStream_t s, const half_t* A, const half_t* B, half_t* C, i
                    const half_t* R = nullptr, half_t* C2 = nullptr, float alpha = 1.f, int qcols = 0) {
     ARGCHK(M % 128 == 0 && N % 128 == 0 && K % 64 == 0, "transformer GEMM shape is not a multiple of the 128 x 128 x 64 tile");
     TfGemmArgs g{A, B, C, bias, R, C2, M, N, K, alpha, qcols};
+    // 256-row tiles (tf_gemm_big): one 8-wave workgroup per CU, half (TN = 256) or three quarters (TN = 128) of the L2 -> LDS
+    // traffic per flop of the 128 x 128 kernel. Opt-in tuning knob (measured level with or behind the 128 x 128 kernel, tf.h):
+    // PPDE_TF_BIG=1 uses it wherever the shape allows, =256 / =128 only with that column tile. Same bits either way.
+    static const int big = []() { const char* e = getenv("PPDE_TF_BIG"); return e ? atoi(e) : 0; }();
+    if (big && M % 256 == 0 && K % 128 == 0 && N >= 256) {
+        const bool wide = N % 256 == 0 && big != 128, narrow = N % 128 == 0 && big != 256;
+        if (wide || narrow) {
+            const int TN = wide ? 256 : 128;
+            const int tiles = (M >> 8) * (N / TN), tiles8 = (tiles + 7) & ~7;
+            const dim3 grid(std::min(tiles8, 256));
+            if (wide) hipLaunchKernelGGL((tf_gemm_big<EPI, 256>), grid, dim3(512), tf_gemm_big_lds<256>(), s, g);
+            else hipLaunchKernelGGL((tf_gemm_big<EPI, 128>), grid, dim3(512), tf_gemm_big_lds<128>(), s, g);
+            HIPCHK(hipGetLastError());
+            return PPDE_OK;
+        }
+    }
     // staged k depth x LDS buffers (tuning knob PPDE_TF_GEMM=64x2|64x3|32x2|32x3|32x4|64x2w8|32x3w8; default: the measured optimum)
     static const int variant = []() {
         const char* e = getenv("PPDE_TF_GEMM");
@@ -250,7 +266,7 @@ static thread_local TfEventList* g_tf_fc1_events = nullptr;
 // the scores w.r.t. the Potts one-hot input into grad_out rows [n][L*20] (fp32).
 static int tf_eval_chunk(const TfModel* t, TfWork* wk, const uint8_t* rows, int Ls, int sh, int n, float* score_out, float* grad_out, hipStream_t s) {
     ARGCHK(n <= wk->n_cap, "transformer workspace too small for this batch");
-    const int D = t->D, F = t->F, L = t->L, H = t->H, M = n * L, Mp = (M + 127) & ~127;
+    const int D = t->D, F = t->F, L = t->L, H = t->H, M = n * L, Mp = (M + 255) & ~255;
     const float qs = 1.0f / sqrtf((float)t->HD);
     hipLaunchKernelGGL(tf_embed, dim3(M), dim3(128), 0, s, rows, Ls, sh, L, n, t->perm, t->E16, D, wk->act[0].xin);
     HIPCHK(hipGetLastError());

@@ -9,6 +9,8 @@ import sys
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
 SHAPES = [(26624, 1920, 640), (26624, 640, 640), (26624, 2560, 640), (26624, 640, 2560), (26624, 640, 1920)]
+if os.environ.get('TF_TUNE_SHAPES'):
+    SHAPES = [tuple(int(x) for x in t.split('x')) for t in os.environ['TF_TUNE_SHAPES'].split(',')]
 if os.environ.get("TF_TUNE_CHILD"):
     from ppde_amd import _hip
     lib = _hip.load()
@@ -16,10 +18,12 @@ if os.environ.get("TF_TUNE_CHILD"):
         for epi, name in ((5, "plain"), (2, "bias+resid"), (3, "bias+gelu"), (4, "gelu'")):
             us = C.c_float()
             _hip.check(lib.ppde_transformer_time_gemm(0, M, N, K, 30, epi, C.byref(us)))
-            print(f"{os.environ.get('PPDE_TF_GEMM', 'default'):8s} M={M} N={N:5d} K={K:5d} {name:10s}: {us.value:8.1f} us  {2.0 * M * N * K / us.value / 1e6:7.1f} TFLOP/s", flush=True)
+            print(f"{os.environ.get('PPDE_TF_GEMM', 'default'):8s} big={os.environ.get('PPDE_TF_BIG', '1')} M={M} N={N:5d} K={K:5d} {name:10s}: {us.value:8.1f} us  {2.0 * M * N * K / us.value / 1e6:7.1f} TFLOP/s", flush=True)
     sys.exit(0)
-for v in (sys.argv[1:] or ("64x2", "64x3", "32x2", "32x3", "32x4", "64x2w8", "32x3w8")):
-    r = subprocess.run([sys.executable, os.path.abspath(__file__)], env=dict(os.environ, TF_TUNE_CHILD="1", PPDE_TF_GEMM=v), capture_output=True, text=True)
+# variants: "64x2" ... = the 128 x 128 kernel's staging (PPDE_TF_BIG=0); "big" = 256-row tiles where the shape allows (default)
+for v in (sys.argv[1:] or ("big", "64x2", "64x3", "32x2", "32x3", "32x4", "64x2w8", "32x3w8")):
+    env = dict(os.environ, TF_TUNE_CHILD="1", PPDE_TF_BIG="1") if v == "big" else dict(os.environ, TF_TUNE_CHILD="1", PPDE_TF_GEMM=v, PPDE_TF_BIG="0")
+    r = subprocess.run([sys.executable, os.path.abspath(__file__)], env=env, capture_output=True, text=True)
     sys.stdout.write(r.stdout)
     if r.returncode:
         sys.stdout.write(r.stderr[-1500:])

@@ -334,6 +334,42 @@ def test_populations_beyond_the_workspace_budget_run_in_chunks():
     assert np.array_equal(got["eh"], ch.collect()["energy_history"])
 
 
+_BIG_TILES = r"""
+import sys
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[1] + "/tests"); sys.path.insert(0, sys.argv[1] + "/oracle")
+import numpy as np, torch
+from test_transformer_gpu import _model
+out = {}
+for tag, (L, layers, dim, heads, ffn, n) in dict(toy=(24, 2, 128, 4, 256, 13), wide=(104, 2, 640, 20, 2560, 6)).items():
+    m, wt, st, _ = _model(L, layers, dim, heads, ffn)
+    idx = np.random.default_rng(4).integers(0, 20, (n, L)).astype(np.uint8)
+    e, f, g = m.energy_grad(torch.as_tensor(idx).cuda(), 4)
+    out[tag + "_e"], out[tag + "_g"] = e.cpu().numpy(), g.cpu().numpy()
+np.savez(sys.argv[2], **out)
+"""
+
+
+def test_opt_in_256_row_gemm_tiles_give_the_same_bits():
+    """PPDE_TF_BIG=1 routes every GEMM whose shape allows it through tf_gemm_big (256 x 256 / 256 x 128 tiles, loader /
+    storer wave roles, all six epilogues): the k order per output element is that of the default 128 x 128 kernel, so scores
+    and gradients are bit-identical (toy shapes and one layer pair at the 150M widths: N = 1920, 640, 2560; K = 640, 2560)."""
+    import subprocess
+    import sys
+    REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    with tempfile.TemporaryDirectory() as d:
+        script = os.path.join(d, "big.py")
+        open(script, "w").write(_BIG_TILES)
+        for big in ("0", "1"):
+            out = os.path.join(d, f"big{big}.npz")
+            r = subprocess.run([sys.executable, script, REPO, out], capture_output=True, text=True, timeout=300,
+                               env=dict(os.environ, PPDE_TF_BIG=big))
+            assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+            res[big] = dict(np.load(out))
+    for k in res["0"]:
+        assert np.isfinite(res["0"][k]).all() and np.array_equal(res["0"][k], res["1"][k]), k
+
+
 def test_reference_style_energy_object_with_a_checkpoint_file():
     """ProteinProductOfExperts(args) with --unsupervised_expert transformer: weights from a checkpoint file in the
     published format (the reference downloads it into --hub_dir)."""
