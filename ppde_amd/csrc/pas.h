@@ -216,6 +216,35 @@ __device__ __forceinline__ void args_up_front(const PasArgs& a) {
                  "s"(a.rec), "s"(a.rec_stride), "s"(a.key.chain_lo), "s"(a.key.k0), "s"(a.key.k1));
 }
 
+// Specialised instantiations: the kernels take their configuration in the (by-value) argument struct and branch on it at run
+// time; every such branch is wave-uniform and cheap to execute, but hipcc merges its wait counts conservatively where the
+// paths join and keeps both paths' values alive (the race's division / reciprocal switch alone cost k_propose 0.55 us as a
+// run-time branch). SPEC != 0 pins the fields of the COMMON configuration to constants in the kernel's own copy of the
+// struct, so that constant propagation through the inlined helpers deletes the other paths. The host selects it only when
+// the run's configuration equals the pinned one (chain_spec() in ppde_api.hip); SPEC = 0 is the general kernel.
+// SPEC = 0: the general kernel. Otherwise a bit field (PAS_SPEC_* below), always implying: device RNG, no trace buffers, not
+// paper_results, pre-reset recording, Potts window of at most 128 residues, and
+//   bits 0-1  experts: 1 = Potts only (BASELINE config 2), 2 = Potts + CNN product of experts (config 3; n_parts stays run-time)
+//   bit 2     no mutation cap (nmut_threshold 0, the reference's default): the cap's masks and counts drop out of every sub-step
+//   bits 3-4  gradient reuse: 1 = re-evaluating policy, 2 = reuse (0 = left to the run-time flag)
+#define PAS_SPEC_POTTS 1
+#define PAS_SPEC_POE 2
+#define PAS_SPEC_NOCAP 4
+#define PAS_SPEC_REEVAL 8
+#define PAS_SPEC_REUSE 16
+template <int SPEC>
+__device__ __forceinline__ void pin_config(PasArgs& a) {
+    if constexpr (SPEC != 0) {
+        a.rng_mode = 1; a.paper = 0; a.rec_after_reset = 0;
+        a.tr_flat = nullptr; a.tr_acc = nullptr; a.tr_logacc = nullptr; a.tr_U = nullptr;
+        a.which = (SPEC & 3) == PAS_SPEC_POTTS ? 1 : 3; a.gwhich = a.which;
+        if constexpr (SPEC & PAS_SPEC_NOCAP) a.thr = 0x7fffffff;
+        if constexpr (SPEC & PAS_SPEC_REEVAL) a.reuse = 0;
+        if constexpr (SPEC & PAS_SPEC_REUSE) a.reuse = 1;
+        __builtin_assume(a.g.Lp <= 128);
+    }
+}
+
 // Iteration index = device counter (graph replay) + node-local offset. The counter only changes between launches,
 // so it is read through the constant address space: a scalar load, counted apart from the vector loads, whose
 // result every Philox call of the kernel takes straight from an SGPR.
@@ -440,7 +469,8 @@ __device__ __forceinline__ float4 forward_logits(const PasArgs& a, const float* 
 }
 
 // Exp(1) race variates of sub-step s for this thread's groups (state independent)
-template <int GPT>
+// HOSTQ: the variates come from the caller's noise block (rng_mode 0) instead of Philox: a compile-time switch, like EXACT
+template <int GPT, bool HOSTQ>
 __device__ __forceinline__ void race_variates(const PasArgs& a, int b, int it, int s, float4 (&q)[GPT]) {
     const int n4 = a.g.N / 4;
     const uint32_t gchain = a.key.chain_lo + (uint32_t)b;
@@ -448,7 +478,7 @@ __device__ __forceinline__ void race_variates(const PasArgs& a, int b, int it, i
     for (int r = 0; r < GPT; ++r) {
         const int g4 = threadIdx.x + r * PPDE_BLOCK;
         if (g4 >= n4) { q[r] = make_float4(1.f, 1.f, 1.f, 1.f); continue; }
-        if (a.rng_mode == 0) {
+        if constexpr (HOSTQ) {
             q[r] = *(const float4*)(a.q_in + ((size_t)s * a.n + b) * a.g.N + 4 * g4);
         } else {
             const U4 rr = philox4x32_10(U4{gchain, (uint32_t)it, (uint32_t)(2 + s), (uint32_t)g4}, a.key.k0, a.key.k1);
@@ -464,22 +494,24 @@ struct ProposePrefetch {
     int dist;                   // mutation count of the current state (from the chain record)
     float4 q0[GPT];
 };
-template <int GPT>
+template <int GPT, bool HOSTQ>
 __device__ __forceinline__ ProposePrefetch<GPT> propose_prefetch(const PasArgs& a, int b, int it) {
     ProposePrefetch<GPT> p;
-    if (a.rng_mode == 0) p.Ub = a.U_in[b + opaque_zero()];
+    if constexpr (HOSTQ) p.Ub = a.U_in[b + opaque_zero()];
     else p.Ub = pathlen_from_bits(philox4x32_10(U4{a.key.chain_lo + (uint32_t)b, (uint32_t)it, 0u, 0u}, a.key.k0, a.key.k1).x, a.pas);
     p.Uraw = p.Ub;
     p.Ub = min(max(p.Ub, 1), min(a.mu_max, a.mu_cap));
     p.dist = rec_of(a, b + opaque_zero())->dist_cur;
-    race_variates<GPT>(a, b, it, 0, p.q0);
+    race_variates<GPT, HOSTQ>(a, b, it, 0, p.q0);
     return p;
 }
 
 // ------------------------------------------------------------------------------------------------
 // The forward path of one iteration (ppde.py:67-116). Expects lds.G / lds.St / lds.Wt staged and visible, R
 // holding the current letters, `dist` = mutation count of that state.
-template <int GPT>
+// EXACT: the race compares p / q with an IEEE division, as torch.multinomial does (replay of caller-supplied noise,
+// rng_mode 0); otherwise p * rcp(q) (device RNG).
+template <int GPT, bool EXACT>
 __device__ __forceinline__ void propose_body(const PasArgs& a, const RowLds& lds, RowRegs<GPT>& R, int b, int it, int dist0,
                                              const ProposePrefetch<GPT>& pp, bool stamp) {
     int dist = dist0;
@@ -494,7 +526,7 @@ __device__ __forceinline__ void propose_body(const PasArgs& a, const RowLds& lds
     for (int r = 0; r < GPT; ++r) q[r] = pp.q0[r];
 
     int pend_l = 0, pend_k = 0;                      // the last move, not yet applied to lds.St
-    const bool exact_race = a.rng_mode == 0;
+    constexpr bool exact_race = EXACT;             // (a compile-time switch: as a run-time branch in this loop it cost k_propose 0.55 us)
     for (int s = 0; s < Ub; ++s) {
         const bool capped = dist >= a.thr;
         // ---- logits z = (g - g[current letter]) / 2 with the forward masks (ppde.py:98-104)
@@ -513,7 +545,7 @@ __device__ __forceinline__ void propose_body(const PasArgs& a, const RowLds& lds
         }
         // next sub-step's race variates: state independent, so the Philox + log chains overlap with pass 2
         float4 qn[GPT];
-        if (s + 1 < Ub) race_variates<GPT>(a, b, it, s + 1, qn);
+        if (s + 1 < Ub) race_variates<GPT, EXACT>(a, b, it, s + 1, qn);
         // ---- softmax -> clamp (ppde/utils.py:106-111): p = clamp(exp(z - m) / S1), exp(z - m) = e * exp(m_w - m); the
         //      exponential race arg-max of p / q (torch.multinomial) and the clamped row sum S3 in one pass + one
         //      barrier. Each thread keeps its best entry (value, flat index, probability; strict > in index order: the
@@ -629,9 +661,10 @@ __device__ __forceinline__ void propose_body(const PasArgs& a, const RowLds& lds
     PPDE_STAMP(a.dbg, 19, stamp);
 }
 
-template <int GPT>
+template <int GPT, bool EXACT, int SPEC = 0>
 __global__ __launch_bounds__(PPDE_BLOCK) void k_propose(PasArgs a) {
     args_up_front(a);
+    pin_config<SPEC>(a);
     extern __shared__ unsigned char smem_raw[];
     const RowLds lds = carve_lds(smem_raw, a.g);
     const int b = a.b_off + blockIdx.x;
@@ -640,10 +673,10 @@ __global__ __launch_bounds__(PPDE_BLOCK) void k_propose(PasArgs a) {
     RowRegs<GPT> R;
     const int it = iteration_of(a);
     const RowLetters<GPT> rl = row_issue<GPT>(a.g, current_grad_row(a, b), a.cur + (size_t)b * a.g.Ls, a.wt, R);
-    const ProposePrefetch<GPT> pp = propose_prefetch<GPT>(a, b, it);
+    const ProposePrefetch<GPT> pp = propose_prefetch<GPT, EXACT>(a, b, it);
     row_commit<GPT>(lds, a.g, rl, R);
     PPDE_STAMP(a.dbg, 9, stamp);
-    propose_body<GPT>(a, lds, R, b, it, __builtin_amdgcn_readfirstlane(pp.dist), pp, stamp);
+    propose_body<GPT, EXACT>(a, lds, R, b, it, __builtin_amdgcn_readfirstlane(pp.dist), pp, stamp);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -864,9 +897,10 @@ __device__ __forceinline__ void commit_current_row(const PasArgs& a, const RowLd
     }
 }
 
-template <int GPT>
+template <int GPT, int SPEC = 0>
 __global__ __launch_bounds__(PPDE_BLOCK) void k_accept(PasArgs a) {
     args_up_front(a);
+    pin_config<SPEC>(a);
     extern __shared__ unsigned char smem_raw[];
     const RowLds lds = carve_lds(smem_raw, a.g);
     const int b = a.b_off + blockIdx.x;
@@ -889,9 +923,11 @@ __global__ __launch_bounds__(PPDE_BLOCK) void k_accept(PasArgs a) {
 // Accept phase of iteration `it` and forward path of iteration `it + 1` in one launch (gradient reuse only): an
 // accepted chain already has its next gradient row staged; a rejected / reset chain re-stages the row it falls
 // back to. Saves a launch boundary and a row staging per iteration.
-template <int GPT>
+template <int GPT, int SPEC = 0>
 __global__ __launch_bounds__(PPDE_BLOCK) void k_accept_propose(PasArgs a) {
     args_up_front(a);
+    pin_config<SPEC>(a);
+    a.reuse = 1; a.rng_mode = 1;                     // (this kernel exists for gradient reuse on the device RNG only)
     extern __shared__ unsigned char smem_raw[];
     const Geom g = a.g;
     const RowLds lds = carve_lds(smem_raw, g);
@@ -902,7 +938,7 @@ __global__ __launch_bounds__(PPDE_BLOCK) void k_accept_propose(PasArgs a) {
     RowRegs<GPT> R;
     const RowLetters<GPT> rl = row_issue<GPT>(g, slot_row(a, 1, b), a.cur + (size_t)b * g.Ls, a.wt, R);
     const AcceptPrefetch pf = accept_prefetch(a, lds, b, it);
-    const ProposePrefetch<GPT> pp = propose_prefetch<GPT>(a, b, it + 1);
+    const ProposePrefetch<GPT> pp = propose_prefetch<GPT, false>(a, b, it + 1);
     accept_stage_path(a, lds, pf);
     row_commit<GPT>(lds, g, rl, R);
     const AcceptOut o = accept_body<GPT>(a, lds, R, b, it, pf, stamp);
@@ -921,7 +957,7 @@ __global__ __launch_bounds__(PPDE_BLOCK) void k_accept_propose(PasArgs a) {
     for (int r = 0; r < GPT; ++r)
         if (R.valid[r] && R.kb[r] == 0) lds.St[R.l[r]] = (uint8_t)R.cur[r];
     __syncthreads();
-    propose_body<GPT>(a, lds, R, b, it + 1, o.dist, pp, stamp);
+    propose_body<GPT, false>(a, lds, R, b, it + 1, o.dist, pp, stamp);   // (fused launches exist on the device RNG only)
 }
 
 // history row 0 and the running best from the initial population (ppde.py:38-47): one wave per chain

@@ -6,6 +6,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <algorithm>
+#include <type_traits>
 #include <string>
 #include <vector>
 
@@ -917,16 +918,48 @@ static int launch_chain_kernel(ppde_chains* c, ChainKernel which, const PasArgs&
     const ppde_model* m = c->m;
     const size_t lds = pas_lds_bytes(m->g);
     const int gpt = (m->g.N / 4 + PPDE_BLOCK - 1) / PPDE_BLOCK;
-#define PPDE_CK(KERNEL)                                                                                 \
-    switch (gpt) {                                                                                      \
-        case 1: hipLaunchKernelGGL(KERNEL<1>, dim3(n_sub), dim3(PPDE_BLOCK), lds, s, a); break;          \
-        case 2: hipLaunchKernelGGL(KERNEL<2>, dim3(n_sub), dim3(PPDE_BLOCK), lds, s, a); break;          \
-        default: hipLaunchKernelGGL(KERNEL<3>, dim3(n_sub), dim3(PPDE_BLOCK), lds, s, a); break;         \
-    }
-    if (which == KP_PROPOSE) { PPDE_CK(k_propose) }
-    else if (which == KP_ACCEPT) { PPDE_CK(k_accept) }
-    else { PPDE_CK(k_accept_propose) }
-#undef PPDE_CK
+    // specialised instantiation for the common configurations (pas.h pin_config), the general kernel otherwise
+    static const bool spec_on = []() { const char* e = getenv("PPDE_CHAIN_SPEC"); return !e || atoi(e) != 0; }();   // tuning knob
+    int spec = 0;
+    if (spec_on && a.rng_mode == 1 && !a.paper && !a.rec_after_reset && !a.tr_flat && a.which == a.gwhich &&
+        (a.which == 1 || a.which == 3) && m->g.Lp <= 128)
+        spec = (a.which == 1 ? PAS_SPEC_POTTS : PAS_SPEC_POE) | (a.thr == 0x7fffffff ? PAS_SPEC_NOCAP : 0) |
+               (which == KP_ACCEPT_PROPOSE ? 0 : a.reuse ? PAS_SPEC_REUSE : PAS_SPEC_REEVAL);
+    // (every specialisation the host can ask for is instantiated below: experts x cap x policy; the fused kernel has no policy bit)
+    auto with_gpt = [&](auto&& f) {
+        switch (gpt) {
+            case 1: f(std::integral_constant<int, 1>{}); break;
+            case 2: f(std::integral_constant<int, 2>{}); break;
+            default: f(std::integral_constant<int, 3>{}); break;
+        }
+    };
+    auto with_spec = [&](auto&& f) {
+        switch (spec) {
+#define PPDE_SP(v) case (v): f(std::integral_constant<int, (v)>{}); break;
+#define PPDE_SP3(b) PPDE_SP(b) PPDE_SP((b) | PAS_SPEC_REEVAL) PPDE_SP((b) | PAS_SPEC_REUSE)
+            PPDE_SP3(PAS_SPEC_POTTS) PPDE_SP3(PAS_SPEC_POTTS | PAS_SPEC_NOCAP) PPDE_SP3(PAS_SPEC_POE) PPDE_SP3(PAS_SPEC_POE | PAS_SPEC_NOCAP)
+#undef PPDE_SP3
+#undef PPDE_SP
+            default: f(std::integral_constant<int, 0>{}); break;
+        }
+    };
+    with_gpt([&](auto G) {
+        constexpr int GP = decltype(G)::value;
+        if (which == KP_PROPOSE && a.rng_mode == 0) {
+            hipLaunchKernelGGL((k_propose<GP, true, 0>), dim3(n_sub), dim3(PPDE_BLOCK), lds, s, a);
+            return;
+        }
+        with_spec([&](auto S) {
+            constexpr int SP = decltype(S)::value;
+            constexpr bool policy = (SP & (PAS_SPEC_REEVAL | PAS_SPEC_REUSE)) != 0;
+            if (which == KP_ACCEPT_PROPOSE) {
+                if constexpr (!policy) hipLaunchKernelGGL((k_accept_propose<GP, SP>), dim3(n_sub), dim3(PPDE_BLOCK), lds, s, a);
+            } else if constexpr (policy || SP == 0) {
+                if (which == KP_PROPOSE) hipLaunchKernelGGL((k_propose<GP, false, SP>), dim3(n_sub), dim3(PPDE_BLOCK), lds, s, a);
+                else hipLaunchKernelGGL((k_accept<GP, SP>), dim3(n_sub), dim3(PPDE_BLOCK), lds, s, a);
+            }
+        });
+    });
     HIPCHK(hipGetLastError());
     return PPDE_OK;
 }

@@ -303,6 +303,27 @@ def test_philox_mode_vs_oracle_and_invariances():
     assert np.array_equal(np.concatenate([a["best_idx"], b["best_idx"]], 0), res["best_idx"])
 
 
+@pytest.mark.parametrize("which,nmut,reuse", [(1, 0, False), (1, 0, True), (1, 3, False), (1, 3, True), (3, 0, False), (3, 0, True), (3, 4, True), (3, 4, False)])
+def test_specialised_chain_kernels_equal_the_general_ones(which, nmut, reuse):
+    """The chain kernels are instantiated once in general form and once per common configuration with that configuration's
+    fields pinned to constants (pas.h pin_config: device RNG, no trace, experts, mutation cap or none, evaluation policy).
+    A run WITHOUT trace buffers takes the specialised instantiation, the same run WITH them the general one (the one every
+    oracle comparison above goes through): histories, best states and the recorded trajectory must be bit-identical."""
+    from ppde_amd.sampler import Chains
+    fx, J, h, i0, wt_idx, cnn, m = _philox_setup()
+    n, T, Lp = 24, 130, J.shape[0]
+    res = []
+    for trace in (False, True):
+        ch = Chains(m, n, T, 2, nmut, False, i0, i0 + Lp - 1, which, 1, reuse_grad=reuse, trace=trace, random_chain=5, seed=4242,
+                    use_graph=True)
+        ch.init(torch.as_tensor(np.tile(wt_idx, (n, 1))).cuda())
+        ch.run(T)
+        res.append(ch.collect())
+    for k in ("energy_history", "fitness_history", "best_idx", "best_energy", "best_fitness", "best_step", "random_traj"):
+        assert np.array_equal(res[0][k], res[1][k]), k
+    assert (res[0]["energy_history"][1:] != res[0]["energy_history"][:-1]).any()
+
+
 def test_full_size_properties():
     """BASELINE config sizes (128 chains, PABP, 1000 steps): properties that need no oracle run."""
     fx, J, h, i0, wt_idx, cnn, m = _philox_setup()
