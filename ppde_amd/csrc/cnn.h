@@ -212,15 +212,24 @@ __device__ __forceinline__ void cnn_route_rows(const CnnNet& net, const int rows
 // against four waves, unfused launches): the gather, list and route phases are latency-bound and gain from the second wave
 // per SIMD; the contractions are bound by the matrix pipe either way.
 #define CNN_NT 512
-template <int RT, int KT, int NT = CNN_NT>
-__device__ __forceinline__ void cnn_body(const CnnArgs& a, const int bx, const int ni, const int n_bx, const int n_ni,
+// PABP: the shape of the PABP_YEAST networks (L = 96: 96 channels, 192 features, 5 taps; three networks in four output rows;
+// gradients wanted) as compile-time constants instead of the argument struct's run-time values, so that every trip count
+// below is known to the compiler (the host selects it only for exactly that shape; the struct itself is not written to:
+// a modified by-value argument struct with run-time indexed members would move to scratch memory).
+template <int RT, int KT, int NT = CNN_NT, bool PABP = false>
+__device__ __forceinline__ void cnn_body(const CnnArgs& a_, const int bx, const int ni, const int n_bx, const int n_ni,
                                          unsigned char* smem_raw) {
-    const Geom g = a.g;
+    struct Shape { int n_nets, n_parts, T, CP, F, FP, J, JP, want_grad; };
+    const Shape a_shape = PABP ? Shape{3, 4, 92, 96, 192, 192, 100, 112, 1}
+                               : Shape{a_.n_nets, a_.n_parts, a_.T, a_.CP, a_.F, a_.FP, a_.J, a_.JP, a_.want_grad};
+    const CnnArgs& a = a_;
+    Geom g = a.g;
+    if constexpr (PABP) { g.L = 96; g.N = 1920; }
     const int b = a.b_off + bx, tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int part = ni;                                            // output row; the network it belongs to:
-    const CnnNet net = a.net[min(part, a.n_nets - 1)];
-    const int T = a.T, CP = a.CP, F = a.F, FP = a.FP, J = a.J, JP = a.JP;
+    const CnnNet net = a.net[min(part, a_shape.n_nets - 1)];
+    const int T = a_shape.T, CP = a_shape.CP, F = a_shape.F, FP = a_shape.FP, J = a_shape.J, JP = a_shape.JP;
     const int AS = cnn_astride(CP);
     const int rows = RT * 16;
     const int KSP = CP / 4;                                         // CP is padded to a multiple of 4*CNN_KB
@@ -228,9 +237,9 @@ __device__ __forceinline__ void cnn_body(const CnnArgs& a, const int bx, const i
     const int BW = (CP + 31) / 32;                                  // gate words per row
     // feature tiles of this workgroup: all of them, or one half of the split network's (a half does the whole convolution
     // and both halves' gradients add up: every step after the arg-max is linear in the routed features)
-    const bool halved = a.n_parts > a.n_nets && part >= a.n_nets - 1;
+    const bool halved = a_shape.n_parts > a_shape.n_nets && part >= a_shape.n_nets - 1;
     const int FT = FP / 16, ct_mid = (FT + 1) / 2;
-    const int ct_lo = (halved && part == a.n_nets) ? ct_mid : 0, ct_hi = (halved && part < a.n_nets) ? ct_mid : FT;
+    const int ct_lo = (halved && part == a_shape.n_nets) ? ct_mid : 0, ct_hi = (halved && part < a_shape.n_nets) ? ct_mid : FT;
     float* sH = (float*)smem_raw;                                   // [rows][AS] h1, later O [rows][J]
     float* sD = sH + (size_t)rows * (AS > OS ? AS : OS);            // [rows][AS] routed gradient
     uint32_t* sG = (uint32_t*)(sD + (size_t)rows * AS);             // [rows][BW] bit o of word: h1[t][o] > 0
@@ -351,16 +360,16 @@ __device__ __forceinline__ void cnn_body(const CnnArgs& a, const int bx, const i
             s += wv * mf;
             cf[k] = (f < F && mf > 0.f) ? a.scale * wv : 0.f;
         }
-        if (a.want_grad)
+        if (a_shape.want_grad)
             for (int w = tid; w < rows * BWF; w += NT) sB[w] = 0u;  // route bitmap (filled behind the barrier below)
         const float tot = block_sum<NT / 64>(s, red, phase);             // (its barrier also orders the sM rewrite below)
-        if (tid == 0) a.fitC[((size_t)slot * a.n_parts + part) * a.n + b] = part < a.n_nets ? tot + net.bd : tot;   // (the bias once)
+        if (tid == 0) a.fitC[((size_t)slot * a_shape.n_parts + part) * a.n + b] = part < a_shape.n_nets ? tot + net.bd : tot;   // (the bias once)
         k = 0;
         for (int f = tid; f < FP; f += NT, ++k)
             if (k < 2) sM[f] = cf[k];
     }
     PPDE_STAMP(a.dbg, sb + 4, stamp);
-    if (!a.want_grad) return;
+    if (!a_shape.want_grad) return;
 
     // ---- route + gate (cnn_route_rows): d pre1 = relu'(pre1) * (features routed into their arg-max rows) -> sD
     cnn_route_rows<NT>(net, rows, 0, CP, AS, FP, BW, sD, sB, sG, sM, sTs, sStart, sList, (int*)(red + 12));
@@ -387,7 +396,7 @@ __device__ __forceinline__ void cnn_body(const CnnArgs& a, const int bx, const i
     __syncthreads();
     PPDE_STAMP(a.dbg, sb + 8, stamp);
     // ---- transposed convolution: dx[p][c] = sum_kappa O[p - kappa][kappa*20 + c]
-    float* out = a.gradC + (((size_t)slot * a.n_parts + part) * a.n + b) * g.N;
+    float* out = a.gradC + (((size_t)slot * a_shape.n_parts + part) * a.n + b) * g.N;
     for (int e0 = tid; e0 < g.N; e0 += 2 * NT) {                       // two elements per round: 2*KT LDS reads in flight
         float x[2][KT];
         int pp[2];

@@ -158,12 +158,15 @@ __device__ __forceinline__ size_t state_t4_offset_dev(int NC, int n_pad, int b, 
 // Body of one workgroup: `tile` = 4 output columns, `by` = block of NG*64 chains. A __device__ function so that
 // the kernel below and the fused experts launch (ppde_api.hip: k_experts) share it.
 // GM (ring variant) = chunk groups whose letters a wave keeps in registers: the window may have up to 16*GM*... 4*GM chunks per part.
-template <int NG, bool RING = false, int GM = 2>   // NG groups of 64 chains per workgroup
+// NCC: the window's chunk count as a compile-time constant (0 = read g.NC at run time). With it every trip count, every DMA
+// piece count and every counted s_waitcnt of the body is an immediate (the run-time form goes through wait_vmcnt's switch);
+// the host instantiates NCC = 5 (windows of 65..80 residues: PABP_YEAST 80, UBE4B_MOUSE 76).
+template <int NG, bool RING = false, int GM = 2, int NCC = 0>   // NG groups of 64 chains per workgroup
 __device__ __forceinline__ void potts_body(const PottsArgs& a, const int tile, const int by, float4* smem) {
     static_assert(!RING || NG <= 2, "the part sums of a ring workgroup live in one wave's ring");
     static_assert(RING || GM == 2, "the resident slab holds at most 8 chunks per part");
     const Geom g = a.g;
-    const int NC = g.NC, G = potts_groups(NC);
+    const int NC = NCC ? NCC : g.NC, G = potts_groups(NC);
     constexpr int CPB = NG * 64;
     static_assert(CPB <= 256, "one thread per chain in the epilogue");
     const int tid = threadIdx.x, lane = tid & 63;
@@ -301,13 +304,13 @@ __device__ __forceinline__ void potts_body(const PottsArgs& a, const int tile, c
 
 // grid = (tiles x chain blocks) workgroups in one dimension; consecutive work items (chain blocks of a tile, then the
 // next tile) go to one XCD (xcd_contiguous)
-template <int NG, bool RING = false, int GM = 2>
+template <int NG, bool RING = false, int GM = 2, int NCC = 0>
 __global__ __launch_bounds__(256, RING ? (GM <= 4 ? 5 : 4) : 2) void potts_energy_grad_kernel(PottsArgs a, int nby) {
     warm_kernargs<sizeof(PottsArgs) + 8>();
     extern __shared__ float4 smem[];
     const int v = xcd_contiguous(blockIdx.x, gridDim.x);
-    if (nby == 1) potts_body<NG, RING, GM>(a, v, 0, smem);
-    else potts_body<NG, RING, GM>(a, v / nby, v % nby, smem);
+    if (nby == 1) potts_body<NG, RING, GM, NCC>(a, v, 0, smem);
+    else potts_body<NG, RING, GM, NCC>(a, v / nby, v % nby, smem);
 }
 
 // State rows [n][Ls] -> their T4 copy (API edge and initialisation; the chain kernels write both forms themselves).

@@ -216,7 +216,11 @@ static int launch_potts(const ppde_model* m, const States& st, int n, const Eval
         ARGCHK(m->g.NC <= 8, "Potts window too long for the resident-slab kernel (the ring variant takes it)");
         const size_t lds = potts_lds_bytes(m->g.NC, NG);
         const int nby = (n_sub + NG * 64 - 1) / (NG * 64);
-        switch (NG) {
+        static const bool nc_spec = []() { const char* e = getenv("PPDE_POTTS_SPEC"); return !e || atoi(e) != 0; }();   // tuning knob
+        if (nc_spec && m->g.NC == 5 && NG <= 2) {               // chunk count pinned (potts.h NCC): PABP / UBE4B windows
+            if (NG == 1) hipLaunchKernelGGL((potts_energy_grad_kernel<1, false, 2, 5>), dim3(tiles * nby), dim3(256), lds, s, a, nby);
+            else hipLaunchKernelGGL((potts_energy_grad_kernel<2, false, 2, 5>), dim3(tiles * nby), dim3(256), lds, s, a, nby);
+        } else switch (NG) {
             case 1: hipLaunchKernelGGL(potts_energy_grad_kernel<1>, dim3(tiles * nby), dim3(256), lds, s, a, nby); break;
             case 2: hipLaunchKernelGGL(potts_energy_grad_kernel<2>, dim3(tiles * nby), dim3(256), lds, s, a, nby); break;
             default: hipLaunchKernelGGL(potts_energy_grad_kernel<4>, dim3(tiles * nby), dim3(256), lds, s, a, nby); break;
@@ -324,18 +328,21 @@ struct ExpertsArgs {
     int cnn_bx, cnn_ni;        // CNN workgroups = cnn_bx (chains) x cnn_ni (networks), first in block order
     int potts_items, potts_nby;   // then potts_items = tiles x potts_nby (chain blocks) Potts workgroups
 };
-template <int RT, int NG>
+// PABP: the CNN's shape pinned to the PABP_YEAST networks' (L = 96: 96 channels, 192 features, 5 taps, three networks in four
+// output rows, gradients wanted), so that every trip count of cnn_body is a compile-time constant (as pin_config in pas.h)
+template <int RT, int NG, bool PABP = false>
 __global__ __launch_bounds__(CNN_NT, 2) void k_experts(ExpertsArgs a) {
     warm_kernargs<sizeof(ExpertsArgs)>();
+
     extern __shared__ float4 smem_experts[];
     const int w = blockIdx.x, n_cnn = a.cnn_bx * a.cnn_ni;
     if (w < n_cnn) {
         const int ni = w / a.cnn_bx;
-        cnn_body<RT, 5>(a.c, w - ni * a.cnn_bx, ni, a.cnn_bx, a.cnn_ni, (unsigned char*)smem_experts);
+        cnn_body<RT, 5, CNN_NT, PABP>(a.c, w - ni * a.cnn_bx, ni, a.cnn_bx, a.cnn_ni, (unsigned char*)smem_experts);
     } else {
         if (threadIdx.x >= 256) return;          // a Potts tile is the work of four waves (the barrier counts live waves only)
         const int v = xcd_contiguous(w - n_cnn, a.potts_items);
-        potts_body<NG>(a.p, v / a.potts_nby, v % a.potts_nby, smem_experts);
+        potts_body<NG, false, 2, PABP ? 5 : 0>(a.p, v / a.potts_nby, v % a.potts_nby, smem_experts);
     }
 }
 
@@ -365,6 +372,14 @@ static int launch_experts_fused(const ppde_model* m, const States& st, int n, co
     a.potts_nby = (n_sub + CPB - 1) / CPB;
     a.potts_items = m->g.Lp * 5 * a.potts_nby;
     const dim3 grid(a.cnn_bx * a.cnn_ni + a.potts_items);
+    static const bool shape_spec = []() { const char* e = getenv("PPDE_CNN_SPEC"); return !e || atoi(e) != 0; }();   // tuning knob
+    if (shape_spec && NG == 2 && m->L == 96 && m->g.NC == 5 && c.C == 96 && c.CP == 96 && c.K == 5 && c.F == 192 && c.FP == 192 && c.T == 92 && c.J == 100 &&
+        c.JP == 112 && c.n_nets == 3 && c.n_parts == 4) {
+        hipLaunchKernelGGL((k_experts<6, 2, true>), grid, dim3(CNN_NT), lds_c, s, a);
+        HIPCHK(hipGetLastError());
+        *done = true;
+        return PPDE_OK;
+    }
 #define PPDE_EX(RTV)                                                                              \
     if (NG == 1) hipLaunchKernelGGL((k_experts<RTV, 1>), grid, dim3(CNN_NT), lds_c, s, a);         \
     else hipLaunchKernelGGL((k_experts<RTV, 2>), grid, dim3(CNN_NT), lds_c, s, a);
