@@ -937,7 +937,7 @@ static int launch_chain_kernel(ppde_chains* c, ChainKernel which, const PasArgs&
     static const bool spec_on = []() { const char* e = getenv("PPDE_CHAIN_SPEC"); return !e || atoi(e) != 0; }();   // tuning knob
     int spec = 0;
     if (spec_on && a.rng_mode == 1 && !a.paper && !a.rec_after_reset && !a.tr_flat && a.which == a.gwhich &&
-        (a.which == 1 || a.which == 3) && m->g.Lp <= 128)
+        (a.which == 1 || a.which == 3))
         spec = (a.which == 1 ? PAS_SPEC_POTTS : PAS_SPEC_POE) | (a.thr == 0x7fffffff ? PAS_SPEC_NOCAP : 0) |
                (which == KP_ACCEPT_PROPOSE ? 0 : a.reuse ? PAS_SPEC_REUSE : PAS_SPEC_REEVAL);
     // (every specialisation the host can ask for is instantiated below: experts x cap x policy; the fused kernel has no policy bit)
