@@ -7,8 +7,12 @@ TAG=${1:-r03}
 PHASE=${2:-all}       # all | a (bench lines, kernel tables, counters) | b (transformer, probes, stamps)
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 OUT=$ROOT/gpurun_out
-P=$ROOT/profiles
+# summaries go under gpurun_out/ (the only directory that travels back from the GPU box); copy them into profiles/ afterwards:
+#   cp gpurun_out/profiles_<tag>/* profiles/
+P=$OUT/profiles_$TAG
+export PPDE_PROFILES_OUT=$P
 mkdir -p "$OUT" "$P"
+cp "$ROOT/profiles/potts_pmc.json" "$P/" 2>/dev/null || true
 cd /tmp && export TMPDIR=/tmp
 run() { echo "== $*"; "$@"; }
 if [ "$PHASE" != b ]; then

@@ -17,7 +17,7 @@ import shutil
 import pandas as pd
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-OUT = os.path.join(REPO, "profiles")
+OUT = os.environ.get("PPDE_PROFILES_OUT") or os.path.join(REPO, "profiles")
 
 
 def counters(d):
