@@ -2,7 +2,8 @@
 
 Only `tests/`, `__graft_entry__.smoke()` and `bench.py`'s `cpu_baseline` leg may import this file.
 
-PARITY UNPINNED. The reference's transformer expert (ppde/nets.py:172-240 `Transformer`, :302-312 `PottsTransformer`,
+PARITY UNPINNED (the ESM-2 arithmetic below; the reference's glue around it IS pinned, see the end of this header).
+The reference's transformer expert (ppde/nets.py:172-240 `Transformer`, :302-312 `PottsTransformer`,
 ppde/energy.py:110-130) calls `esm_one_hot.pretrained.esm2_t30_150M_UR50D()`: a third-party dependency
 (`git+https://github.com/pemami4911/esm_one_hot.git`, unpinned, environment.yml:22) that is not in the mount, whose
 weights come from torch hub at run time, and for which the reference holds no tests or fixtures. What follows is a
@@ -26,7 +27,15 @@ sites, with the token embedding written as a matmul on one-hot input as the fork
 Precision. The reference runs the model under `torch.cuda.amp.autocast()` (nets.py:230): matmuls in fp16 with fp32
 accumulation, softmax / layer norm / log-softmax in fp32. `half_points=True` rounds to fp16 where autocast would hand an
 fp16 tensor on (every linear output, residual sums, GELU, attention probabilities), which is also where the HIP path
-stores fp16; the autograd of those casts rounds the gradients to fp16 at the same places.
+stores fp16; the autograd of those casts rounds the gradients to fp16 at the same places. One known idealisation: GELU is
+evaluated in fp32 on the fp16-rounded input and rounded once, where autocast runs the elementwise `gelu` kernel in fp16;
+the difference is below every tolerance used against this file (scores 2e-3 relative, gradients 3e-2 of the largest).
+
+What IS pinned: `tests/golden/make_golden.py tf` runs the REFERENCE's own code (nets.py:193-240 permutation / local_score /
+Delta against the wild type, :302-312 PottsTransformer, energy.py:110-130 minibatch loop and gradient w.r.t. the slice,
+PPDE_PAS.run on top) over a stand-in `esm_one_hot` that serves `EsmOracle(half_points=False)` (fp32: on the CPU the
+reference's autocast is disabled), and freezes ops_tfpoe_toy.npz / run_tfpoe_toy_*.npz; `TransformerDelta` below +
+`ppde_oracle.EnergyOracle(tf=...)` replay them (tests/test_oracle_golden.py).
 """
 import math
 

@@ -176,6 +176,27 @@ def test_sharded_run_gathers_to_the_unsharded_result_gloo():
         os.unlink(path)
 
 
+def test_esm2_checkpoint_in_the_published_layout_loads(tmp_path):
+    """The published ESM-2 files pickle an argparse.Namespace under cfg.model next to the tensors (facebookresearch/esm reads
+    cfg.model.encoder_layers / encoder_attention_heads from it); torch >= 2.6 refuses that class under its default
+    weights-only unpickler. The loader allows exactly that class, strips the 'encoder.sentence_encoder.' / 'encoder.'
+    prefixes, drops the tied lm_head.weight, and returns the head count of the file."""
+    import argparse
+    path = str(tmp_path / "checkpoints" / "esm2_t30_150M_UR50D.pt")
+    st = synthetic.write_esm2_checkpoint(path, 2, 128, 4, 256, seed=2)
+    ck = torch.load(path, map_location="cpu", weights_only=False)
+    assert isinstance(ck["cfg"]["model"], argparse.Namespace) and ck["cfg"]["model"].encoder_attention_heads == 4
+    with pytest.raises(Exception):
+        torch.load(path, map_location="cpu", weights_only=True)          # what the loader used to do
+    sd, heads = weights.load_esm2_state(path, with_heads=True)
+    assert heads == 4 and set(sd) == set(st) and "lm_head.weight" not in sd
+    assert all(np.array_equal(sd[k], st[k]) for k in st)
+    # an already stripped dict without cfg still loads (heads unknown)
+    torch.save({k: torch.from_numpy(v) for k, v in st.items()}, str(tmp_path / "plain.pt"))
+    sd2, heads2 = weights.load_esm2_state(str(tmp_path / "plain.pt"), with_heads=True)
+    assert heads2 is None and set(sd2) == set(st)
+
+
 def test_bench_launches_its_own_ranks(monkeypatch):
     """`python bench.py --gpus N` without a launcher: the parent starts torch.distributed.run with N ranks and the same
     arguments, and never touches the GPU itself; as a rank it refuses a world size that differs from --gpus."""

@@ -291,6 +291,39 @@ def test_tfpoe_ube4b_150m_shapes_vs_combined_oracle():
     assert float(e[0]) == lam * float(fit[0])                   # wild type: Delta score exactly 0
 
 
+def test_config5_full_size_properties():
+    """BASELINE config 5 at its full size (256 chains, UBE4B length, esm2_t30_150M geometry, three CNNs, lamda = 3), a few
+    iterations: properties that need no oracle run. Both evaluation policies give the same bits; the running best is the
+    maximum over the history (first index on ties) and the stored best state really has that energy; every chain starts at
+    the wild type's energy lamda * fit(wt); the mutation cap holds."""
+    from ppde_amd.energy import HipModel
+    from ppde_amd.sampler import Chains
+    name = [k for k in synthetic.PROTEINS if k.startswith("UBE4B")][0]
+    wt = seqs_to_idx([synthetic.PROTEINS[name][1]])[0]
+    L, n, T, lam = wt.shape[0], 256, 4, 3.0
+    m = HipModel(wt, "cuda:0")
+    m.set_cnn([synthetic.make_cnn_state(L, s) for s in range(3)])
+    m.set_transformer(synthetic.make_esm2_state(30, 640, 20, 2560, seed=0), 20)
+    m.set_lamda(lam)
+    res = []
+    for reuse in (False, True):
+        ch = Chains(m, n, T, 2, 10, False, 0, L - 1, 6, 1, reuse_grad=reuse, random_chain=7, seed=11, trace=True)
+        ch.init(torch.as_tensor(np.tile(wt, (n, 1))).cuda())
+        ch.run(T)
+        res.append((ch.collect(), ch.trace(), ch.peek()))
+    (a, tra, pka), (b, trb, _) = res
+    for k in ("energy_history", "fitness_history", "best_idx", "best_step", "random_traj"):
+        assert np.array_equal(a[k], b[k]), k
+    assert np.array_equal(tra["flat"], trb["flat"]) and np.array_equal(tra["accepted"], trb["accepted"])
+    eh = a["energy_history"]
+    assert np.isfinite(eh).all() and np.array_equal(a["best_energy"], eh.max(0)) and np.array_equal(a["best_step"], eh.argmax(0))
+    e_wt, f_wt, _ = m.energy_grad(torch.as_tensor(wt[None]).cuda(), 6, want_grad=False)
+    assert np.all(eh[0] == float(e_wt[0])) and float(e_wt[0]) == lam * float(f_wt[0])
+    e_b, f_b, _ = m.energy_grad(torch.as_tensor(a["best_idx"]).cuda(), 6, want_grad=False)
+    assert np.array_equal(e_b.cpu().numpy(), a["best_energy"]) and np.array_equal(f_b.cpu().numpy(), a["best_fitness"])
+    assert (pka["dist"] < 10).all() and 0.0 < tra["accepted"].mean() < 1.0
+
+
 _CHUNKED = r"""
 import sys
 sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[1] + "/tests"); sys.path.insert(0, sys.argv[1] + "/oracle")
