@@ -46,6 +46,14 @@ for trial in range(int(os.environ.get("FZ_TRIALS", 24))):
                 reuse_grad=reuse, use_graph=graph)
     ch.init(torch.as_tensor(start).cuda()); ch.run(T)
     tr, res = ch.trace(), ch.collect()
+    # the same run without trace buffers takes the SPECIALISED chain kernels (pas.h pin_config) where the configuration has
+    # one: histories and best states must equal the general kernels' bit for bit
+    ch2 = Chains(m, n, T, pas, nmut, paper, min_pos, max_pos, which, 1, trace=False, random_chain=0, seed=1000 + trial,
+                 reuse_grad=reuse, use_graph=graph)
+    ch2.init(torch.as_tensor(start).cuda()); ch2.run(T)
+    res2 = ch2.collect()
+    spec_same = all(np.array_equal(res[k], res2[k]) for k in ("energy_history", "fitness_history", "best_idx", "best_step", "random_traj"))
+    del ch2
     noise = []
     for t in range(T):
         qs = []
@@ -76,6 +84,8 @@ for trial in range(int(os.environ.get("FZ_TRIALS", 24))):
     if not first and not np.array_equal(res["best_idx"], ref["best_idx"].numpy()):
         eh = ref["energy_history"].numpy()
         why.append(f"best state (reference best steps {eh.argmax(0)[:6]}, hip {res['best_step'][:6]})")
+    if not spec_same:
+        why.append("run without trace buffers (specialised kernels) differs from the traced run")
     ok = not why
     bad += not ok
     print(f"   -> {'ok' if ok else 'FAIL: ' + '; '.join(why)} (max |dE| {de:.1e}, accepted {tr['accepted'].mean():.2f})", flush=True)
