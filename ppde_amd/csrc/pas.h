@@ -7,7 +7,9 @@
 //                        forward log-probabilities, state update
 //   k_accept  : :122-153 reverse-path log-probabilities on grad(y) (no masks), log acceptance ratio,
 //                        accept/reject, histories, running best (ppde.py:172-183), mutation-cap reset
-// A row of L*20 logits lives in LDS; row reductions are wavefront butterflies + one 4-entry LDS exchange.
+// A row of L*20 logits lives in registers (the gradient row it is formed from in LDS); row reductions are DPP wavefront
+// reductions + one LDS exchange per barrier. The kernels are instantiated in a general form and per common configuration
+// (pin_config below).
 #pragma once
 #include "common.h"
 #include "potts.h"

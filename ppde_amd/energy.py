@@ -8,6 +8,11 @@ with .get_energy(x) -> (e, fit), .get_energy_and_grads(x) -> (e, fit, grad_x), .
 
 Inputs are fp32 one-hot tensors [n, L, 20]; they are converted to residue indices on the device and
 everything else happens in the HIP kernels (ppde_amd/csrc). There is no CPU path: a non-HIP device raises.
+
+Extra, optional attribute on `args` (absent in the reference; the default keeps its behaviour):
+    ppde_full_grad      False (default): with a transformer unsupervised expert, grad_x holds the unsupervised experts'
+                        gradient only, as the reference's minibatch loop yields (it differentiates w.r.t. the slice of x,
+                        energy.py:115, :125, while fit was computed from x, :104); True adds lamda * d fit/dx.
 """
 import ctypes as C
 import os
