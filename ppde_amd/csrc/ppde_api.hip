@@ -202,28 +202,45 @@ static int launch_potts(const ppde_model* m, const States& st, int n, const Eval
     static const int ring_override = []() { const char* e = getenv("PPDE_POTTS_RING"); return e ? atoi(e) : -1; }();   // tuning knob
     const bool ring = ring_override >= 0 ? ring_override != 0 : m->g.NC > 8;   // long windows stream through a ring
     const int tiles = m->g.Lp * 5;
+    // Every window of up to 256 residues (chunk counts 1..16) has an instantiation with its chunk count as a compile-time
+    // constant (potts.h NCC): trip counts, DMA piece counts and counted waits are immediates there. Resident slab 5.12 ->
+    // 4.96 us at PABP size, ring 17.7 -> 16.0 us at GFP size. PPDE_POTTS_SPEC=0: the general kernels (run-time chunk count).
+    static const bool nc_spec = []() { const char* e = getenv("PPDE_POTTS_SPEC"); return !e || atoi(e) != 0; }();   // tuning knob
     if (ring) {
         NG = std::min(NG, 2);
         const size_t lds = potts_ring_lds_bytes();
         const int nby = (n_sub + NG * 64 - 1) / (NG * 64);
+        const dim3 grid(tiles * nby);
         ARGCHK(m->g.NC <= 32, "Potts window longer than 512 residues");
         const bool g4 = potts_groups(m->g.NC) <= 4;             // letters of <= 4 chunk groups per wave: 5 workgroups per CU
-        if (NG == 1 && g4) hipLaunchKernelGGL((potts_energy_grad_kernel<1, true, 4>), dim3(tiles * nby), dim3(256), lds, s, a, nby);
-        else if (NG == 1) hipLaunchKernelGGL((potts_energy_grad_kernel<1, true, 8>), dim3(tiles * nby), dim3(256), lds, s, a, nby);
-        else if (g4) hipLaunchKernelGGL((potts_energy_grad_kernel<2, true, 4>), dim3(tiles * nby), dim3(256), lds, s, a, nby);
-        else hipLaunchKernelGGL((potts_energy_grad_kernel<2, true, 8>), dim3(tiles * nby), dim3(256), lds, s, a, nby);
+        bool launched = false;
+        if (nc_spec && g4) {
+#define PPDE_PR(v) case v: if (NG == 1) hipLaunchKernelGGL((potts_energy_grad_kernel<1, true, 4, v>), grid, dim3(256), lds, s, a, nby); \
+                           else hipLaunchKernelGGL((potts_energy_grad_kernel<2, true, 4, v>), grid, dim3(256), lds, s, a, nby); launched = true; break;
+            switch (m->g.NC) { PPDE_PR(9) PPDE_PR(10) PPDE_PR(11) PPDE_PR(12) PPDE_PR(13) PPDE_PR(14) PPDE_PR(15) PPDE_PR(16) default: break; }
+#undef PPDE_PR
+        }
+        if (launched) { }
+        else if (NG == 1 && g4) hipLaunchKernelGGL((potts_energy_grad_kernel<1, true, 4>), grid, dim3(256), lds, s, a, nby);
+        else if (NG == 1) hipLaunchKernelGGL((potts_energy_grad_kernel<1, true, 8>), grid, dim3(256), lds, s, a, nby);
+        else if (g4) hipLaunchKernelGGL((potts_energy_grad_kernel<2, true, 4>), grid, dim3(256), lds, s, a, nby);
+        else hipLaunchKernelGGL((potts_energy_grad_kernel<2, true, 8>), grid, dim3(256), lds, s, a, nby);
     } else {
         ARGCHK(m->g.NC <= 8, "Potts window too long for the resident-slab kernel (the ring variant takes it)");
         const size_t lds = potts_lds_bytes(m->g.NC, NG);
         const int nby = (n_sub + NG * 64 - 1) / (NG * 64);
-        static const bool nc_spec = []() { const char* e = getenv("PPDE_POTTS_SPEC"); return !e || atoi(e) != 0; }();   // tuning knob
-        if (nc_spec && m->g.NC == 5 && NG <= 2) {               // chunk count pinned (potts.h NCC): PABP / UBE4B windows
-            if (NG == 1) hipLaunchKernelGGL((potts_energy_grad_kernel<1, false, 2, 5>), dim3(tiles * nby), dim3(256), lds, s, a, nby);
-            else hipLaunchKernelGGL((potts_energy_grad_kernel<2, false, 2, 5>), dim3(tiles * nby), dim3(256), lds, s, a, nby);
-        } else switch (NG) {
-            case 1: hipLaunchKernelGGL(potts_energy_grad_kernel<1>, dim3(tiles * nby), dim3(256), lds, s, a, nby); break;
-            case 2: hipLaunchKernelGGL(potts_energy_grad_kernel<2>, dim3(tiles * nby), dim3(256), lds, s, a, nby); break;
-            default: hipLaunchKernelGGL(potts_energy_grad_kernel<4>, dim3(tiles * nby), dim3(256), lds, s, a, nby); break;
+        const dim3 grid(tiles * nby);
+        bool launched = false;
+        if (nc_spec && NG <= 2) {
+#define PPDE_PS(v) case v: if (NG == 1) hipLaunchKernelGGL((potts_energy_grad_kernel<1, false, 2, v>), grid, dim3(256), lds, s, a, nby); \
+                           else hipLaunchKernelGGL((potts_energy_grad_kernel<2, false, 2, v>), grid, dim3(256), lds, s, a, nby); launched = true; break;
+            switch (m->g.NC) { PPDE_PS(1) PPDE_PS(2) PPDE_PS(3) PPDE_PS(4) PPDE_PS(5) PPDE_PS(6) PPDE_PS(7) PPDE_PS(8) default: break; }
+#undef PPDE_PS
+        }
+        if (!launched) switch (NG) {
+            case 1: hipLaunchKernelGGL(potts_energy_grad_kernel<1>, grid, dim3(256), lds, s, a, nby); break;
+            case 2: hipLaunchKernelGGL(potts_energy_grad_kernel<2>, grid, dim3(256), lds, s, a, nby); break;
+            default: hipLaunchKernelGGL(potts_energy_grad_kernel<4>, grid, dim3(256), lds, s, a, nby); break;
         }
     }
     HIPCHK(hipGetLastError());

@@ -119,3 +119,46 @@ def test_batch_composition_does_not_change_a_bit(L, Lp, i0, with_cnn, n):
     for lo in range(0, n, 20):
         e2, f2, g2 = m.energy_grad(x[lo:lo + 20], which)
         assert torch.equal(e[lo:lo + 20], e2) and torch.equal(f[lo:lo + 20], f2) and torch.equal(g[lo:lo + 20], g2), lo
+
+
+_POTTS_WINDOWS = r"""
+import sys
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[1] + "/tests"); sys.path.insert(0, sys.argv[1] + "/oracle")
+import numpy as np, torch
+from test_hip_shapes import _model
+out = {}
+for Lp in (1, 3, 16, 17, 33, 50, 64, 65, 80, 97, 113, 128, 129, 145, 161, 180, 200, 210, 237, 241, 256, 260):
+    L = Lp + 9
+    m, wt, J, h, _ = _model(L, Lp, 4, False, 0.0, seed=Lp)
+    for n in (5, 70, 130):
+        idx = np.random.default_rng(Lp + n).integers(0, 20, (n, L)).astype(np.uint8)
+        e, f, g = m.energy_grad(torch.as_tensor(idx).cuda(), 1)
+        out[f"e_{Lp}_{n}"], out[f"g_{Lp}_{n}"] = e.cpu().numpy(), g.cpu().numpy()
+    m.close()
+np.savez(sys.argv[2], **out)
+"""
+
+
+def test_potts_instantiations_with_pinned_chunk_count_equal_the_general_kernels():
+    """Every Potts window of up to 256 residues runs an instantiation with its chunk count (1..16) as a compile-time constant
+    (potts.h NCC), resident slab and ring alike; PPDE_POTTS_SPEC=0 selects the general kernels (run-time chunk count), which
+    also serve longer windows. Same summation order: energies and gradients must be bit-identical (22 window lengths on both
+    sides of every chunk boundary, three batch sizes = one / two chain groups, ragged)."""
+    import os
+    import subprocess
+    import sys
+    import tempfile
+    REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    with tempfile.TemporaryDirectory() as d:
+        script = os.path.join(d, "windows.py")
+        open(script, "w").write(_POTTS_WINDOWS)
+        for spec in ("1", "0"):
+            out = os.path.join(d, f"spec{spec}.npz")
+            r = subprocess.run([sys.executable, script, REPO, out], capture_output=True, text=True, timeout=400,
+                               env=dict(os.environ, PPDE_POTTS_SPEC=spec))
+            assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+            res[spec] = dict(np.load(out))
+    assert len(res["1"]) == 2 * 22 * 3
+    for k in res["1"]:
+        assert np.isfinite(res["1"][k]).all() and np.array_equal(res["1"][k], res["0"][k]), k
