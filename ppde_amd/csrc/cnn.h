@@ -508,7 +508,14 @@ __device__ __forceinline__ void cnn_build_rows(const CnnNet& net, const uint8_t*
     }
 }
 
-template <int KT>
+// SHAPE: the network shape as compile-time constants (as PABP in cnn_body): 0 = run-time values, 1 = UBE4B_MOUSE (L = 104:
+// 104 channels padded to 128, 208 features, 100 rows), 2 = GFP_AEQVI (L = 237: 237 -> 256 channels, 474 -> 480 features,
+// 233 rows); five taps. The host selects 1 / 2 only for exactly those shapes.
+template <int SHAPE> struct CnnChunkShape {
+    static constexpr int T = SHAPE == 1 ? 100 : 233, CP = SHAPE == 1 ? 128 : 256, F = SHAPE == 1 ? 208 : 474, FP = SHAPE == 1 ? 208 : 480;
+    static constexpr int J = 100, JP = 112;
+};
+template <int KT, int SHAPE = 0>      // (SHAPE != 0 is NOT used by the host for this kernel: measured slower, see launch_cnn)
 __global__ __launch_bounds__(256, 2) void k_cnn_fwd_chunk(CnnChunkArgs ca) {
     warm_kernargs<sizeof(CnnChunkArgs)>();
     extern __shared__ unsigned char smem_raw[];
@@ -518,7 +525,8 @@ __global__ __launch_bounds__(256, 2) void k_cnn_fwd_chunk(CnnChunkArgs ca) {
     const int b = a.b_off + blockIdx.x, ni = blockIdx.y, c = blockIdx.z, tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const CnnNet net = a.net[ni];
-    const int T = a.T, CP = a.CP, FP = a.FP, AS = cnn_astride(CP), KSP = CP / 4;
+    const int T = SHAPE ? CnnChunkShape<SHAPE>::T : a.T, CP = SHAPE ? CnnChunkShape<SHAPE>::CP : a.CP, FP = SHAPE ? CnnChunkShape<SHAPE>::FP : a.FP;
+    const int AS = cnn_astride(CP), KSP = CP / 4;
     const int BW = (CP + 31) / 32;
     float* sH = (float*)smem_raw;
     uint32_t* sG = (uint32_t*)(sH + (size_t)rows * AS);              // [rows][BW] gate bits of this chunk's rows
@@ -575,7 +583,7 @@ __global__ __launch_bounds__(256, 2) void k_cnn_fwd_chunk(CnnChunkArgs ca) {
     PPDE_STAMP(a.dbg, 53, stamp);
 }
 
-template <int KT>
+template <int KT, int SHAPE = 0>
 __global__ __launch_bounds__(256, 2) void k_cnn_bwd_chunk(CnnChunkArgs ca) {
     warm_kernargs<sizeof(CnnChunkArgs)>();
     extern __shared__ unsigned char smem_raw[];
@@ -585,7 +593,9 @@ __global__ __launch_bounds__(256, 2) void k_cnn_bwd_chunk(CnnChunkArgs ca) {
     const int b = a.b_off + blockIdx.x, ni = blockIdx.y, c = blockIdx.z, tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const CnnNet net = a.net[ni];
-    const int T = a.T, CP = a.CP, F = a.F, FP = a.FP, J = a.J, JP = a.JP, AS = cnn_astride(CP), KSP = CP / 4;
+    using SH = CnnChunkShape<SHAPE ? SHAPE : 1>;
+    const int T = SHAPE ? SH::T : a.T, CP = SHAPE ? SH::CP : a.CP, F = SHAPE ? SH::F : a.F, FP = SHAPE ? SH::FP : a.FP;
+    const int J = SHAPE ? SH::J : a.J, JP = SHAPE ? SH::JP : a.JP, AS = cnn_astride(CP), KSP = CP / 4;
     const int OS = J, BW = (CP + 31) / 32;
     float* sD = (float*)smem_raw;                                     // [rows][AS] routed gradient
     float* sO = sD + (size_t)rows * AS;                               // [rows][J]
