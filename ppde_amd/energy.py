@@ -277,6 +277,37 @@ ESM2_CHECKPOINTS = {"transformer-S": ("esm2_t12_35M_UR50D", 20), "transformer-M"
                     "potts+transformer": ("esm2_t30_150M_UR50D", 20)}
 
 
+# how far from {0, 1} the entries of a straight-through sample `(x_soft + x_hard) - x_soft` may lie (rounding of the
+# two fp32 operations; the reference evaluates its experts AT those values, i.e. within this distance of the one-hot point)
+STRAIGHT_THROUGH_ATOL = 4e-7
+
+
+class _EnergyThroughAutograd(torch.autograd.Function):
+    """(e, fit) of `get_energy` as a node of the caller's autograd graph: forward = one evaluation with gradient on the
+    device, backward = that gradient times the incoming one (the supervised expert's own gradient is evaluated only if
+    somebody differentiates `fit`)."""
+
+    @staticmethod
+    def forward(ctx, x, owner):
+        hard = x.detach().round()
+        if float((x.detach() - hard).abs().max()) > STRAIGHT_THROUGH_ATOL:
+            raise ValueError("get_energy under autograd takes (straight-through) one-hot samples; relaxed inputs are not supported")
+        idx = owner.model.onehot_to_idx(hard)
+        e, fit, g = owner.model.energy_grad(idx, owner.which | WHICH_FULL_GRAD if owner.which & 4 else owner.which, True)
+        ctx.owner, ctx.idx, ctx.home = owner, idx, x.device
+        ctx.save_for_backward(g)
+        return e.to(x.device), fit.to(x.device)
+
+    @staticmethod
+    def backward(ctx, ge, gfit):
+        (g,) = ctx.saved_tensors
+        out = g * ge.to(g.device).reshape(-1, 1, 1)
+        if gfit is not None and bool((gfit != 0).any()):
+            _, _, gf = ctx.owner.model.energy_grad(ctx.idx, WHICH_SUPERVISED, True)
+            out = out + gf * gfit.to(g.device).reshape(-1, 1, 1)
+        return out.to(ctx.home), None
+
+
 class _HipEnergy(torch.nn.Module):
     which = WHICH_POE
 
@@ -317,6 +348,13 @@ class _HipEnergy(torch.nn.Module):
         return self.model.energy_grad(self.model.onehot_to_idx(x), which, want_grad)
 
     def get_energy(self, x):
+        """ppde/energy.py:97-101. On a plain tensor: (e, fit), no graph. On a tensor that is part of an autograd graph (the
+        relaxed-categorical baseline differentiates the energy of straight-through samples, mala_approx.py:69-75) the two
+        results are differentiable: backward hands the caller's graph d e / d x at the hard one-hot point, which is what
+        autograd through the reference's experts yields there -- with EVERY expert's term, also on the transformer branch
+        (the slice quirk of get_energy_and_grads, energy.py:125, does not exist in get_energy)."""
+        if torch.is_grad_enabled() and x.requires_grad:
+            return _EnergyThroughAutograd.apply(x, self)
         e, fit, _ = self._eval(x, self.which, False)
         return e, fit
 

@@ -204,6 +204,51 @@ def tf_ops_case(root, protein, lamda, state_seed, out):
     print("wrote", out, f"({os.path.getsize(out) / 1e3:.0f} kB)")
 
 
+def straight_through_case(root, protein, out):
+    """get_energy under autograd (energy.py:97-101), fed what the relaxed-categorical baseline feeds it: straight-through
+    samples `(x_soft + x_hard) - x_soft` drawn by the reference's own MALAApprox.straight_through_sample
+    (mala_approx.py:18-23, :36-42) -- one-hot up to an ulp. Frozen: those inputs, (e, fit), d e.sum() / d input and the
+    gradient of a weighted sum of e and fit, for the Potts product of experts and both transformer branches; and the
+    gradient the baseline itself obtains w.r.t. its logits (mala_approx.py:73-75)."""
+    import argparse
+    from ppde.energy import ProteinProductOfExperts
+    from ppde.protein_samplers.mala_approx import MALAApprox
+    n, tau = 6, 0.9
+    mala = MALAApprox(argparse.Namespace(diffusion_relaxation_tau=tau, diffusion_step_size=0.1))
+    payload = dict(protein=protein, potts_seed=7, tau=tau, **{"esm_" + k: v for k, v in STUB_ESM.items()})
+    for tag, unsup, lamda in (("p", "potts", 5.0), ("t", "transformer", 300.0), ("pt", "potts+transformer", 100.0)):
+        with quiet(), warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            en = ProteinProductOfExperts(ref_args(root, protein, n, lamda, unsup=unsup))
+            wt_idx = en.wt_onehot[0].argmax(-1).numpy().astype(np.uint8)
+            idx = random_states(wt_idx, n, np.random.default_rng(41), 4)
+            torch.manual_seed(77)
+            x_soft = (1 - tau) * (1.0 / 20) * torch.ones(n, len(wt_idx), 20) + tau * to_onehot(idx)
+            dist = torch.distributions.relaxed_categorical.RelaxedOneHotCategorical(torch.tensor([tau]), probs=x_soft)
+            logits = dist.logits.detach().requires_grad_()
+            dist = torch.distributions.relaxed_categorical.RelaxedOneHotCategorical(torch.tensor([tau]), logits=logits)
+            x_st = mala.straight_through_sample(dist)
+            e_chain, _ = en.get_energy(x_st)
+            logit_grad = torch.autograd.grad([e_chain.sum()], [logits])[0]
+            leaf = x_st.detach().clone().requires_grad_()
+            e, fit = en.get_energy(leaf)
+            g_e = torch.autograd.grad([e.sum()], [leaf], retain_graph=True)[0]
+            w_e, w_f = torch.rand(n) + 0.5, torch.rand(n) - 0.5
+            g_mix = torch.autograd.grad([(w_e * e + w_f * fit).sum()], [leaf])[0]
+        payload.update({f"{tag}_lamda": lamda, f"{tag}_x": leaf.detach().numpy(), f"{tag}_e": e.detach().numpy(),
+                        f"{tag}_fit": fit.detach().numpy(), f"{tag}_grad_e": g_e.numpy(), f"{tag}_w_e": w_e.numpy(),
+                        f"{tag}_w_fit": w_f.numpy(), f"{tag}_grad_mix": g_mix.numpy(),
+                        f"{tag}_baseline_logit_grad_absmax": float(logit_grad.abs().max())})
+        payload.update(wt_idx=wt_idx)
+        if unsup == "potts":
+            potts = en.unsupervised_expert
+            payload.update(win_start=int(potts.index_list[0]), Lp=int(potts.seq_len), J_sha=sha(potts.J.detach().numpy()))
+        print(f"  {unsup}: max |x - one-hot| {float((leaf.detach() - leaf.detach().round()).abs().max()):.2e}, "
+              f"|d e / d logits| of the baseline {float(logit_grad.abs().max()):.2e}, max |d e / d x| {float(g_e.abs().max()):.3f}")
+    np.savez_compressed(out, **payload)
+    print("wrote", out, f"({os.path.getsize(out) / 1e3:.0f} kB)")
+
+
 def file_sha(path):
     with open(path, "rb") as fh:
         return hashlib.sha256(fh.read()).hexdigest()
@@ -430,6 +475,11 @@ def main():
                      unsup="transformer")
             run_case(root, "TOY24", 100.0, 8, 20, 302, 2, 0, False, os.path.join(HERE, "run_tfpoe_toy_pt.npz"), store_q=False,
                      unsup="potts+transformer")
+        return
+    if only and "straight" in only:
+        with tempfile.TemporaryDirectory() as root:
+            synthetic.write_weights_dir(root, "TOY24", potts_seed=7)
+            straight_through_case(root, "TOY24", os.path.join(HERE, "ops_straight_through_toy.npz"))
         return
     if only and "script" in only:
         with tempfile.TemporaryDirectory() as root:

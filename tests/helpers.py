@@ -131,3 +131,54 @@ def real_pabp_cnn_states():
     fx = load("real_pabp_cnn.npz")
     names = ("encoder.weight", "encoder.bias", "embedding.0.weight", "embedding.0.bias", "decoder.weight", "decoder.bias")
     return [{k: fx[f"net{i}.{k}"] for k in names} for i in range(3)], [str(x) for x in fx["file_sha"]]
+
+
+def exact_pas_kernel(energy, wt_idx, positions, pas_length, min_pos, max_pos, nmut_threshold=0):
+    """The Markov kernel of ONE path-auxiliary iteration as an explicit matrix, from the oracle's own formulas: every start
+    state over the residues `positions` (all other residues stay wild type), every path length, every path of in-window
+    moves at those residues. K[x, y] = sum_U P(U) sum_paths P(path | x) * (a(path) [end = y] + (1 - a(path)) [x = y]),
+    a = min(1, exp(log_acc)): the accept test is exp(log_acc) >= u with u ~ U[0, 1). Nothing is sampled: the oracle is
+    steered down each path by race variates that make the wanted index win, and reports the path's proposal
+    probabilities and log_acc. Moves the clamp floor still allows outside `positions` (ppde/utils.py:106-111: a masked
+    entry keeps probability 2^-23 / sum) end in the extra last column. With a mutation cap the state a chain holds AFTER the
+    iteration is the wild type wherever the cap was reached (ppde.py:148-153).
+    Returns (K float64 [S, S + 1], states int64 [S, L]) with S = 20 ** len(positions)."""
+    import itertools
+    wt = torch.as_tensor(np.asarray(wt_idx)).long().reshape(-1)
+    L, P = wt.numel(), len(positions)
+    thr = np.iinfo(np.int32).max if nmut_threshold == 0 else nmut_threshold
+    S = A ** P
+    letters = np.array(list(itertools.product(range(A), repeat=P)), dtype=np.int64)            # [S, P], state index = base-20 number
+    states = wt.repeat(S, 1)
+    states[:, positions] = torch.as_tensor(letters)
+    weights = A ** np.arange(P - 1, -1, -1)
+    moves = np.array([p * A + k for p in positions for k in range(A)], dtype=np.int64)             # flat indices a path may take
+    K = np.zeros((S, S + 1))
+    n_len = 2 * pas_length - 1
+    for x in range(S):
+        for U in range(1, n_len + 1):
+            paths = np.array(list(itertools.product(range(len(moves)), repeat=U)), dtype=np.int64)  # [n_paths, U] -> indices into moves
+            flat = moves[paths]
+            c = flat.shape[0]
+            q = torch.full((U, c, L * A), 1e30)
+            for s in range(U):
+                q[s, torch.arange(c), torch.as_tensor(flat[:, s])] = 1e-30
+            start = states[x].repeat(c, 1)
+            out = orc.pas_iteration(energy, start, start, wt, torch.full((c,), U, dtype=torch.int64), q, torch.full((c,), 0.5),
+                                    min_pos, max_pos, thr, keep_probs=True)
+            assert np.array_equal(out["flat"].numpy().T, flat), "the steering variates did not select the wanted path"
+            pf = out["p_fwd"].double().numpy()                                                      # [U, c, N]
+            p_path = np.prod([pf[s, np.arange(c), flat[:, s]] for s in range(U)], axis=0)
+            a = np.minimum(1.0, np.exp(out["log_acc"].double().numpy()))
+            end = out["proposal"].clone()
+            dist = (end != wt).sum(1)
+            end[dist >= thr] = wt                                                                    # accepted, then reset
+            y = (end[:, positions].numpy() * weights).sum(1)
+            stay = x
+            if int((states[x] != wt).sum()) >= thr:
+                stay = int((wt[positions].numpy() * weights).sum())
+            w = p_path / n_len
+            np.add.at(K[x], y, w * a)
+            K[x, stay] += float((w * (1.0 - a)).sum())
+        K[x, S] = max(0.0, 1.0 - K[x, :S].sum())
+    return K, states

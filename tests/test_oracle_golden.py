@@ -202,3 +202,33 @@ def test_philox_known_answers():
     for c, k, out in kat:
         r = orc.philox4x32(np.array(c, dtype=np.uint32), np.array(k, dtype=np.uint32))
         assert tuple(int(v) for v in r) == out
+
+
+@pytest.mark.parametrize("tag,unsup", [("p", "potts"), ("t", "transformer"), ("pt", "potts+transformer")])
+def test_gradient_through_get_energy(tag, unsup):
+    """energy.py:97-101 under autograd, on the straight-through samples the reference's relaxed-categorical baseline feeds
+    it (fixture from the imported reference, make_golden.py straight): d e / d x through get_energy is the FULL gradient
+    (every expert's term, also on the transformer branches), and d fit / d x is the supervised expert's."""
+    import esm_oracle as eo
+    from helpers import esm_from_fixture, load, model_from_fixture
+    fx = load("ops_straight_through_toy.npz")
+    lam = float(fx[f"{tag}_lamda"])
+    J, h, i0, wt_idx, cnn = model_from_fixture(fx)
+    P = orc.PottsOracle(J, h, i0, torch.as_tensor(wt_idx.astype(np.int64))) if "potts" in unsup else None
+    tf = None
+    if "transformer" in unsup:
+        _, _, esm = esm_from_fixture(fx, False)
+        tf = eo.TransformerDelta(esm, wt_idx)
+    en = orc.EnergyOracle(P, orc.CnnOracle(cnn), lam, tf=tf, full_grad=True)
+    x = fx[f"{tag}_x"]
+    assert 0 < np.abs(x - np.round(x)).max() < 4e-7
+    idx = torch.as_tensor(np.round(x).argmax(-1))
+    e, fit, g = en.energy_grad(idx)
+    _, gf = orc.CnnOracle(cnn).fit_grad(idx)
+    scale = max(1.0, float(np.abs(fx[f"{tag}_grad_e"]).max()))
+    assert np.abs(e.numpy() - fx[f"{tag}_e"]).max() <= 2e-5 * (1 + np.abs(fx[f"{tag}_e"]).max())
+    assert np.abs(fit.numpy() - fx[f"{tag}_fit"]).max() <= 5e-6
+    assert np.abs(g.numpy() - fx[f"{tag}_grad_e"]).max() <= 1e-5 * scale
+    mix = torch.as_tensor(fx[f"{tag}_w_e"]).reshape(-1, 1, 1) * g + torch.as_tensor(fx[f"{tag}_w_fit"]).reshape(-1, 1, 1) * gf
+    assert np.abs(mix.numpy() - fx[f"{tag}_grad_mix"]).max() <= 2e-5 * scale
+    assert float(fx[f"{tag}_baseline_logit_grad_absmax"]) == 0.0

@@ -451,3 +451,59 @@ def test_driver_with_the_transformer_expert():
             assert eh.shape == (13, 6) and np.isfinite(eh).all() and pop.shape == (6, 24, 20)
             assert np.array_equal(np.load(os.path.join(out_dir, "energy_scores.npy")), eh.max(0))
             assert "[Iteration 4]" in buf.getvalue()
+
+
+@pytest.mark.parametrize("tag,unsup,which", [("p", "potts", 3), ("t", "transformer", 6), ("pt", "potts+transformer", 7)])
+def test_get_energy_under_autograd_vs_reference_fixture(tag, unsup, which):
+    """`get_energy` as the relaxed-categorical baseline uses it (mala_approx.py:69-75): fed straight-through samples that
+    belong to an autograd graph, differentiated by the caller. Fixture: the REFERENCE's get_energy on inputs its own
+    MALAApprox.straight_through_sample drew, and autograd through it (tests/golden/make_golden.py straight). The gradient
+    through get_energy carries every expert's term, also on the transformer branches."""
+    from helpers import esm_from_fixture, load, model_from_fixture
+    from ppde_amd.energy import HipModel, _HipEnergy
+    fx = load("ops_straight_through_toy.npz")
+    lam = float(fx[f"{tag}_lamda"])
+    J, h, i0, wt_idx, cnn = model_from_fixture(fx)
+    m = HipModel(wt_idx, "cuda:0")
+    if which & 1:
+        m.set_potts(J, h, i0)
+    m.set_cnn(cnn)
+    if which & 4:
+        st, g, _ = esm_from_fixture(fx, True)
+        m.set_transformer(st, g["heads"])
+    m.set_lamda(lam)
+    en = _HipEnergy()
+    en.model, en.which = m, which
+    x = torch.as_tensor(fx[f"{tag}_x"]).cuda().requires_grad_()
+    assert float((x.detach() - x.detach().round()).abs().max()) > 0          # (one-hot up to an ulp, not exactly)
+    e, fit = en.get_energy(x)
+    assert e.requires_grad and fit.requires_grad
+    g_e = torch.autograd.grad([e.sum()], [x], retain_graph=True)[0]
+    w_e, w_f = torch.as_tensor(fx[f"{tag}_w_e"]).cuda(), torch.as_tensor(fx[f"{tag}_w_fit"]).cuda()
+    g_mix = torch.autograd.grad([(w_e * e + w_f * fit).sum()], [x])[0]
+    assert np.abs(fit.detach().cpu().numpy() - fx[f"{tag}_fit"]).max() <= 5e-6
+    half = bool(which & 4)                                                  # fp16 matmuls on the transformer branches
+    e_ref, ge_ref, gm_ref = fx[f"{tag}_e"], fx[f"{tag}_grad_e"], fx[f"{tag}_grad_mix"]
+    if half:        # as _score_tol: relative to the RAW scores (state and wild type), whose difference the energy holds
+        wt_s = abs(float(np.ravel(load("ops_tfpoe_toy.npz")[f"{tag}_wt_score"])[0]))          # (same stand-in model, same wild type)
+        e_tol = 2 * 2e-3 * (1 + np.abs(e_ref - lam * fx[f"{tag}_fit"]) + wt_s)
+    else:
+        e_tol = 5e-6 * np.maximum(1.0, np.abs(e_ref))
+    e_tol = e_tol + 5e-6 * lam * (1 + np.abs(fx[f"{tag}_fit"]))
+    g_tol = 3e-2 * np.abs(ge_ref).max() if half else 2e-6 * max(1.0, lam)
+    assert observed(f"straight_{tag}:e", np.abs(e.detach().cpu().numpy() - e_ref), e_tol) <= 1.0
+    assert observed(f"straight_{tag}:grad_e", np.abs(g_e.cpu().numpy() - ge_ref).max(), g_tol) <= 1.0
+    assert observed(f"straight_{tag}:grad_mix", np.abs(g_mix.cpu().numpy() - gm_ref).max(), 1.5 * g_tol + 2e-6) <= 1.0
+    # the baseline's own use: straight-through of a relaxed sample; its logit gradient is exactly zero in the reference
+    # (the estimator is written (x_soft + x_hard) - x_soft: both paths to x_soft cancel), and so it is here
+    assert float(fx[f"{tag}_baseline_logit_grad_absmax"]) == 0.0
+    soft = torch.rand(x.shape, device="cuda").requires_grad_()
+    hard = torch.nn.functional.one_hot(x.detach().argmax(-1), 20).float()
+    e2, _ = en.get_energy((soft + hard) - soft)
+    assert float(torch.autograd.grad([e2.sum()], [soft])[0].abs().max()) == 0.0
+    # plain tensors: no graph, same numbers; relaxed inputs are refused
+    e3, fit3 = en.get_energy(x.detach().round())
+    assert not e3.requires_grad and torch.equal(e3, e.detach()) and torch.equal(fit3, fit.detach())
+    with pytest.raises(ValueError, match="one-hot"):
+        en.get_energy((0.9 * x.detach() + 0.005).requires_grad_())
+    m.close()
