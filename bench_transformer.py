@@ -91,7 +91,7 @@ def measure(args, rank, world, local, backend, steps, warmup, repeats, with_cpu,
 
     dt, dts = timed(bool(args.reuse_grad))
     dt_other = timed(not bool(args.reuse_grad))[0] if other_policy else None
-    # dominant kernel: tf_gemm_nt at the fc1 shape (bias + GELU epilogue), timed IN SITU: a HIP event pair around every fc1
+    # dominant kernel: the GEMM at the fc1 shape (bias + GELU epilogue; tf_gemm160, or tf_gemm_nt with PPDE_TF_160=0), timed IN SITU: a HIP event pair around every fc1
     # launch of one real evaluation (what rocprofv3's per-kernel average of the same command sees). The same kernel on
     # pseudo-random operands, launched back to back, is reported beside it: random fp16 data toggles more of the matrix
     # pipe and runs at a lower clock than the activations of a real evaluation do.
@@ -100,7 +100,10 @@ def measure(args, rank, world, local, backend, steps, warmup, repeats, with_cpu,
     us, nl = C.c_float(), C.c_int()
     _hip.check(_hip.load().ppde_transformer_time_fc1_in_situ(m.handle, _hip.ptr(x), n, C.byref(us), C.byref(nl)))
     us_rand = C.c_float()
-    _hip.check(_hip.load().ppde_transformer_time_gemm(local, M, F, D, 50, 3, C.byref(us_rand)))
+    use160 = os.environ.get("PPDE_TF_160", "1") != "0" and F % 160 == 0         # (tf_host.h: 160 x 160 tiles, rows padded to 1280)
+    M_launch = (n * L + 1279) // 1280 * 1280 if use160 else M
+    gemm_name = "tf_gemm160" if use160 else "tf_gemm_nt"
+    _hip.check(_hip.load().ppde_transformer_time_gemm(local, M_launch, F, D, 50, 3, C.byref(us_rand)))
     gemm_tf = 2.0 * M * F * D / (us.value * 1e-6) / 1e12
     # one evaluation on its own
     m.energy_grad(x, 4)
@@ -127,10 +130,10 @@ def measure(args, rank, world, local, backend, steps, warmup, repeats, with_cpu,
         "chain_steps_per_s": world * n * steps / dt,
         "timed_blocks": {"repeats": len(dts), "statistic": "median", "ms_per_block": [round(x * 1e3, 3) for x in dts]},
         "graph_captured_in_timed_region": False,
-        "roofline": {"kernel": "tf_gemm_nt<bias+GELU> (fc1 shape)", "bound": "mfma", "achieved": gemm_tf, "peak": MFMA_F16_PEAK_TF / 1.0,
+        "roofline": {"kernel": f"{gemm_name}<bias+GELU> (fc1 shape)", "bound": "mfma", "achieved": gemm_tf, "peak": MFMA_F16_PEAK_TF / 1.0,
                      "unit": "TFLOP/s", "frac": gemm_tf / MFMA_F16_PEAK_TF, "traffic": None,
                      "traffic_source": None, "algorithmic_flops_per_launch": 2.0 * M * F * D, "avg_launch_us": us.value,
-                     "launches_timed": nl.value, "shape": [M, F, D],
+                     "launches_timed": nl.value, "shape": [M, F, D], "rows_launched": M_launch,
                      "timing": "HIP event pair around every fc1 launch of one evaluation (in situ)",
                      "avg_launch_us_random_operands_back_to_back": us_rand.value},
         "evaluation": {"ms": ev * 1e3, "algorithmic_tflop": fl / 1e12, "tflops": fl / ev / 1e12,
@@ -138,7 +141,7 @@ def measure(args, rank, world, local, backend, steps, warmup, repeats, with_cpu,
     }
     if dt_other:
         out["value_reuse_grad" if not args.reuse_grad else "value_reevaluate"] = world * steps / dt_other
-    stats = rocprof_frac("transformer", "tf_gemm_nt<3,", 2.0 * M * F * D, MFMA_F16_PEAK_TF * 1e12)       # <3, ...> = the bias + GELU epilogue (fc1)
+    stats = rocprof_frac("transformer", "tf_gemm160<3>" if use160 else "tf_gemm_nt<3,", 2.0 * M * F * D, MFMA_F16_PEAK_TF * 1e12)   # <3 ...> = the bias + GELU epilogue (fc1)
     if stats:
         out["roofline"]["rocprof"] = stats
     if world > 1:

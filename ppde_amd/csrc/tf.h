@@ -300,6 +300,187 @@ __global__ __launch_bounds__(64 * NWAVE, 2) void tf_gemm_nt(TfGemmArgs g) {
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// The same product on 160 x 160 x 64 tiles: the largest square tile whose two 64-deep stage pairs fit a CU's LDS TWICE
+// (2 x 2 x 160 x 64 halfs = 80 KB per workgroup), so two 4-wave workgroups still share a CU and hide each other's epilogue as
+// in tf_gemm_nt, while a k step stages 40 KB for 3.3 MFLOP: 80 flop per staged byte against 64 (the k loop of the 128 x 128
+// kernel is bound by the chip's L2 -> LDS fill). Waves 2 x 2, each 80 x 80 = 5 x 5 MFMA tiles (100
+// accumulator registers; 10 fragment reads per 25 MFMAs against 8 per 16). Everything else is tf_gemm_nt: LDS-DMA staging with
+// the XOR swizzle on the source side, persistent XCD-contiguous tile walk, the second operand prefetched as whole rows,
+// the output staged through LDS. Same k order per output element: same bits.
+// Requirements (the host pads / dispatches): M % 160 == 0, N % 160 == 0, K % 64 == 0.
+// ------------------------------------------------------------------------------------------------------------
+__host__ __device__ constexpr size_t tf_gemm160_lds() { return (size_t)2 * 2 * 160 * 64 * 2; }
+
+template <int EPI>
+__global__ __launch_bounds__(256, 2) void tf_gemm160(TfGemmArgs g) {
+    constexpr int BT = 160, BK = 64, TILE = BT * BK, PPT = 5, MT = 5, WT = 80;   // tile edge, k depth, halfs per operand tile, DMA pieces per wave, MFMA tiles per wave edge, wave tile edge
+    constexpr int OCH = BT / 8, OLD = BT + 8;                    // 16-byte chunks per output row, padded row length of the staged tile
+    constexpr int NCHUNK = BT * OCH, RCH = (NCHUNK + 255) / 256; // chunks of the tile, per thread (the last round is partial)
+    extern __shared__ __attribute__((aligned(16))) unsigned char tf_smem[];
+    half_t* sA = (half_t*)tf_smem;                               // [2][160][64]
+    half_t* sB = sA + 2 * TILE;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int tiles_n = g.N / BT, tiles_total = (g.M / BT) * tiles_n;
+    const int K = g.K, nk = K / BK;
+    const int lr = lane >> 3, lc = lane & 7;
+    uint32_t voff[PPT];
+#pragma unroll
+    for (int i = 0; i < PPT; ++i) {
+        const int r = (wave * PPT + i) * 8 + lr;
+        voff[i] = (uint32_t)r * (uint32_t)(K * 2) + (uint32_t)((lc ^ (r & 7)) << 4);
+    }
+    const int fr = lane & 15, fg = lane >> 4;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, wpx = gridDim.x >> 3;
+    const int xq = tiles_total >> 3, xr = tiles_total & 7;
+    const int xbeg = xcd * xq + min(xcd, xr), xcnt = xq + (xcd < xr ? 1 : 0);
+    for (int ti = slot; ti < xcnt; ti += wpx) {
+    const int v = xbeg + ti;
+    const int m0 = (v / tiles_n) * BT, n0 = (v % tiles_n) * BT;
+    const half_t* baseA = g.A + (size_t)m0 * K;
+    const half_t* baseB = g.B + (size_t)n0 * K;
+    auto stage = [&](int buf, int kt) {
+        const half_t* ka = baseA + (size_t)kt * BK;
+        const half_t* kb = baseB + (size_t)kt * BK;
+#pragma unroll
+        for (int i = 0; i < PPT; ++i) {
+            const int p = wave * PPT + i;
+            tf_glds16(ka, voff[i], (uint32_t)(uintptr_t)(sA + buf * TILE + p * 512));
+            tf_glds16(kb, voff[i], (uint32_t)(uintptr_t)(sB + buf * TILE + p * 512));
+        }
+    };
+    tf_f32x4 acc[MT][MT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < MT; ++j) acc[i][j] = (tf_f32x4){0.f, 0.f, 0.f, 0.f};
+    auto compute = [&](int buf) {
+        const half_t* a = sA + buf * TILE + (wm * WT + fr) * BK;      // rows fr + 16 i + 80 wm: (row & 7) == (fr & 7)
+        const half_t* b = sB + buf * TILE + (wn * WT + fr) * BK;
+#pragma unroll
+        for (int s = 0; s < BK / 32; ++s) {
+            f16x8 af[MT], bf[MT];
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                af[i] = *(const f16x8*)(a + i * 16 * BK + (((s * 4 + fg) ^ (fr & 7)) << 3));
+                bf[i] = *(const f16x8*)(b + i * 16 * BK + (((s * 4 + fg) ^ (fr & 7)) << 3));
+            }
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < MT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j], af[i], acc[i][j], 0, 0, 0);
+        }
+    };
+    stage(0, 0);
+    for (int kt = 0; kt < nk; ++kt) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // k tile kt has landed (this wave's pieces)
+        __builtin_amdgcn_s_barrier();                                 // ... for every wave; buffer (kt + 1) & 1 is free
+        asm volatile("" ::: "memory");
+        if (kt + 1 < nk) stage((kt + 1) & 1, kt + 1);
+        compute(kt & 1);
+    }
+    // ---- epilogue (as tf_gemm_nt): the fp16 tile goes through LDS and leaves as whole rows, 16 bytes per lane
+    // (lane indices behind a zero the compiler cannot see through: the epilogue's address arithmetic is invariant over the
+    //  persistent tile loop and would otherwise be hoisted above the k loop, where it costs spills next to 100 accumulators)
+    const int oz = (EPI == TF_EPI_BIAS_RESID || EPI == TF_EPI_GELU_BWD) ? opaque_zero() : 0;   // (the others do not spill without it)
+    const int tide = tid + oz, lanee = lane + oz, fre = fr + oz, fge = fg + oz;
+    half_t* sOut = (half_t*)tf_smem;
+    static_assert((size_t)BT * OLD * 2 <= tf_gemm160_lds(), "the output tile is staged in the operand buffers");
+    constexpr bool NT_OUT = EPI == TF_EPI_BIAS_GELU || EPI == TF_EPI_BIAS_QSCALE;
+    auto flush = [&](half_t* dst, bool nt) {
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < RCH; ++u) {
+            const int c = tide + u * 256;
+            if (c < NCHUNK) {
+                const int row = c / OCH, ch = c % OCH;
+                const f16x8 val = *(const f16x8*)(sOut + row * OLD + ch * 8);
+                f16x8* gp = (f16x8*)(dst + (size_t)(m0 + row) * g.N + n0 + ch * 8);
+                if (nt) __builtin_nontemporal_store(val, gp);
+                else *gp = val;
+            }
+        }
+    };
+    __syncthreads();                                                  // every wave is done with the operand tiles
+    // the second operand (residual / pre-activation): its tile comes by LDS-DMA into the operand buffers (free now) as whole
+    // 320-byte rows -- 100 accumulators leave no registers to prefetch it in, and the co-resident workgroup covers the wait --,
+    // an unpadded [160][160] image whose 16-byte chunks are XOR-ed with the row (mod 4) on the source side, and is read from
+    // there in the accumulator layout
+    [[maybe_unused]] f16x4 rpre[MT][MT];
+    if constexpr (EPI == TF_EPI_BIAS_RESID || EPI == TF_EPI_GELU_BWD) {
+#pragma unroll
+        for (int u = 0; u < RCH; ++u) {
+            const int piece = wave + 4 * u, c = piece * 64 + lanee;        // 1-KiB pieces of the image, dealt round the waves
+            if (c < NCHUNK) {
+                const int row = c / OCH, ch = (c % OCH) ^ (row & 3);
+                const half_t* src = g.R + (size_t)(m0 + row) * g.N + n0 + ch * 8;
+                asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(src), "s"((uint32_t)(uintptr_t)(sOut + piece * 512)) : "memory");
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < MT; ++j) {
+                const int row = wm * WT + i * 16 + fre, col = wn * WT + j * 16 + 4 * fge;
+                rpre[i][j] = *(const f16x4*)(sOut + row * BT + ((((col >> 3) ^ (row & 3))) << 3) + (col & 7));
+            }
+        __syncthreads();
+    }
+    [[maybe_unused]] f16x4 second[MT][MT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        const int ml = wm * WT + i * 16 + fre;
+#pragma unroll
+        for (int j = 0; j < MT; ++j) {
+            const int nl = wn * WT + j * 16 + 4 * fge, n = n0 + nl;
+            float vv[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+            f16x4 out;
+            if constexpr (EPI == TF_EPI_PLAIN) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) out[r] = (half_t)vv[r];
+            } else if constexpr (EPI == TF_EPI_GELU_BWD) {
+                const f16x4 h = rpre[i][j];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) out[r] = (half_t)((float)(half_t)vv[r] * tf_gelu_grad((float)h[r]));
+            } else {
+                const float4 b4 = *(const float4*)(g.bias + n);
+                const float bb[4] = {b4.x, b4.y, b4.z, b4.w};
+#pragma unroll
+                for (int r = 0; r < 4; ++r) out[r] = (half_t)(vv[r] + bb[r]);
+                if constexpr (EPI == TF_EPI_BIAS_QSCALE) {
+                    if (n < g.qcols) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) out[r] = (half_t)((float)out[r] * g.alpha);
+                    }
+                } else if constexpr (EPI == TF_EPI_BIAS_RESID) {
+                    const f16x4 res = rpre[i][j];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) out[r] = (half_t)((float)out[r] + (float)res[r]);
+                } else if constexpr (EPI == TF_EPI_BIAS_GELU) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) second[i][j][r] = (half_t)tf_gelu((float)out[r]);
+                }
+            }
+            *(f16x4*)(sOut + ml * OLD + nl) = out;
+        }
+    }
+    if constexpr (EPI == TF_EPI_BIAS_GELU) {
+        flush(g.C2, NT_OUT);
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < MT; ++j) *(f16x4*)(sOut + (wm * WT + i * 16 + fre) * OLD + wn * WT + j * 16 + 4 * fge) = second[i][j];
+    }
+    flush(g.C, NT_OUT);      // (the fc1 activation too: kept in the caches for fc2 instead, an evaluation takes 30.4 ms against 30.0)
+    __syncthreads();                                                  // the staged tile has been read: the next tile may overwrite it
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
 // The same product on 256 x TN tiles (TN = 256 or 128), one 8-wave workgroup per CU (waves 4 x 2, each 64 x TN/2).
 //
 // Why larger tiles: the k loop of the 128 x 128 kernel is bound by the L2 -> LDS fill, not by the matrix pipe. A

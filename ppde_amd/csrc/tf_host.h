@@ -135,6 +135,9 @@ static int tf_build_model(TfModel* t, int L, const ppde_tf_weights* w) {
 // reference bounds the same memory by evaluating 64 chains at a time (8 for transformer-L; energy.py:77, :113-127); here the
 // budget is PPDE_TF_WORK_GB (default 48 GiB of the 288: 256 chains of UBE4B on esm2_t30_150M take 9.3 GiB, on esm2_t33_650M
 // 20 GiB) and larger populations are evaluated in chunks of that many chains (tf_eval): same numbers, chain by chain.
+static bool tf_use_160() { static const bool on = []() { const char* e = getenv("PPDE_TF_160"); return !e || atoi(e) != 0; }(); return on; }
+// rows of the padded token dimension: whole 256-row tiles (tf_gemm_big), and whole 160-row tiles too where those are in use
+static int tf_pad_rows(int M) { const int g = tf_use_160() ? 1280 : 256; return (M + g - 1) / g * g; }
 static size_t tf_bytes_per_chain(const TfModel* t) {
     const size_t D = t->D, F = t->F, L = t->L, H = t->H;
     const size_t per_layer = L * ((D + 3 * D + D + F) * sizeof(half_t) + 4 * sizeof(float)) + H * L * sizeof(float2);
@@ -151,7 +154,7 @@ static int tf_alloc_work(const TfModel* t, TfWork* wk, int n_chains) {
     const int D = t->D, F = t->F, L = t->L;
     const int n = std::min(n_chains, tf_chunk_cap(t));               // larger populations go through in chunks (tf_eval)
     wk->n_cap = n;
-    const int M = n * L, Mp = (M + 255) & ~255;                        // (whole 256-row GEMM tiles)
+    const int M = n * L, Mp = tf_pad_rows(M);                        // (whole 256-row GEMM tiles)
     wk->M_pad = Mp;
     bool ok = true;
     auto A = [&](auto** p, size_t count) {
@@ -202,6 +205,15 @@ static int tf_gemm(hipStream_t s, const half_t* A, const half_t* B, half_t* C, i
             HIPCHK(hipGetLastError());
             return PPDE_OK;
         }
+    }
+    // 160 x 160 tiles (tf_gemm160) wherever the shape allows: PPDE_TF_160=0 switches them off
+    // (not for the GELU' epilogue: its second operand cannot be prefetched next to 100 accumulators and arrives after the k loop,
+    //  in front of the most expensive arithmetic of all epilogues: 162 us against 142 at N = 2560, K = 640)
+    if (tf_use_160() && EPI != TF_EPI_GELU_BWD && M % 160 == 0 && N % 160 == 0) {
+        const int tiles = (M / 160) * (N / 160), tiles8 = (tiles + 7) & ~7;
+        hipLaunchKernelGGL(tf_gemm160<EPI>, dim3(std::min(tiles8, 512)), dim3(256), tf_gemm160_lds(), s, g);
+        HIPCHK(hipGetLastError());
+        return PPDE_OK;
     }
     // staged k depth x LDS buffers (tuning knob PPDE_TF_GEMM=64x2|64x3|32x2|32x3|32x4|64x2w8|32x3w8; default: the measured optimum)
     static const int variant = []() {
@@ -266,7 +278,7 @@ static thread_local TfEventList* g_tf_fc1_events = nullptr;
 // the scores w.r.t. the Potts one-hot input into grad_out rows [n][L*20] (fp32).
 static int tf_eval_chunk(const TfModel* t, TfWork* wk, const uint8_t* rows, int Ls, int sh, int n, float* score_out, float* grad_out, hipStream_t s) {
     ARGCHK(n <= wk->n_cap, "transformer workspace too small for this batch");
-    const int D = t->D, F = t->F, L = t->L, H = t->H, M = n * L, Mp = (M + 255) & ~255;
+    const int D = t->D, F = t->F, L = t->L, H = t->H, M = n * L, Mp = tf_pad_rows(M);
     const float qs = 1.0f / sqrtf((float)t->HD);
     hipLaunchKernelGGL(tf_embed, dim3(M), dim3(128), 0, s, rows, Ls, sh, L, n, t->perm, t->E16, D, wk->act[0].xin);
     HIPCHK(hipGetLastError());

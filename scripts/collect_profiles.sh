@@ -69,11 +69,11 @@ python3 "$ROOT/bench.py" --workload transformer > "$OUT/prof_${TAG}_tf_bench.log
 grep '^{' "$OUT/prof_${TAG}_tf_bench.log" > "$P/${TAG}_transformer_bench_stdout.log"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_${TAG}_tf" -- python3 "$ROOT/bench.py" --workload transformer --steps 4 --warmup 1 --repeats 1 --no-cpu-baseline > "$OUT/prof_${TAG}_tf.log" 2>&1
 cp "$(ls -t "$OUT"/prof_${TAG}_tf/*/*kernel_stats.csv | head -1)" "$P/${TAG}_transformer_kernel_stats.csv"
-python3 "$ROOT/scripts/tune_tf_gemm.py" 64x2 big 64x2w8 2>&1 | grep -v amdgpu.ids > "$P/${TAG}_transformer_gemm_variants.log" || true
-for b in 0 1; do PPDE_TF_BIG=$b python3 "$ROOT/bench.py" --workload transformer --steps 4 --warmup 1 --repeats 2 --no-cpu-baseline 2>/dev/null | grep '^{' > "$P/${TAG}_transformer_bench_big${b}.log" || true; done
+python3 "$ROOT/scripts/tune_tf_gemm.py" 160 64x2 big 64x2w8 2>&1 | grep -v amdgpu.ids > "$P/${TAG}_transformer_gemm_variants.log" || true
+for b in 0 1; do PPDE_TF_160=0 PPDE_TF_BIG=$b python3 "$ROOT/bench.py" --workload transformer --steps 4 --warmup 1 --repeats 2 --no-cpu-baseline 2>/dev/null | grep '^{' > "$P/${TAG}_transformer_bench_big${b}.log" || true; done
 # vendor yardsticks at the same shapes (torch's GEMM and attention; nothing in the product calls them)
-{ echo "# python scripts/probes/hipblaslt_yardstick.py ; python scripts/tune_tf_gemm.py 64x2 | grep plain   (vendor = torch.nn.functional.linear, fp16; 64x2 = tf_gemm_nt)";
-  python3 "$ROOT/scripts/probes/hipblaslt_yardstick.py" 2>&1 | grep -v amdgpu.ids; python3 "$ROOT/scripts/tune_tf_gemm.py" 64x2 2>&1 | grep plain; } > "$P/${TAG}_gemm_vendor_yardstick.log" || true
+{ echo "# python scripts/probes/hipblaslt_yardstick.py ; python scripts/tune_tf_gemm.py 160 64x2 | grep plain   (vendor = torch.nn.functional.linear, fp16; 160x160 = tf_gemm160, 64x2 = tf_gemm_nt)";
+  python3 "$ROOT/scripts/probes/hipblaslt_yardstick.py" 2>&1 | grep -v amdgpu.ids; python3 "$ROOT/scripts/tune_tf_gemm.py" 160 64x2 2>&1 | grep plain; } > "$P/${TAG}_gemm_vendor_yardstick.log" || true
 { echo "# python scripts/probes/sdpa_yardstick.py   (torch scaled_dot_product_attention, fp16, 256 x 20 heads x 104 x 32; compare tf_attn_fwd / tf_attn_bwd in ${TAG}_transformer_kernel_stats.csv, which also apply the rotary embedding)";
   python3 "$ROOT/scripts/probes/sdpa_yardstick.py" 2>&1 | grep -v amdgpu.ids; } > "$P/${TAG}_attention_vendor_yardstick.log" || true
 echo "transformer done"
