@@ -10,7 +10,8 @@
 // fp32 on the matrix cores (v_mfma_f32_16x16x32_f16), activations and activation gradients are stored in fp16 where
 // autocast hands fp16 tensors on, softmax / layer norm / log-softmax statistics are fp32.
 //
-// Kernels: tf_gemm_nt (all linear layers, forward and backward, fused bias / residual / GELU / GELU' epilogues),
+// Kernels: tf_gemm160 / tf_gemm_nt (all linear layers, forward and backward, fused bias / residual / GELU / GELU' epilogues; 160 x 160
+// tiles where the shape allows, else 128 x 128; tf_gemm_big: an opt-in 256-row variant),
 // tf_attn_fwd / tf_attn_bwd (one workgroup of four waves per (chain, head): rotary, QK^T, softmax, PV and their gradients
 // on the matrix cores; instances for sequences up to 128 / 256 residues and head widths 24 / 32 / 64), tf_ln_fwd / tf_ln_bwd, tf_embed, tf_score (log-softmax, score, gradient seeds), tf_finish_grad.
 #pragma once
