@@ -886,6 +886,117 @@ __global__ __launch_bounds__(256) void tf_ln_bwd(TfLnArgs a) {
     }
 }
 
+// The same two kernels with a row spread over SIXTEEN lanes (four rows per wavefront): NCH chunks of 8 halfs per lane, all of
+// a lane's loads in flight at once, the row sums by four DPP steps inside the 16-lane row. At D = 640 a row is 80 chunks:
+// five per lane and every lane busy, where the one-row-per-wavefront form has 64 lanes on the first chunk and 16 on the second.
+__device__ __forceinline__ float tf_row16_sum(float v) {
+    v += dpp_f<DPP_XOR1>(v);
+    v += dpp_f<DPP_XOR2>(v);
+    v += dpp_f<DPP_HALF_MIRROR>(v);
+    v += dpp_f<DPP_MIRROR>(v);
+    return v;
+}
+template <int NCH>
+__global__ __launch_bounds__(256) void tf_ln_fwd16(TfLnArgs a) {
+    const int lane = threadIdx.x & 63, sub = lane & 15;
+    const int row = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 4 + (lane >> 4);
+    const bool live = row < a.M;                                      // (lanes of rows past the end idle through the DPP steps)
+    const int nc = a.D >> 3;
+    const f16x8* xr = (const f16x8*)(a.x + (size_t)min(row, a.M - 1) * a.ld);
+    float v[NCH][8];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const int c = sub + 16 * i;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[i][e] = 0.f;
+        if (c < nc) {
+            const f16x8 t = xr[c];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { v[i][e] = (float)t[e]; s += v[i][e]; }
+        }
+    }
+    const float mean = tf_row16_sum(s) / (float)a.D;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i)
+        if (sub + 16 * i < nc) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { const float d = v[i][e] - mean; q += d * d; }
+        }
+    const float rstd = 1.0f / sqrtf(tf_row16_sum(q) / (float)a.D + 1e-5f);
+    if (!live) return;
+    f16x8* yr = (f16x8*)(a.y + (size_t)row * a.ld);
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const int c = sub + 16 * i;
+        if (c < nc) {
+            float ga[8], be[8];
+            tf_load8(a.gamma + 8 * c, ga);
+            tf_load8(a.beta + 8 * c, be);
+            f16x8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = (half_t)((v[i][e] - mean) * rstd * ga[e] + be[e]);
+            yr[c] = o;
+        }
+    }
+    if (sub == 0) { a.mean[row] = mean; a.rstd[row] = rstd; }
+}
+template <int NCH>
+__global__ __launch_bounds__(256) void tf_ln_bwd16(TfLnArgs a) {
+    const int lane = threadIdx.x & 63, sub = lane & 15;
+    const int row = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 4 + (lane >> 4);
+    const bool live = row < a.M;
+    const int rr_ = min(row, a.M - 1);
+    const int nc = a.D >> 3;
+    const f16x8* xr = (const f16x8*)(a.x + (size_t)rr_ * a.ld);
+    const f16x8* dr = (const f16x8*)(a.dy + (size_t)rr_ * a.ld);
+    const f16x8* rr = a.gres ? (const f16x8*)(a.gres + (size_t)rr_ * a.ld) : nullptr;
+    const float mean = a.mean[rr_], rstd = a.rstd[rr_];
+    f16x8 tx[NCH], td[NCH], tr[NCH];                                   // raw rows: every load is issued before the first value is used
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const int c = min(sub + 16 * i, nc - 1);
+        tx[i] = xr[c]; td[i] = dr[c];
+        tr[i] = rr ? rr[c] : (f16x8){0, 0, 0, 0, 0, 0, 0, 0};
+    }
+    float xh[NCH][8], gg[NCH][8];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const int c = sub + 16 * i;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) xh[i][e] = gg[i][e] = 0.f;
+        if (c < nc) {
+            float ga[8];
+            tf_load8(a.gamma + 8 * c, ga);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                xh[i][e] = ((float)tx[i][e] - mean) * rstd;
+                gg[i][e] = (float)td[i][e] * ga[e];
+                s1 += gg[i][e];
+                s2 += gg[i][e] * xh[i][e];
+            }
+        }
+    }
+    const float m1 = tf_row16_sum(s1) / (float)a.D, m2 = tf_row16_sum(s2) / (float)a.D;
+    if (!live) return;
+    f16x8* yr = (f16x8*)(a.y + (size_t)row * a.ld);
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const int c = sub + 16 * i;
+        if (c < nc) {
+            f16x8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                o[e] = (half_t)(rstd * (gg[i][e] - m1 - xh[i][e] * m2) + (float)tr[i][e]);
+                if (a.out_scale != 1.0f) o[e] = (half_t)((float)o[e] * a.out_scale);
+            }
+            yr[c] = o;
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------------------
 // Embedding of residue letters: x[m][:] = fp16(E16[token(m)][:] * 0.88)  (one-hot @ E under autocast picks the fp16 row;
 // ESM-2's token-dropout rescale follows). idx in state layout.

@@ -248,6 +248,19 @@ static int tf_ln(hipStream_t s, bool bwd, const half_t* x, half_t* y, const floa
                  int M, int D, int ld, const half_t* dy = nullptr, const half_t* gres = nullptr, float out_scale = 1.f) {
     TfLnArgs a{x, y, gamma, beta, mean, rstd, dy, gres, M, D, ld, out_scale};
     ARGCHK(D % 8 == 0 && D <= TF_LN_MAXD, "layer-norm width");
+    // sixteen lanes per row (tf_ln_fwd16 / tf_ln_bwd16) where a lane's share is at most 10 chunks; PPDE_TF_LN16=0: one row per wavefront
+    static const bool ln16 = []() { const char* e = getenv("PPDE_TF_LN16"); return !e || atoi(e) != 0; }();
+    const int nch = ((D >> 3) + 15) / 16;
+    // (measured at D = 640: forward 15.6 -> 14.0 us per launch, backward 24.7 either way -- it moves 136 MB at 5.5 TB/s; the
+    //  backward keeps the sixteen-lane form only while a lane's three row copies fit 128 registers)
+    if (ln16 && (bwd ? nch <= 5 : nch <= 10)) {
+        const dim3 grid((M + 15) / 16);
+        if (bwd) hipLaunchKernelGGL(tf_ln_bwd16<5>, grid, dim3(256), 0, s, a);
+        else if (nch <= 5) hipLaunchKernelGGL(tf_ln_fwd16<5>, grid, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL(tf_ln_fwd16<10>, grid, dim3(256), 0, s, a);
+        HIPCHK(hipGetLastError());
+        return PPDE_OK;
+    }
     const bool wide = D > 1024;                                      // three 16-byte chunks per lane instead of two
     if (bwd && wide) hipLaunchKernelGGL(tf_ln_bwd<3>, dim3((M + 3) / 4), dim3(256), 0, s, a);
     else if (bwd) hipLaunchKernelGGL(tf_ln_bwd<2>, dim3((M + 3) / 4), dim3(256), 0, s, a);
