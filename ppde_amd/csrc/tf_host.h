@@ -207,9 +207,10 @@ static int tf_gemm(hipStream_t s, const half_t* A, const half_t* B, half_t* C, i
         }
     }
     // 160 x 160 tiles (tf_gemm160) wherever the shape allows: PPDE_TF_160=0 switches them off
-    // (not for the GELU' epilogue: its second operand cannot be prefetched next to 100 accumulators and arrives after the k loop,
-    //  in front of the most expensive arithmetic of all epilogues: 162 us against 142 at N = 2560, K = 640)
-    if (tf_use_160() && EPI != TF_EPI_GELU_BWD && M % 160 == 0 && N % 160 == 0) {
+    // (the GELU' epilogue too: back to back on random operands it is slower on these tiles -- its second operand cannot be
+    //  prefetched next to 100 accumulators and arrives after the k loop: 148-162 us against 142 at N = 2560, K = 640 --, inside
+    //  an evaluation it is not: 62.6 ms per step against 62.95, A/B/A/B on one box)
+    if (tf_use_160() && M % 160 == 0 && N % 160 == 0) {
         const int tiles = (M / 160) * (N / 160), tiles8 = (tiles + 7) & ~7;
         hipLaunchKernelGGL(tf_gemm160<EPI>, dim3(std::min(tiles8, 512)), dim3(256), tf_gemm160_lds(), s, g);
         HIPCHK(hipGetLastError());

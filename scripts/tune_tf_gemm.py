@@ -22,7 +22,7 @@ if os.environ.get("TF_TUNE_CHILD"):
             _hip.check(lib.ppde_transformer_time_gemm(0, M, N, K, 30, epi, C.byref(us)))
             print(f"{'160x160' if os.environ.get('PPDE_TF_160') == '1' else os.environ.get('PPDE_TF_GEMM', 'default'):8s} big={os.environ.get('PPDE_TF_BIG', '1')} M={M} N={N:5d} K={K:5d} {name:10s}: {us.value:8.1f} us  {2.0 * M * N * K / us.value / 1e6:7.1f} TFLOP/s", flush=True)
     sys.exit(0)
-# variants: "160" = tf_gemm160 (the default wherever N % 160 == 0, except GELU'); "64x2" ... = the 128 x 128 kernel's staging;
+# variants: "160" = tf_gemm160 (the default wherever N % 160 == 0); "64x2" ... = the 128 x 128 kernel's staging;
 # "big" = 256-row tiles where the shape allows
 for v in (sys.argv[1:] or ("160", "64x2", "big", "64x3", "32x2", "32x3", "32x4", "64x2w8", "32x3w8")):
     env = dict(os.environ, TF_TUNE_CHILD="1", PPDE_TF_160="0", PPDE_TF_BIG="0")
