@@ -1609,6 +1609,186 @@ __global__ __launch_bounds__(64 * TF_ATT_WAVES_B, (TP == 128 && HD == 32) ? 2 : 
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// The same backward for sequences of up to 128 residues at head width 32 (config 5) with the dK / dV products handed to KEY
+// OWNERS. tf_attn_bwd above keeps, per wave, accumulators for dK and dV of ALL key tiles (128 registers of 226) and is held at
+// two waves per SIMD; the counters (profiles/r03_attention_pmc.txt) show it waiting, not computing. Here the query tiles are
+// taken in rounds of four (one per wave); a wave builds P and dS of its query tile against all keys and dQ exactly as above,
+// then the 16 x 16 tiles go through the per-wave transpose tiles in LDS as before -- but are read back by the wave that OWNS
+// the key tile (key tile 4 b + w belongs to wave w in batch b), which multiplies them with the query tile's q and dO. A wave
+// accumulates dK, dV of its two key tiles only (32 registers), no sums are exchanged at the end, the row-major LDS images
+// suffice (transposed operands by ds_read_b64_tr_b16): 49 KB of LDS and <= 168 registers, THREE workgroups per CU.
+// dK / dV of a key tile are summed over the query tiles in ascending order (a fixed order: deterministic).
+// ------------------------------------------------------------------------------------------------------------
+template <int TP, int HD> __host__ __device__ constexpr size_t tf_attn_bwd_ko_lds() {
+    return (size_t)(4 * TP * HD + TF_ATT_WAVES_B * TF_ATT_TRB * 512) * 2 + TP * sizeof(float2);
+}
+template <int TP, int HD>
+__global__ __launch_bounds__(64 * TF_ATT_WAVES_B, 3) void tf_attn_bwd_ko(TfAttnArgs a) {
+    static_assert(TP == 128 && HD == 32 && TF_ATT_WAVES_B == 4 && TF_ATT_TRB == 4, "one key tile per wave and batch");
+    constexpr int HL = HD, NKT = TP / 16, ND = HL / 16, NDH = ND / 2, TRB = TF_ATT_TRB;
+    extern __shared__ __attribute__((aligned(16))) unsigned char tf_smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int b = blockIdx.x / a.H, h = blockIdx.x % a.H;
+    const int L = a.L, D = a.D, ld = 3 * D;
+    half_t* sV = (half_t*)tf_smem;                             // [TP][HL]
+    half_t* sdO = sV + TP * HL;
+    half_t* sK = sdO + TP * HL;                                // rotated k
+    half_t* sQ = sK + TP * HL;                                 // rotated q
+    half_t* sTall = sQ + TP * HL;                              // [wave][TRB][(dS, P)][16 x 16] transpose tiles
+    half_t* sT = sTall + wave * TRB * 512;
+    float2* sStat = (float2*)(sTall + TF_ATT_WAVES_B * TRB * 512);
+    const half_t* base = a.qkv + (size_t)b * L * ld + h * HD;
+    const half_t* dob = a.dctx + (size_t)b * L * D + h * HD;
+    half_t* dq_out = a.dqkv + (size_t)b * L * ld + h * HD;
+    const int fr = lane & 15, fg = lane >> 4;
+    const int NQ = (L + 15) >> 4, NK = NQ;
+    typedef __attribute__((address_space(3))) tf_hfx4* lds_tr_ptr;
+    const int tr_off = (4 * fg + (fr >> 2)) * 16 + 4 * (fr & 3);
+    // A operand X^T [d = 16 dj + fr][k = 16 t + 4 fg ..] of the 16x16x16 MFMA from the row-major tile X [16 t + ..][16 dj + ..]
+    auto tr_operand = [&](const half_t* rows, int dj, int t) -> f16x4 {
+        const tf_hfx4 v = __builtin_amdgcn_ds_read_tr16_b64_v4f16((lds_tr_ptr)(rows + (t * 16 + 4 * fg + (fr >> 2)) * HL + dj * 16 + 4 * (fr & 3)));
+        f16x4 o;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] = (half_t)v[r];
+        return o;
+    };
+    {
+        constexpr int NT = 64 * TF_ATT_WAVES_B;
+        TfRotRaw<NT, TP, HD> rq, rk;
+        TfRope<NT, TP, HD> rp;
+        TfPlainRaw<NT, TP, HD> rv, ro;
+        tf_fetch_plain(base + 2 * D, ld, L, tid, rv);
+        tf_fetch_plain(dob, D, L, tid, ro);
+        tf_fetch_rot(base + D, ld, L, tid, rk);
+        tf_fetch_rot(base, ld, L, tid, rq);
+        tf_fetch_rope(a.rope_cos, a.rope_sin, L, tid, rp);
+        tf_put_plain<false>(rv, L, tid, sV);
+        tf_put_plain<false>(ro, L, tid, sdO);
+        tf_put_rot<true, false>(rk, rp, L, tid, sK, nullptr);
+        tf_put_rot<true, false>(rq, rp, L, tid, sQ, nullptr);
+        for (int t = tid; t < TP; t += NT) sStat[t] = t < L ? a.stat[(size_t)(b * a.H + h) * L + t] : make_float2(0.f, 0.f);
+    }
+    __syncthreads();
+    tf_f32x4 accK[ND][2], accV[ND][2];                                   // [head-width tile][batch]: key tile 4 * batch + wave
+#pragma unroll
+    for (int dj = 0; dj < ND; ++dj)
+#pragma unroll
+        for (int bb = 0; bb < 2; ++bb) { accK[dj][bb] = (tf_f32x4){0.f, 0.f, 0.f, 0.f}; accV[dj][bb] = (tf_f32x4){0.f, 0.f, 0.f, 0.f}; }
+    for (int q0 = 0; q0 < NQ; q0 += TF_ATT_WAVES_B) {                    // a round: query tiles q0 .. q0 + 3, one per wave
+        const int qi = q0 + wave;
+        f16x4 pt[NKT], ds[NKT];
+#pragma unroll
+        for (int j = 0; j < NKT; ++j) { ds[j] = (f16x4){0, 0, 0, 0}; pt[j] = (f16x4){0, 0, 0, 0}; }
+        if (qi < NQ) {
+            const int q = qi * 16 + fr;
+            const float2 st = sStat[qi * 16 + fr];
+            float delta = 0.f;
+#pragma unroll
+            for (int j = 0; j < NKT; ++j) {
+                if (j < NK) {
+                    const tf_f32x4 dp = tf_tile_kq<HL>(sV + (j * 16 + fr) * HL, sdO + (qi * 16 + fr) * HL, fg);   // dP^T [key][query]
+                    const tf_f32x4 sc = tf_tile_kq<HL>(sK + (j * 16 + fr) * HL, sQ + (qi * 16 + fr) * HL, fg);    // the forward's scores again
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int key = j * 16 + 4 * fg + r;
+                        const float sv = key < L ? (float)(half_t)sc[r] : -INFINITY;
+                        pt[j][r] = (half_t)(__expf(sv - st.x) * st.y);
+                        ds[j][r] = (half_t)dp[r];
+                        delta += (float)ds[j][r] * (float)pt[j][r];
+                    }
+                }
+            }
+            delta = tf_quad_rows_sum(delta);
+            tf_f32x4 o[ND];
+#pragma unroll
+            for (int dj = 0; dj < ND; ++dj) o[dj] = (tf_f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < NKT; ++j)
+                if (j < NK) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) ds[j][r] = (half_t)((float)pt[j][r] * ((float)ds[j][r] - delta));
+#pragma unroll
+                    for (int dj = 0; dj < ND; ++dj)                   // dQ^T [d][query] += Kr^T (rows d, k = these keys) x dS^T
+                        o[dj] = __builtin_amdgcn_mfma_f32_16x16x16f16(tr_operand(sK, dj, j), ds[j], o[dj], 0, 0, 0);
+                }
+            if (q < L) {
+#pragma unroll
+                for (int dj = 0; dj < NDH; ++dj) {                     // rotary transpose on (d, d + HD/2), then the q scaling
+                    const int c1 = tf_gcol<HD>(dj, fg), c2 = tf_gcol<HD>(dj + NDH, fg), rcol = tf_rope_col<HD>(dj, fg);
+                    f16x4 o1, o2;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float co = a.rope_cos[q * (HD / 2) + rcol + r], si = a.rope_sin[q * (HD / 2) + rcol + r];
+                        const float y1 = (float)(half_t)o[dj][r], y2 = (float)(half_t)o[dj + NDH][r];
+                        o1[r] = (half_t)((float)(half_t)(y1 * co + y2 * si) * a.qscale);
+                        o2[r] = (half_t)((float)(half_t)(y2 * co - y1 * si) * a.qscale);
+                    }
+                    *(f16x4*)(dq_out + (size_t)q * ld + c1) = o1;
+                    *(f16x4*)(dq_out + (size_t)q * ld + c2) = o2;
+                }
+            }
+        }
+        // dK^T [d][key] += Qr^T (rows d, k = query) x dS (k = query on the rows), dV^T += dO^T x P: by the key tile's owner
+#pragma unroll
+        for (int bb = 0; bb < 2; ++bb) {
+            if (4 * bb >= NK) break;
+#pragma unroll
+            for (int u = 0; u < TRB; ++u) {                              // my query tile's dS and P against key tiles 4 bb .. 4 bb + 3
+                *(f16x4*)(sT + u * 512 + fr * 16 + 4 * fg) = ds[4 * bb + u];
+                *(f16x4*)(sT + u * 512 + 256 + fr * 16 + 4 * fg) = pt[4 * bb + u];
+            }
+            tf_lds_barrier();
+            if (4 * bb + wave < NK) {
+                for (int sw = 0; sw < TF_ATT_WAVES_B; ++sw) {            // the four query tiles of the round, in ascending order
+                    const int qs = q0 + sw;
+                    if (qs >= NQ) break;
+                    const half_t* src = sTall + sw * TRB * 512 + wave * 512;
+                    const tf_hfx4 dsq_ = __builtin_amdgcn_ds_read_tr16_b64_v4f16((lds_tr_ptr)(src + tr_off));
+                    const tf_hfx4 pq_ = __builtin_amdgcn_ds_read_tr16_b64_v4f16((lds_tr_ptr)(src + 256 + tr_off));
+                    f16x4 dsq, pq;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { dsq[r] = (half_t)dsq_[r]; pq[r] = (half_t)pq_[r]; }
+#pragma unroll
+                    for (int dj = 0; dj < ND; ++dj) {
+                        accK[dj][bb] = __builtin_amdgcn_mfma_f32_16x16x16f16(tr_operand(sQ, dj, qs), dsq, accK[dj][bb], 0, 0, 0);
+                        accV[dj][bb] = __builtin_amdgcn_mfma_f32_16x16x16f16(tr_operand(sdO, dj, qs), pq, accV[dj][bb], 0, 0, 0);
+                    }
+                }
+            }
+            tf_lds_barrier();                                            // the tiles have been read: the next batch may overwrite them
+        }
+    }
+    // the owner writes its key tiles: rotary transpose on dK, then the stores
+#pragma unroll
+    for (int bb = 0; bb < 2; ++bb) {
+        const int j = 4 * bb + wave, key = j * 16 + fr;
+        if (j < NK && key < L) {
+#pragma unroll
+            for (int dj = 0; dj < NDH; ++dj) {
+                const int c1 = tf_gcol<HD>(dj, fg), c2 = tf_gcol<HD>(dj + NDH, fg), rcol = tf_rope_col<HD>(dj, fg);
+                f16x4 k1, k2, v1, v2;
+                float co[4], si[4];
+                *(float4*)co = *(const float4*)(a.rope_cos + key * (HD / 2) + rcol);
+                *(float4*)si = *(const float4*)(a.rope_sin + key * (HD / 2) + rcol);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float y1 = (float)(half_t)accK[dj][bb][r], y2 = (float)(half_t)accK[dj + NDH][bb][r];
+                    k1[r] = (half_t)(y1 * co[r] + y2 * si[r]);
+                    k2[r] = (half_t)(y2 * co[r] - y1 * si[r]);
+                    v1[r] = (half_t)accV[dj][bb][r];
+                    v2[r] = (half_t)accV[dj + NDH][bb][r];
+                }
+                *(f16x4*)(dq_out + (size_t)key * ld + D + c1) = k1;
+                *(f16x4*)(dq_out + (size_t)key * ld + D + c2) = k2;
+                *(f16x4*)(dq_out + (size_t)key * ld + 2 * D + c1) = v1;
+                *(f16x4*)(dq_out + (size_t)key * ld + 2 * D + c2) = v2;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
 // Score and gradient seeds from the logits (fp16, [M][TF_VOCAB_PAD]): one workgroup per chain, one thread per
 // residue. logp = log_softmax over the 33 tokens (fp32); score[b] = sum_l logp[l][token_l] (fixed tree);
 // dlogits[l][k] = [k == token_l] - softmax[l][k]  (d score / d logits, through x * log_softmax);

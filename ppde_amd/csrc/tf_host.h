@@ -135,6 +135,9 @@ static int tf_build_model(TfModel* t, int L, const ppde_tf_weights* w) {
 // reference bounds the same memory by evaluating 64 chains at a time (8 for transformer-L; energy.py:77, :113-127); here the
 // budget is PPDE_TF_WORK_GB (default 48 GiB of the 288: 256 chains of UBE4B on esm2_t30_150M take 9.3 GiB, on esm2_t33_650M
 // 20 GiB) and larger populations are evaluated in chunks of that many chains (tf_eval): same numbers, chain by chain.
+// attention backward with the dK / dV products handed to key owners (tf_attn_bwd_ko: three workgroups per CU; 117 us per launch
+// against 151 at config 5's shape); PPDE_TF_ATT_KO=0: every wave accumulates dK / dV of all keys (tf_attn_bwd)
+static bool tf_att_key_owner() { static const bool on = []() { const char* e = getenv("PPDE_TF_ATT_KO"); return !e || atoi(e) != 0; }(); return on; }
 static bool tf_use_160() { static const bool on = []() { const char* e = getenv("PPDE_TF_160"); return !e || atoi(e) != 0; }(); return on; }
 // rows of the padded token dimension: whole 256-row tiles (tf_gemm_big), and whole 160-row tiles too where those are in use
 static int tf_pad_rows(int M) { const int g = tf_use_160() ? 1280 : 256; return (M + g - 1) / g * g; }
@@ -350,6 +353,7 @@ static int tf_eval_chunk(const TfModel* t, TfWork* wk, const uint8_t* rows, int 
         else if (t->HD == 24) hipLaunchKernelGGL((tf_attn_bwd<256, 24>), dim3(n * H), dim3(64 * TF_ATT_WAVES_B), (tf_attn_bwd_lds<256, 24>()), s, at);
         else if (t->HD == 64 && L <= 128) hipLaunchKernelGGL((tf_attn_bwd<128, 64>), dim3(n * H), dim3(64 * TF_ATT_WAVES_B), (tf_attn_bwd_lds<128, 64>()), s, at);
         else if (t->HD == 64) hipLaunchKernelGGL((tf_attn_bwd<256, 64>), dim3(n * H), dim3(64 * TF_ATT_WAVES_B), (tf_attn_bwd_lds<256, 64>()), s, at);
+        else if (L <= 128 && tf_att_key_owner()) hipLaunchKernelGGL((tf_attn_bwd_ko<128, 32>), dim3(n * H), dim3(64 * TF_ATT_WAVES_B), (tf_attn_bwd_ko_lds<128, 32>()), s, at);
         else if (L <= 128) hipLaunchKernelGGL((tf_attn_bwd<128, 32>), dim3(n * H), dim3(64 * TF_ATT_WAVES_B), (tf_attn_bwd_lds<128, 32>()), s, at);
         else hipLaunchKernelGGL((tf_attn_bwd<256, 32>), dim3(n * H), dim3(64 * TF_ATT_WAVES_B), (tf_attn_bwd_lds<256, 32>()), s, at);
         HIPCHK(hipGetLastError());
