@@ -1609,23 +1609,24 @@ __global__ __launch_bounds__(64 * TF_ATT_WAVES_B, (TP == 128 && HD == 32) ? 2 : 
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// The same backward for sequences of up to 128 residues at head width 32 (config 5) with the dK / dV products handed to KEY
+// The same backward for sequences of up to 128 residues (config 5: head width 32) with the dK / dV products handed to KEY
 // OWNERS. tf_attn_bwd above keeps, per wave, accumulators for dK and dV of ALL key tiles (128 registers of 226) and is held at
 // two waves per SIMD; the counters (profiles/r03_attention_pmc.txt) show it waiting, not computing. Here the query tiles are
 // taken in rounds of four (one per wave); a wave builds P and dS of its query tile against all keys and dQ exactly as above,
 // then the 16 x 16 tiles go through the per-wave transpose tiles in LDS as before -- but are read back by the wave that OWNS
 // the key tile (key tile 4 b + w belongs to wave w in batch b), which multiplies them with the query tile's q and dO. A wave
 // accumulates dK, dV of its two key tiles only (32 registers), no sums are exchanged at the end, the row-major LDS images
-// suffice (transposed operands by ds_read_b64_tr_b16): 49 KB of LDS and <= 168 registers, THREE workgroups per CU.
+// suffice (transposed operands by ds_read_b64_tr_b16), the softmax statistics sit in registers: 48 KB of LDS and 101 registers
+// at head width 32 (THREE workgroups per CU), 80 KB at head width 64 (two, where the form above has one).
 // dK / dV of a key tile are summed over the query tiles in ascending order (a fixed order: deterministic).
 // ------------------------------------------------------------------------------------------------------------
 template <int TP, int HD> __host__ __device__ constexpr size_t tf_attn_bwd_ko_lds() {
-    return (size_t)(4 * TP * HD + TF_ATT_WAVES_B * TF_ATT_TRB * 512) * 2 + TP * sizeof(float2);
+    return (size_t)(4 * TP * tf_lds_width(HD) + TF_ATT_WAVES_B * TF_ATT_TRB * 512) * 2;      // head width 64: 80 KB, two workgroups per CU
 }
 template <int TP, int HD>
 __global__ __launch_bounds__(64 * TF_ATT_WAVES_B, 3) void tf_attn_bwd_ko(TfAttnArgs a) {
-    static_assert(TP == 128 && HD == 32 && TF_ATT_WAVES_B == 4 && TF_ATT_TRB == 4, "one key tile per wave and batch");
-    constexpr int HL = HD, NKT = TP / 16, ND = HL / 16, NDH = ND / 2, TRB = TF_ATT_TRB;
+    static_assert(TP == 128 && TF_ATT_WAVES_B == 4 && TF_ATT_TRB == 4, "two rounds of four query tiles; one key tile per wave and batch");
+    constexpr int HL = tf_lds_width(HD), NKT = TP / 16, ND = HL / 16, NDH = ND / 2, TRB = TF_ATT_TRB;
     extern __shared__ __attribute__((aligned(16))) unsigned char tf_smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1637,7 +1638,6 @@ __global__ __launch_bounds__(64 * TF_ATT_WAVES_B, 3) void tf_attn_bwd_ko(TfAttnA
     half_t* sQ = sK + TP * HL;                                 // rotated q
     half_t* sTall = sQ + TP * HL;                              // [wave][TRB][(dS, P)][16 x 16] transpose tiles
     half_t* sT = sTall + wave * TRB * 512;
-    float2* sStat = (float2*)(sTall + TF_ATT_WAVES_B * TRB * 512);
     const half_t* base = a.qkv + (size_t)b * L * ld + h * HD;
     const half_t* dob = a.dctx + (size_t)b * L * D + h * HD;
     half_t* dq_out = a.dqkv + (size_t)b * L * ld + h * HD;
@@ -1653,7 +1653,27 @@ __global__ __launch_bounds__(64 * TF_ATT_WAVES_B, 3) void tf_attn_bwd_ko(TfAttnA
         for (int r = 0; r < 4; ++r) o[r] = (half_t)v[r];
         return o;
     };
-    {
+    // softmax row statistics of this wave's (at most two) query tiles: registers, requested with the head's other loads
+    float2 stq[2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const int t = (4 * r + wave) * 16 + fr;
+        stq[r] = t < L ? a.stat[(size_t)(b * a.H + h) * L + t] : make_float2(0.f, 0.f);
+    }
+    if constexpr (HD == 24) {
+        constexpr int NT = 64 * TF_ATT_WAVES_B;
+        TfRow24<NT, TP> rq, rk, rv, ro;
+        TfRope24<NT, TP> rp;
+        tf_fetch24(base + 2 * D, ld, L, tid, rv);
+        tf_fetch24(dob, D, L, tid, ro);
+        tf_fetch24(base + D, ld, L, tid, rk);
+        tf_fetch24(base, ld, L, tid, rq);
+        tf_fetch_rope24(a.rope_cos, a.rope_sin, L, tid, rp);
+        tf_put_plain24<false>(rv, L, tid, sV);
+        tf_put_plain24<false>(ro, L, tid, sdO);
+        tf_put_rot24<true, false>(rk, rp, L, tid, sK, nullptr);
+        tf_put_rot24<true, false>(rq, rp, L, tid, sQ, nullptr);
+    } else {
         constexpr int NT = 64 * TF_ATT_WAVES_B;
         TfRotRaw<NT, TP, HD> rq, rk;
         TfRope<NT, TP, HD> rp;
@@ -1667,7 +1687,6 @@ __global__ __launch_bounds__(64 * TF_ATT_WAVES_B, 3) void tf_attn_bwd_ko(TfAttnA
         tf_put_plain<false>(ro, L, tid, sdO);
         tf_put_rot<true, false>(rk, rp, L, tid, sK, nullptr);
         tf_put_rot<true, false>(rq, rp, L, tid, sQ, nullptr);
-        for (int t = tid; t < TP; t += NT) sStat[t] = t < L ? a.stat[(size_t)(b * a.H + h) * L + t] : make_float2(0.f, 0.f);
     }
     __syncthreads();
     tf_f32x4 accK[ND][2], accV[ND][2];                                   // [head-width tile][batch]: key tile 4 * batch + wave
@@ -1682,7 +1701,7 @@ __global__ __launch_bounds__(64 * TF_ATT_WAVES_B, 3) void tf_attn_bwd_ko(TfAttnA
         for (int j = 0; j < NKT; ++j) { ds[j] = (f16x4){0, 0, 0, 0}; pt[j] = (f16x4){0, 0, 0, 0}; }
         if (qi < NQ) {
             const int q = qi * 16 + fr;
-            const float2 st = sStat[qi * 16 + fr];
+            const float2 st = q0 == 0 ? stq[0] : stq[1];
             float delta = 0.f;
 #pragma unroll
             for (int j = 0; j < NKT; ++j) {
@@ -1716,6 +1735,7 @@ __global__ __launch_bounds__(64 * TF_ATT_WAVES_B, 3) void tf_attn_bwd_ko(TfAttnA
 #pragma unroll
                 for (int dj = 0; dj < NDH; ++dj) {                     // rotary transpose on (d, d + HD/2), then the q scaling
                     const int c1 = tf_gcol<HD>(dj, fg), c2 = tf_gcol<HD>(dj + NDH, fg), rcol = tf_rope_col<HD>(dj, fg);
+                    if (c1 < 0) continue;                                 // (padding columns of a 24-wide head)
                     f16x4 o1, o2;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
@@ -1767,6 +1787,7 @@ __global__ __launch_bounds__(64 * TF_ATT_WAVES_B, 3) void tf_attn_bwd_ko(TfAttnA
 #pragma unroll
             for (int dj = 0; dj < NDH; ++dj) {
                 const int c1 = tf_gcol<HD>(dj, fg), c2 = tf_gcol<HD>(dj + NDH, fg), rcol = tf_rope_col<HD>(dj, fg);
+                if (c1 < 0) continue;
                 f16x4 k1, k2, v1, v2;
                 float co[4], si[4];
                 *(float4*)co = *(const float4*)(a.rope_cos + key * (HD / 2) + rcol);

@@ -349,7 +349,9 @@ static int tf_eval_chunk(const TfModel* t, TfWork* wk, const uint8_t* rows, int 
         TFRC(tf_ln(s, true, a.xmid, wk->gB, w.ln2g, w.ln2b, a.mean2, a.rstd2, M, t->Dr, D, wk->tmpD, wk->gA));
         TFRC(tf_gemm<TF_EPI_PLAIN>(s, wk->gB, w.WoT, wk->tmpD, Mp, D, D));
         TfAttnArgs at{a.qkv, nullptr, a.stat, t->rope_cos, t->rope_sin, wk->tmpD, wk->dqkv, n, L, H, D, qs};
-        if (t->HD == 24 && L <= 128) hipLaunchKernelGGL((tf_attn_bwd<128, 24>), dim3(n * H), dim3(64 * TF_ATT_WAVES_B), (tf_attn_bwd_lds<128, 24>()), s, at);
+        if (t->HD == 24 && L <= 128 && tf_att_key_owner()) hipLaunchKernelGGL((tf_attn_bwd_ko<128, 24>), dim3(n * H), dim3(64 * TF_ATT_WAVES_B), (tf_attn_bwd_ko_lds<128, 24>()), s, at);
+        else if (t->HD == 64 && L <= 128 && tf_att_key_owner()) hipLaunchKernelGGL((tf_attn_bwd_ko<128, 64>), dim3(n * H), dim3(64 * TF_ATT_WAVES_B), (tf_attn_bwd_ko_lds<128, 64>()), s, at);
+        else if (t->HD == 24 && L <= 128) hipLaunchKernelGGL((tf_attn_bwd<128, 24>), dim3(n * H), dim3(64 * TF_ATT_WAVES_B), (tf_attn_bwd_lds<128, 24>()), s, at);
         else if (t->HD == 24) hipLaunchKernelGGL((tf_attn_bwd<256, 24>), dim3(n * H), dim3(64 * TF_ATT_WAVES_B), (tf_attn_bwd_lds<256, 24>()), s, at);
         else if (t->HD == 64 && L <= 128) hipLaunchKernelGGL((tf_attn_bwd<128, 64>), dim3(n * H), dim3(64 * TF_ATT_WAVES_B), (tf_attn_bwd_lds<128, 64>()), s, at);
         else if (t->HD == 64) hipLaunchKernelGGL((tf_attn_bwd<256, 64>), dim3(n * H), dim3(64 * TF_ATT_WAVES_B), (tf_attn_bwd_lds<256, 64>()), s, at);
