@@ -12,7 +12,7 @@
 //
 // Kernels: tf_gemm160 / tf_gemm_nt (all linear layers, forward and backward, fused bias / residual / GELU / GELU' epilogues; 160 x 160
 // tiles where the shape allows, else 128 x 128; tf_gemm_big: an opt-in 256-row variant),
-// tf_attn_fwd / tf_attn_bwd (one workgroup of four waves per (chain, head): rotary, QK^T, softmax, PV and their gradients
+// tf_attn_fwd / tf_attn_bwd_ko (tf_attn_bwd: the older form of the backward) (one workgroup of four waves per (chain, head): rotary, QK^T, softmax, PV and their gradients
 // on the matrix cores; instances for sequences up to 128 / 256 residues and head widths 24 / 32 / 64), tf_ln_fwd / tf_ln_bwd, tf_embed, tf_score (log-softmax, score, gradient seeds), tf_finish_grad.
 #pragma once
 #include "common.h"
@@ -1609,24 +1609,27 @@ __global__ __launch_bounds__(64 * TF_ATT_WAVES_B, (TP == 128 && HD == 32) ? 2 : 
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// The same backward for sequences of up to 128 residues (config 5: head width 32) with the dK / dV products handed to KEY
-// OWNERS. tf_attn_bwd above keeps, per wave, accumulators for dK and dV of ALL key tiles (128 registers of 226) and is held at
+// The same backward (config 5: up to 128 residues, head width 32) with the dK / dV products handed to KEY OWNERS. tf_attn_bwd above keeps, per wave, accumulators for dK and dV of ALL key tiles (128 registers of 226) and is held at
 // two waves per SIMD; the counters (profiles/r03_attention_pmc.txt) show it waiting, not computing. Here the query tiles are
 // taken in rounds of four (one per wave); a wave builds P and dS of its query tile against all keys and dQ exactly as above,
 // then the 16 x 16 tiles go through the per-wave transpose tiles in LDS as before -- but are read back by the wave that OWNS
 // the key tile (key tile 4 b + w belongs to wave w in batch b), which multiplies them with the query tile's q and dO. A wave
 // accumulates dK, dV of its two key tiles only (32 registers), no sums are exchanged at the end, the row-major LDS images
 // suffice (transposed operands by ds_read_b64_tr_b16), the softmax statistics sit in registers: 48 KB of LDS and 101 registers
-// at head width 32 (THREE workgroups per CU), 80 KB at head width 64 (two, where the form above has one).
+// at head width 32 (THREE workgroups per CU), 80 KB at head width 64 or 256 residues (two, where the form above has one and,
+// beyond 128 residues, makes two or four passes), 144 KB for both (one).
 // dK / dV of a key tile are summed over the query tiles in ascending order (a fixed order: deterministic).
 // ------------------------------------------------------------------------------------------------------------
 template <int TP, int HD> __host__ __device__ constexpr size_t tf_attn_bwd_ko_lds() {
     return (size_t)(4 * TP * tf_lds_width(HD) + TF_ATT_WAVES_B * TF_ATT_TRB * 512) * 2;      // head width 64: 80 KB, two workgroups per CU
 }
+// waves per SIMD the LDS image allows: 48 KB (three workgroups per CU), 80 KB (two), 144 KB (one)
+constexpr int tf_attn_ko_wps(int TP, int HD) { return TP == 128 ? (tf_lds_width(HD) == 32 ? 3 : 2) : (tf_lds_width(HD) == 32 ? 2 : 1); }
 template <int TP, int HD>
-__global__ __launch_bounds__(64 * TF_ATT_WAVES_B, 3) void tf_attn_bwd_ko(TfAttnArgs a) {
-    static_assert(TP == 128 && TF_ATT_WAVES_B == 4 && TF_ATT_TRB == 4, "two rounds of four query tiles; one key tile per wave and batch");
+__global__ __launch_bounds__(64 * TF_ATT_WAVES_B, tf_attn_ko_wps(TP, HD)) void tf_attn_bwd_ko(TfAttnArgs a) {
+    static_assert((TP == 128 || TP == 256) && TF_ATT_WAVES_B == 4 && TF_ATT_TRB == 4, "rounds of four query tiles; one key tile per wave and batch");
     constexpr int HL = tf_lds_width(HD), NKT = TP / 16, ND = HL / 16, NDH = ND / 2, TRB = TF_ATT_TRB;
+    constexpr int NR = NKT / 4, NB = NKT / 4;                          // rounds of query tiles, batches of key tiles (at most)
     extern __shared__ __attribute__((aligned(16))) unsigned char tf_smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1654,9 +1657,9 @@ __global__ __launch_bounds__(64 * TF_ATT_WAVES_B, 3) void tf_attn_bwd_ko(TfAttnA
         return o;
     };
     // softmax row statistics of this wave's (at most two) query tiles: registers, requested with the head's other loads
-    float2 stq[2];
+    float2 stq[NR];
 #pragma unroll
-    for (int r = 0; r < 2; ++r) {
+    for (int r = 0; r < NR; ++r) {
         const int t = (4 * r + wave) * 16 + fr;
         stq[r] = t < L ? a.stat[(size_t)(b * a.H + h) * L + t] : make_float2(0.f, 0.f);
     }
@@ -1689,19 +1692,22 @@ __global__ __launch_bounds__(64 * TF_ATT_WAVES_B, 3) void tf_attn_bwd_ko(TfAttnA
         tf_put_rot<true, false>(rq, rp, L, tid, sQ, nullptr);
     }
     __syncthreads();
-    tf_f32x4 accK[ND][2], accV[ND][2];                                   // [head-width tile][batch]: key tile 4 * batch + wave
+    tf_f32x4 accK[ND][NB], accV[ND][NB];                                 // [head-width tile][batch]: key tile 4 * batch + wave
 #pragma unroll
     for (int dj = 0; dj < ND; ++dj)
 #pragma unroll
-        for (int bb = 0; bb < 2; ++bb) { accK[dj][bb] = (tf_f32x4){0.f, 0.f, 0.f, 0.f}; accV[dj][bb] = (tf_f32x4){0.f, 0.f, 0.f, 0.f}; }
-    for (int q0 = 0; q0 < NQ; q0 += TF_ATT_WAVES_B) {                    // a round: query tiles q0 .. q0 + 3, one per wave
+        for (int bb = 0; bb < NB; ++bb) { accK[dj][bb] = (tf_f32x4){0.f, 0.f, 0.f, 0.f}; accV[dj][bb] = (tf_f32x4){0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+    for (int rd = 0; rd < NR; ++rd) {                                    // a round: query tiles q0 .. q0 + 3, one per wave
+        const int q0 = 4 * rd;
+        if (q0 >= NQ) break;
         const int qi = q0 + wave;
         f16x4 pt[NKT], ds[NKT];
 #pragma unroll
         for (int j = 0; j < NKT; ++j) { ds[j] = (f16x4){0, 0, 0, 0}; pt[j] = (f16x4){0, 0, 0, 0}; }
         if (qi < NQ) {
             const int q = qi * 16 + fr;
-            const float2 st = q0 == 0 ? stq[0] : stq[1];
+            const float2 st = stq[rd];
             float delta = 0.f;
 #pragma unroll
             for (int j = 0; j < NKT; ++j) {
@@ -1751,7 +1757,7 @@ __global__ __launch_bounds__(64 * TF_ATT_WAVES_B, 3) void tf_attn_bwd_ko(TfAttnA
         }
         // dK^T [d][key] += Qr^T (rows d, k = query) x dS (k = query on the rows), dV^T += dO^T x P: by the key tile's owner
 #pragma unroll
-        for (int bb = 0; bb < 2; ++bb) {
+        for (int bb = 0; bb < NB; ++bb) {
             if (4 * bb >= NK) break;
 #pragma unroll
             for (int u = 0; u < TRB; ++u) {                              // my query tile's dS and P against key tiles 4 bb .. 4 bb + 3
@@ -1781,7 +1787,7 @@ __global__ __launch_bounds__(64 * TF_ATT_WAVES_B, 3) void tf_attn_bwd_ko(TfAttnA
     }
     // the owner writes its key tiles: rotary transpose on dK, then the stores
 #pragma unroll
-    for (int bb = 0; bb < 2; ++bb) {
+    for (int bb = 0; bb < NB; ++bb) {
         const int j = 4 * bb + wave, key = j * 16 + fr;
         if (j < NK && key < L) {
 #pragma unroll

@@ -349,15 +349,14 @@ static int tf_eval_chunk(const TfModel* t, TfWork* wk, const uint8_t* rows, int 
         TFRC(tf_ln(s, true, a.xmid, wk->gB, w.ln2g, w.ln2b, a.mean2, a.rstd2, M, t->Dr, D, wk->tmpD, wk->gA));
         TFRC(tf_gemm<TF_EPI_PLAIN>(s, wk->gB, w.WoT, wk->tmpD, Mp, D, D));
         TfAttnArgs at{a.qkv, nullptr, a.stat, t->rope_cos, t->rope_sin, wk->tmpD, wk->dqkv, n, L, H, D, qs};
-        if (t->HD == 24 && L <= 128 && tf_att_key_owner()) hipLaunchKernelGGL((tf_attn_bwd_ko<128, 24>), dim3(n * H), dim3(64 * TF_ATT_WAVES_B), (tf_attn_bwd_ko_lds<128, 24>()), s, at);
-        else if (t->HD == 64 && L <= 128 && tf_att_key_owner()) hipLaunchKernelGGL((tf_attn_bwd_ko<128, 64>), dim3(n * H), dim3(64 * TF_ATT_WAVES_B), (tf_attn_bwd_ko_lds<128, 64>()), s, at);
-        else if (t->HD == 24 && L <= 128) hipLaunchKernelGGL((tf_attn_bwd<128, 24>), dim3(n * H), dim3(64 * TF_ATT_WAVES_B), (tf_attn_bwd_lds<128, 24>()), s, at);
-        else if (t->HD == 24) hipLaunchKernelGGL((tf_attn_bwd<256, 24>), dim3(n * H), dim3(64 * TF_ATT_WAVES_B), (tf_attn_bwd_lds<256, 24>()), s, at);
-        else if (t->HD == 64 && L <= 128) hipLaunchKernelGGL((tf_attn_bwd<128, 64>), dim3(n * H), dim3(64 * TF_ATT_WAVES_B), (tf_attn_bwd_lds<128, 64>()), s, at);
-        else if (t->HD == 64) hipLaunchKernelGGL((tf_attn_bwd<256, 64>), dim3(n * H), dim3(64 * TF_ATT_WAVES_B), (tf_attn_bwd_lds<256, 64>()), s, at);
-        else if (L <= 128 && tf_att_key_owner()) hipLaunchKernelGGL((tf_attn_bwd_ko<128, 32>), dim3(n * H), dim3(64 * TF_ATT_WAVES_B), (tf_attn_bwd_ko_lds<128, 32>()), s, at);
-        else if (L <= 128) hipLaunchKernelGGL((tf_attn_bwd<128, 32>), dim3(n * H), dim3(64 * TF_ATT_WAVES_B), (tf_attn_bwd_lds<128, 32>()), s, at);
-        else hipLaunchKernelGGL((tf_attn_bwd<256, 32>), dim3(n * H), dim3(64 * TF_ATT_WAVES_B), (tf_attn_bwd_lds<256, 32>()), s, at);
+#define TF_BWD_KO(TPV, HDV) hipLaunchKernelGGL((tf_attn_bwd_ko<TPV, HDV>), dim3(n * H), dim3(64 * TF_ATT_WAVES_B), (tf_attn_bwd_ko_lds<TPV, HDV>()), s, at)
+#define TF_BWD_ALL(TPV, HDV) hipLaunchKernelGGL((tf_attn_bwd<TPV, HDV>), dim3(n * H), dim3(64 * TF_ATT_WAVES_B), (tf_attn_bwd_lds<TPV, HDV>()), s, at)
+        const bool ko = tf_att_key_owner(), shortseq = L <= 128;
+        if (t->HD == 24) { if (ko) { if (shortseq) TF_BWD_KO(128, 24); else TF_BWD_KO(256, 24); } else { if (shortseq) TF_BWD_ALL(128, 24); else TF_BWD_ALL(256, 24); } }
+        else if (t->HD == 64) { if (ko) { if (shortseq) TF_BWD_KO(128, 64); else TF_BWD_KO(256, 64); } else { if (shortseq) TF_BWD_ALL(128, 64); else TF_BWD_ALL(256, 64); } }
+        else { if (ko) { if (shortseq) TF_BWD_KO(128, 32); else TF_BWD_KO(256, 32); } else { if (shortseq) TF_BWD_ALL(128, 32); else TF_BWD_ALL(256, 32); } }
+#undef TF_BWD_KO
+#undef TF_BWD_ALL
         HIPCHK(hipGetLastError());
         TFRC(tf_gemm<TF_EPI_PLAIN>(s, wk->dqkv, w.WqkvT, wk->tmpD, Mp, D, 3 * D));
         TFRC(tf_ln(s, true, a.xin, wk->gA, w.ln1g, w.ln1b, a.mean1, a.rstd1, M, t->Dr, D, wk->tmpD, wk->gB, l == 0 ? TF_TOKEN_DROPOUT_SCALE : 1.f));
