@@ -1224,7 +1224,8 @@ __global__ __launch_bounds__(64 * TF_ATT_WAVES_F) void tf_attn_fwd(TfAttnArgs a)
     constexpr int NKT = TP / 16, LDP = TP + 8, ND = HL / 16;
     extern __shared__ __attribute__((aligned(16))) unsigned char tf_smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int b = blockIdx.x / a.H, h = blockIdx.x % a.H;
+    const int bh = xcd_contiguous(blockIdx.x, gridDim.x);      // neighbouring heads of a chain (they share 128-byte lines of q|k|v, dO, dq|dk|dv) on ONE XCD: backward 116.8 -> 112.8 us
+    const int b = bh / a.H, h = bh % a.H;
     const int L = a.L, D = a.D, ld = 3 * D;
     half_t* sQ = (half_t*)tf_smem;
     half_t* sK = sQ + TP * HL;
@@ -1417,7 +1418,8 @@ __global__ __launch_bounds__(64 * TF_ATT_WAVES_B, (TP == 128 && HD == 32) ? 2 : 
     constexpr int TRB = TF_ATT_TRB;
     extern __shared__ __attribute__((aligned(16))) unsigned char tf_smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int b = blockIdx.x / a.H, h = blockIdx.x % a.H;
+    const int bh = xcd_contiguous(blockIdx.x, gridDim.x);      // neighbouring heads of a chain (they share 128-byte lines of q|k|v, dO, dq|dk|dv) on ONE XCD: backward 116.8 -> 112.8 us
+    const int b = bh / a.H, h = bh % a.H;
     const int L = a.L, D = a.D, ld = 3 * D;
     half_t* sV = (half_t*)tf_smem;                             // [TP][HL]
     half_t* sdO = sV + TP * HL;                                // [TP][HL]
@@ -1633,7 +1635,8 @@ __global__ __launch_bounds__(64 * TF_ATT_WAVES_B, tf_attn_ko_wps(TP, HD)) void t
     extern __shared__ __attribute__((aligned(16))) unsigned char tf_smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int b = blockIdx.x / a.H, h = blockIdx.x % a.H;
+    const int bh = xcd_contiguous(blockIdx.x, gridDim.x);      // neighbouring heads of a chain (they share 128-byte lines of q|k|v, dO, dq|dk|dv) on ONE XCD: backward 116.8 -> 112.8 us
+    const int b = bh / a.H, h = bh % a.H;
     const int L = a.L, D = a.D, ld = 3 * D;
     half_t* sV = (half_t*)tf_smem;                             // [TP][HL]
     half_t* sdO = sV + TP * HL;
