@@ -1203,6 +1203,19 @@ __device__ __forceinline__ void tf_put_plain24(const TfRow24<NTHR, TP>& w, int L
 __device__ __forceinline__ float tf_quad_rows_max(float v) { return fmaxf(fmaxf(v, __shfl_xor(v, 16)), fmaxf(__shfl_xor(v, 32), __shfl_xor(v, 48))); }
 __device__ __forceinline__ float tf_quad_rows_sum(float v) { v += __shfl_xor(v, 16); v += __shfl_xor(v, 32); return v; }
 
+// exp(s - m) of an fp16 score as exp2(s * log2(e) + nm), nm = -m * log2(e) per row: one mixed-precision FMA (the fp16 score is
+// read as it stands in its packed register) and one v_exp_f32. Forward and backward use THIS function, so the backward's
+// probabilities are the forward's bit for bit.
+#define TF_LOG2E 1.4426950408889634f
+__device__ __forceinline__ float tf_exp_score(half_t s16, float nm) { return __builtin_amdgcn_exp2f(__builtin_fmaf((float)s16, TF_LOG2E, nm)); }
+__device__ __forceinline__ float tf_exp_score_f(float s_fp16_valued, float nm) { return __builtin_amdgcn_exp2f(__builtin_fmaf(s_fp16_valued, TF_LOG2E, nm)); }   // the same value from the score already widened
+// c + a . b over two fp16 pairs, fp32 accumulation (v_dot2_f32_f16)
+__device__ __forceinline__ float tf_dot4(f16x4 a, f16x4 b, float c) {
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    c = __builtin_amdgcn_fdot2((h2){a[0], a[1]}, (h2){b[0], b[1]}, c, false);
+    return __builtin_amdgcn_fdot2((h2){a[2], a[3]}, (h2){b[2], b[3]}, c, false);
+}
+
 // one 16 x 16 score tile S^T [key][query] = sum over the head width of K rows x Q rows (HD / 32 MFMA k steps)
 template <int HD>
 __device__ __forceinline__ tf_f32x4 tf_tile_kq(const half_t* krows, const half_t* qrows, int fg) {
@@ -1276,12 +1289,13 @@ __global__ __launch_bounds__(64 * TF_ATT_WAVES_F) void tf_attn_fwd(TfAttnArgs a)
             }
         }
         mx = tf_quad_rows_max(mx);
+        const float nmx = -mx * TF_LOG2E;
         float sum = 0.f;
 #pragma unroll
         for (int j = 0; j < NKT; ++j)
             if (j < NK) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) { s[j][r] = __expf(s[j][r] - mx); sum += s[j][r]; }
+                for (int r = 0; r < 4; ++r) { s[j][r] = tf_exp_score_f(s[j][r], nmx); sum += s[j][r]; }   // (-inf -> 0)
             }
         sum = tf_quad_rows_sum(sum);
         const float inv = 1.0f / sum;
@@ -1497,6 +1511,7 @@ __global__ __launch_bounds__(64 * TF_ATT_WAVES_B, (TP == 128 && HD == 32) ? 2 : 
         for (int qi = wave; qi < NQ; qi += TF_ATT_WAVES_B) {
             const int q = qi * 16 + fr;
             const float2 st = sStat[qi * 16 + fr];
+            const float nmx = -st.x * TF_LOG2E;
             f16x4 pt[NKT], ds[NKT];                                      // ds: dP as the fp16 tensor it is, then dS in place
             float delta = 0.f;
 #pragma unroll
@@ -1509,15 +1524,19 @@ __global__ __launch_bounds__(64 * TF_ATT_WAVES_B, (TP == 128 && HD == 32) ? 2 : 
                     const tf_f32x4 sc = tf_tile_kq<HL>(sK + (j * 16 + fr) * HL, sQ + (qi * 16 + fr) * HL, fg);
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const int key = j * 16 + 4 * fg + r;
-                        const float sv = key < L ? (float)(half_t)sc[r] : -INFINITY;
-                        pt[j][r] = (half_t)(__expf(sv - st.x) * st.y);
+                        pt[j][r] = (half_t)(tf_exp_score((half_t)sc[r], nmx) * st.y);
                         ds[j][r] = (half_t)dp[r];
-                        delta += (float)ds[j][r] * (float)pt[j][r];
                     }
+                    if (j + 1 == NK) {                                // keys past the sequence (only the last tile has any): probability 0
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            if (j * 16 + 4 * fg + r >= L) pt[j][r] = (half_t)0;
+                    }
+                    delta = tf_dot4(ds[j], pt[j], delta);
                 }
             }
             delta = tf_quad_rows_sum(delta);
+            const float ndelta = -delta;
             tf_f32x4 o[ND];
 #pragma unroll
             for (int dj = 0; dj < ND; ++dj) o[dj] = (tf_f32x4){0.f, 0.f, 0.f, 0.f};
@@ -1525,7 +1544,8 @@ __global__ __launch_bounds__(64 * TF_ATT_WAVES_B, (TP == 128 && HD == 32) ? 2 : 
             for (int j = 0; j < NKT; ++j)
                 if (j < NK) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) ds[j][r] = (half_t)((float)pt[j][r] * ((float)ds[j][r] - delta));
+                    for (int r = 0; r < 4; ++r)                       // P (dP - delta) as two mixed-precision FMAs on the fp16 operands
+                        ds[j][r] = (half_t)__builtin_fmaf((float)pt[j][r], (float)ds[j][r], __builtin_fmaf((float)pt[j][r], ndelta, 0.0f));
                     if constexpr (HALF == 0) {
                         // dQ^T [d][query] += Kr^T (rows d, k = these keys) x dS^T (k = key on the rows: the tile as it stands)
 #pragma unroll
@@ -1711,6 +1731,7 @@ __global__ __launch_bounds__(64 * TF_ATT_WAVES_B, tf_attn_ko_wps(TP, HD)) void t
         if (qi < NQ) {
             const int q = qi * 16 + fr;
             const float2 st = stq[rd];
+            const float nmx = -st.x * TF_LOG2E;
             float delta = 0.f;
 #pragma unroll
             for (int j = 0; j < NKT; ++j) {
@@ -1719,15 +1740,19 @@ __global__ __launch_bounds__(64 * TF_ATT_WAVES_B, tf_attn_ko_wps(TP, HD)) void t
                     const tf_f32x4 sc = tf_tile_kq<HL>(sK + (j * 16 + fr) * HL, sQ + (qi * 16 + fr) * HL, fg);    // the forward's scores again
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const int key = j * 16 + 4 * fg + r;
-                        const float sv = key < L ? (float)(half_t)sc[r] : -INFINITY;
-                        pt[j][r] = (half_t)(__expf(sv - st.x) * st.y);
+                        pt[j][r] = (half_t)(tf_exp_score((half_t)sc[r], nmx) * st.y);
                         ds[j][r] = (half_t)dp[r];
-                        delta += (float)ds[j][r] * (float)pt[j][r];
                     }
+                    if (j + 1 == NK) {                                // keys past the sequence (only the last tile has any): probability 0
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            if (j * 16 + 4 * fg + r >= L) pt[j][r] = (half_t)0;
+                    }
+                    delta = tf_dot4(ds[j], pt[j], delta);
                 }
             }
             delta = tf_quad_rows_sum(delta);
+            const float ndelta = -delta;
             tf_f32x4 o[ND];
 #pragma unroll
             for (int dj = 0; dj < ND; ++dj) o[dj] = (tf_f32x4){0.f, 0.f, 0.f, 0.f};
@@ -1735,7 +1760,8 @@ __global__ __launch_bounds__(64 * TF_ATT_WAVES_B, tf_attn_ko_wps(TP, HD)) void t
             for (int j = 0; j < NKT; ++j)
                 if (j < NK) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) ds[j][r] = (half_t)((float)pt[j][r] * ((float)ds[j][r] - delta));
+                    for (int r = 0; r < 4; ++r)                       // P (dP - delta) as two mixed-precision FMAs on the fp16 operands
+                        ds[j][r] = (half_t)__builtin_fmaf((float)pt[j][r], (float)ds[j][r], __builtin_fmaf((float)pt[j][r], ndelta, 0.0f));
 #pragma unroll
                     for (int dj = 0; dj < ND; ++dj)                   // dQ^T [d][query] += Kr^T (rows d, k = these keys) x dS^T
                         o[dj] = __builtin_amdgcn_mfma_f32_16x16x16f16(tr_operand(sK, dj, j), ds[j], o[dj], 0, 0, 0);
