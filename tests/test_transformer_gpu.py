@@ -510,3 +510,44 @@ def test_get_energy_under_autograd_vs_reference_fixture(tag, unsup, which):
     with pytest.raises(ValueError, match="one-hot"):
         en.get_energy((0.9 * x.detach() + 0.005).requires_grad_())
     m.close()
+
+
+_ATT_FORMS = r"""
+import sys
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[1] + "/tests"); sys.path.insert(0, sys.argv[1] + "/oracle")
+import numpy as np, torch
+from test_transformer_gpu import _model
+out = {}
+for tag, (L, layers, dim, heads, ffn, n) in dict(w32=(104, 2, 256, 8, 512, 5), w64long=(237, 2, 256, 4, 512, 3), w24=(60, 2, 96, 4, 256, 4)).items():
+    m, wt, st, _ = _model(L, layers, dim, heads, ffn)
+    idx = np.random.default_rng(7).integers(0, 20, (n, L)).astype(np.uint8)
+    e, f, g = m.energy_grad(torch.as_tensor(idx).cuda(), 4)
+    out[tag + "_e"], out[tag + "_g"] = e.cpu().numpy(), g.cpu().numpy()
+np.savez(sys.argv[2], **out)
+"""
+
+
+def test_both_forms_of_the_attention_backward_agree():
+    """tf_attn_bwd_ko (the default: dK / dV accumulated by key owners, one pass at every size) against tf_attn_bwd
+    (PPDE_TF_ATT_KO=0: every wave accumulates dK / dV of all keys; two or four passes beyond 128 residues or at head width 64):
+    same forward, same P and dS, a different summation order of dK / dV over the query tiles -- scores equal, gradients equal
+    to fp16 rounding of the intermediate tensors (head widths 32, 64 at GFP length, 24)."""
+    import subprocess
+    import sys
+    REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    with tempfile.TemporaryDirectory() as d:
+        script = os.path.join(d, "forms.py")
+        open(script, "w").write(_ATT_FORMS)
+        for ko in ("1", "0"):
+            out = os.path.join(d, f"ko{ko}.npz")
+            r = subprocess.run([sys.executable, script, REPO, out], capture_output=True, text=True, timeout=300, env=dict(os.environ, PPDE_TF_ATT_KO=ko))
+            assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+            res[ko] = dict(np.load(out))
+    for k in res["1"]:
+        a, b = res["1"][k], res["0"][k]
+        assert np.isfinite(a).all() and np.isfinite(b).all(), k
+        if k.endswith("_e"):
+            assert np.array_equal(a, b), k                     # the forward does not depend on the backward's form
+        else:
+            assert observed(f"attn_forms:{k}", np.abs(a - b).max(), 5e-3 * np.abs(a).max()) <= 1.0, k
