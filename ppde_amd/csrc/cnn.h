@@ -12,6 +12,7 @@
 // a broadcast-operand FMA loop). A operands are read from LDS one dword per lane (row stride = 2 mod 4 dwords:
 // conflict-free), B operands stream from L2 in [k][n] layout. Arithmetic per chain does not depend on the batch.
 #pragma once
+#include <string.h>
 #include "common.h"
 
 typedef __attribute__((ext_vector_type(4))) float f32x4;
@@ -24,6 +25,8 @@ struct CnnNet {
     const float* be;     // [FP]
     const float* wd;     // [FP]
     const float* Wf;     // [CP][JP]      conv weights as [channel] x [kappa*20 + c] (B operand of the backward)
+    const uint4* WeB;    // [FP/16][CP/32][3][64]  We as MFMA B fragments of its exact three-term bf16 split (split-precision path)
+    const uint4* WfB;    // [JP/16][CP/32][3][64]  Wf likewise
     float bd;
 };
 
@@ -57,6 +60,137 @@ __host__ __device__ inline size_t cnn_lds_bytes(int T, int CP, int FP, int J, in
     const size_t bits = rows * ((CP + 31) / 32) * 4;        // ReLU gate of h1
     const size_t route = (rows + 4 + (size_t)FP) * 4;       // row offsets and the row-sorted list of routed features
     return r0 + r1 + bits + route + (size_t)FP * 8 + 64 + ((L + CNN_MAX_K + 15) & ~15);
+}
+
+// ---- split-precision contractions on the bf16 matrix pipe ---------------------------------------------------------------
+// v_mfma_f32_16x16x4_f32 runs at 1/16 of the bf16 MFMA rate. An fp32 value is EXACTLY the sum of three bf16 values (8 + 8 + 8
+// significant bits, each rounded to nearest even from the remainder of the previous one), and a product of two bf16 values is
+// exact in fp32, so a * b = sum of nine exact cross terms; the six terms a1b1, a1b2, a2b1, a2b2, a1b3, a3b1 leave out
+// a2b3 + a3b2 + a3b3 <= 2^-26 |a b| (a quarter of an fp32 rounding of the product). Six v_mfma_f32_16x16x32_bf16 with fp32
+// accumulation replace eight v_mfma_f32_16x16x4_f32 per 16 x 16 x 32 block: 16 * 6 against 32 * 8 matrix-pipe cycles (2.7x).
+// The weights are split once at upload (ppde_model_set_cnn), the activations when they are written to LDS.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// host side of the split (integer round-to-nearest-even: what v_cvt_pk_bf16_f32 does for finite values)
+inline uint16_t bf16_rne_bits(float x) {
+    uint32_t u;
+    memcpy(&u, &x, 4);
+    if ((u & 0x7f800000u) == 0x7f800000u) return (uint16_t)(u >> 16);          // inf / nan: truncate
+    return (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+}
+inline float bf16_bits_to_float(uint16_t h) {
+    const uint32_t u = (uint32_t)h << 16;
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
+inline void bf16_split3_host(float a, uint16_t (&t)[3]) {
+    t[0] = bf16_rne_bits(a);
+    const float r1 = a - bf16_bits_to_float(t[0]);
+    t[1] = bf16_rne_bits(r1);
+    const float r2 = r1 - bf16_bits_to_float(t[1]);
+    t[2] = bf16_rne_bits(r2);
+}
+
+// two values -> one dword of two bf16 (v_cvt_pk_bf16_f32); the remainders a - hi are exact in fp32
+__device__ __forceinline__ uint32_t bf16_pk_rem(float& a, float& b) {
+    const bf16x2 h = __builtin_convertvector((f32x2){a, b}, bf16x2);
+    const uint32_t u = __builtin_bit_cast(uint32_t, h);
+    a = a - __uint_as_float(u << 16);
+    b = b - __uint_as_float(u & 0xffff0000u);
+    return u;
+}
+// four consecutive k of one row -> their 8 bytes in each of the three planes
+__device__ __forceinline__ void bf16_split3_pack4(float4 x, uint2& p0, uint2& p1, uint2& p2) {
+    p0.x = bf16_pk_rem(x.x, x.y); p0.y = bf16_pk_rem(x.z, x.w);
+    p1.x = bf16_pk_rem(x.x, x.y); p1.y = bf16_pk_rem(x.z, x.w);
+    p2.x = bf16_pk_rem(x.x, x.y); p2.y = bf16_pk_rem(x.z, x.w);
+}
+// LDS image of a split [rows x CP] operand: per (k step of 32, row tile of 16) three 1-KiB blocks (one per plane) in MFMA A
+// fragment order, lane (row r, k quarter kq) at 16-byte slot kq * 16 + (r ^ kq ^ 4 * (ks & 1)): a wave's ds_read_b128 is
+// conflict-free (every 16-lane group of the instruction covers 16 distinct slots mod 16), and the XOR spreads the 8-byte stores
+// of the producers (same row, neighbouring k) over the banks.
+__device__ __forceinline__ int bf_plane_off(int RT, int ks, int tile, int kq, int row) {
+    return ((ks * RT + tile) * 3072) + ((kq * 16 + (row ^ kq ^ ((ks & 1) << 2))) << 4);
+}
+__device__ __forceinline__ void bf_store4(unsigned char* planes, int RT, int t, int c4, float4 x) {
+    uint2 p0, p1, p2;
+    bf16_split3_pack4(x, p0, p1, p2);
+    const int k0 = 4 * c4;
+    unsigned char* d = planes + bf_plane_off(RT, k0 >> 5, t >> 4, (k0 & 31) >> 3, t & 15) + 2 * (k0 & 7);
+    *(uint2*)d = p0; *(uint2*)(d + 1024) = p1; *(uint2*)(d + 2048) = p2;
+}
+__host__ __device__ inline size_t cnn_bf_region_bytes(int T, int CP, int J) {
+    const size_t rows = cnn_rows(T);
+    const size_t planes = (size_t)3 * (CP / 32) * (rows / 16) * 1024, so = rows * (size_t)J * 4;
+    return planes > so ? planes : so;                      // h1 planes, then the routed gradient's, then O [rows][J] fp32
+}
+__host__ __device__ inline size_t cnn_bf_lds_bytes(int T, int CP, int FP, int J, int L) {
+    const size_t rows = cnn_rows(T);
+    const size_t bits = rows * ((CP + 31) / 32) * 4;        // ReLU gate of h1
+    const size_t route = (rows + 4 + (size_t)FP) * 4;       // row offsets and the row-sorted list of routed features
+    return cnn_bf_region_bytes(T, CP, J) + bits + route + (size_t)FP * 8 + 64 + ((L + CNN_MAX_K + 15) & ~15);
+}
+
+// One wave: for its strips ct = ct0, ct0 + ct_step, ... < ct_end:  acc[RT] = A [rows x 32 KS] (split planes in LDS) x B strip
+// (split fragments from L2: [ct][ks][term][lane] 16 bytes), then epi(i, ct, acc) with i = the wave's i-th strip. Three fragment
+// buffers in rotation over the sequence of (strip, k step) pairs: while one multiplies, the next two are in flight.
+template <int RT, typename Epi>
+__device__ __forceinline__ void bf_strips(const unsigned char* planes, const uint4* Bfrag, const int KS, const int ct0,
+                                          const int ct_step, const int ct_end, Epi&& epi) {
+    const int lane = threadIdx.x & 63, row = lane & 15, kq = lane >> 4;
+    const int nstr = ct0 < ct_end ? (ct_end - ct0 + ct_step - 1) / ct_step : 0;
+    const int Q = nstr * KS;
+    if (Q == 0) return;
+    const uint4* bp = Bfrag + lane;
+    const int lo0 = (kq * 16 + (row ^ kq)) << 4, lo1 = (kq * 16 + (row ^ kq ^ 4)) << 4;
+    uint4 bx[3], by[3], bz[3];
+    f32x4 acc[RT];
+    auto fill = [&](uint4 (&b)[3], int q) {
+        q = min(q, Q - 1);
+        const int i = q / KS, ks = q - i * KS;
+        const size_t at = ((size_t)(ct0 + i * ct_step) * KS + ks) * 192;
+        b[0] = bp[at]; b[1] = bp[at + 64]; b[2] = bp[at + 128];
+    };
+    auto mult = [&](const uint4 (&b)[3], const int q) {
+        const int i = q / KS, ks = q - i * KS;
+        if (ks == 0) {
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) acc[rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+        const bf16x8 b1 = __builtin_bit_cast(bf16x8, b[0]), b2 = __builtin_bit_cast(bf16x8, b[1]), b3 = __builtin_bit_cast(bf16x8, b[2]);
+        const unsigned char* ap = planes + ks * (RT * 3072) + ((ks & 1) ? lo1 : lo0);
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+            const bf16x8 a1 = __builtin_bit_cast(bf16x8, *(const uint4*)(ap + rt * 3072));
+            const bf16x8 a2 = __builtin_bit_cast(bf16x8, *(const uint4*)(ap + rt * 3072 + 1024));
+            const bf16x8 a3 = __builtin_bit_cast(bf16x8, *(const uint4*)(ap + rt * 3072 + 2048));
+            f32x4 c = acc[rt];                                   // (small terms first)
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a3, b1, c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b3, c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2, b2, c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2, b1, c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b2, c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b1, c, 0, 0, 0);
+            acc[rt] = c;
+        }
+        if (ks == KS - 1) epi(i, ct0 + i * ct_step, acc);
+    };
+    fill(bx, 0); fill(by, 1); fill(bz, 2);
+    for (int q = 0; q < Q; q += 3) {
+        mult(bx, q);
+        if (q + 3 < Q) fill(bx, q + 3);
+        if (q + 1 < Q) {
+            mult(by, q + 1);
+            if (q + 4 < Q) fill(by, q + 4);
+        }
+        if (q + 2 < Q) {
+            mult(bz, q + 2);
+            if (q + 5 < Q) fill(bz, q + 5);
+        }
+    }
 }
 
 // One wave: C[rows x 16] (+)= A[rows x CP] (LDS, stride AS) * B[CP x 16] (global, leading dimension ldb, first
@@ -115,7 +249,7 @@ __device__ __forceinline__ void mfma_strip(f32x4 (&acc)[RT], const float* A, int
 //       coming straight from L2 with a dozen loads in flight per thread, and applies the gate.
 // sM[f] = coefficient (0: not routed), sTs[f] = absolute arg-max row. sB (rows x ceil(FP/32) words) must be ZERO on
 // entry and may alias sD (it is dead before sD is written); rows <= 128. Ends with a barrier.
-template <int NT>
+template <int NT, bool BF = false>
 __device__ __forceinline__ void cnn_route_rows(const CnnNet& net, const int rows, const int r0, const int CP, const int AS,
                                                const int FP, const int BW, float* sD, uint32_t* sB, const uint32_t* sG,
                                                const float* sM, const int* sTs, int* sStart, int* sList, int* sTot) {
@@ -197,9 +331,12 @@ __device__ __forceinline__ void cnn_route_rows(const CnnNet& net, const int rows
                 acc.x = (nib & 1u) ? acc.x : 0.f; acc.y = (nib & 2u) ? acc.y : 0.f;
                 acc.z = (nib & 4u) ? acc.z : 0.f; acc.w = (nib & 8u) ? acc.w : 0.f;
                 if (item0 + NT * j < items) {
-                    float* dp = sD + t[j] * AS + 4 * c4[j];          // AS = 2 mod 4: rows are only 8-byte aligned
-                    *(float2*)dp = make_float2(acc.x, acc.y);
-                    *(float2*)(dp + 2) = make_float2(acc.z, acc.w);
+                    if constexpr (BF) bf_store4((unsigned char*)sD, rows / 16, t[j], c4[j], acc);   // split planes (AS unused)
+                    else {
+                        float* dp = sD + t[j] * AS + 4 * c4[j];      // AS = 2 mod 4: rows are only 8-byte aligned
+                        *(float2*)dp = make_float2(acc.x, acc.y);
+                        *(float2*)(dp + 2) = make_float2(acc.z, acc.w);
+                    }
                 }
             }
         }
@@ -425,11 +562,219 @@ __device__ __forceinline__ void cnn_body(const CnnArgs& a_, const int bx, const 
     PPDE_WG_STAMP(a.dbg, wg_lin, 3);
 }
 
-template <int RT, int KT, int NT = CNN_NT>
+// The same workgroup with both dense contractions on the bf16 matrix pipe (split-precision, see bf_strips): h1 and the routed
+// gradient live in LDS as three-plane bf16 images in MFMA fragment order (one region: h1 planes, then the route bitmap, then the
+// routed gradient's planes, then O); a wave owns whole column strips (all row tiles: every B fragment is fetched once per
+// workgroup), the max / arg-max over t comes straight from the accumulators as before; the backward strips (at most two per
+// wave) stay in registers until every wave has read the routed gradient, then O takes its storage. Everything else (conv
+// gather, route, transposed convolution, the order of every sum outside the two contractions) is cnn_body's.
+template <int RT, int KT, int NT = CNN_NT, bool PABP = false>
+__device__ __forceinline__ void cnn_body_bf(const CnnArgs& a_, const int bx, const int ni, const int n_bx, const int n_ni,
+                                            unsigned char* smem_raw) {
+    struct Shape { int n_nets, n_parts, T, CP, F, FP, J, JP, want_grad; };
+    const Shape a_shape = PABP ? Shape{3, 4, 92, 96, 192, 192, 100, 112, 1}
+                               : Shape{a_.n_nets, a_.n_parts, a_.T, a_.CP, a_.F, a_.FP, a_.J, a_.JP, a_.want_grad};
+    const CnnArgs& a = a_;
+    Geom g = a.g;
+    if constexpr (PABP) { g.L = 96; g.N = 1920; }
+    const int b = a.b_off + bx, tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int part = ni;
+    const CnnNet net = a.net[min(part, a_shape.n_nets - 1)];
+    const int T = a_shape.T, CP = a_shape.CP, F = a_shape.F, FP = a_shape.FP;
+    constexpr int J = KT * 20, JP = (J + 15) & ~15;                // (what ppde_model_set_cnn derives from the tap count)
+    constexpr int rows = RT * 16;
+    const int KS = CP / 32;
+    const int OS = J;
+    const int BW = (CP + 31) / 32;
+    const bool halved = a_shape.n_parts > a_shape.n_nets && part >= a_shape.n_nets - 1;
+    const int FT = FP / 16, ct_mid = (FT + 1) / 2;
+    const int ct_lo = (halved && part == a_shape.n_nets) ? ct_mid : 0, ct_hi = (halved && part < a_shape.n_nets) ? ct_mid : FT;
+    unsigned char* sP = smem_raw;                                   // split planes of h1, later of the routed gradient; O
+    const size_t region = PABP ? (size_t)3 * 3 * RT * 1024 : cnn_bf_region_bytes(T, CP, J);
+    uint32_t* sG = (uint32_t*)(smem_raw + region);                  // [rows][BW] bit o of word: h1[t][o] > 0
+    const int BWF = (FP + 31) / 32;
+    uint32_t* sB = (uint32_t*)sP;                                   // [rows][BWF] route bitmap (in the region: h1 is dead by then)
+    int* sStart = (int*)(sG + (size_t)rows * BW);
+    int* sList = sStart + rows + 4;
+    float* sM = (float*)(sList + FP);
+    int* sTs = (int*)(sM + FP);
+    float* red = (float*)(sTs + FP);
+    uint8_t* sSt = (uint8_t*)(red + 16);
+    int phase = 0;
+    const int slot = a.slot;
+
+    [[maybe_unused]] const bool first_wg = bx == 0 && ni == 0;
+    [[maybe_unused]] const bool stamp = first_wg || (bx == n_bx - 1 && ni == n_ni - 1);
+    [[maybe_unused]] const int sb = first_wg ? 40 : 50;
+    [[maybe_unused]] const int wg_lin = bx + n_bx * ni;
+    PPDE_STAMP(a.dbg, sb, stamp);
+    PPDE_WG_STAMP(a.dbg, wg_lin, 0);
+    float wdf[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) wdf[k] = net.wd[min(tid + NT * k, FP - 1)];
+    for (int l = tid; l < g.L + CNN_MAX_K; l += NT) sSt[l] = l < g.L ? min((int)a.idx[(size_t)b * g.Ls + g.sh + l], 19) : 0;
+    for (int w = tid; w < rows * BW; w += NT) sG[w] = 0u;
+    if (halved)
+        for (int f = tid; f < FP; f += NT) { sM[f] = 0.f; sTs[f] = 0; }
+    __syncthreads();
+    PPDE_STAMP(a.dbg, sb + 1, stamp);
+
+    // ---- h1 = relu(conv) as in cnn_body; every (row, 4 channels) piece is split and stored into the three planes
+    {
+        const int G4 = CP / 4;
+        const int RPR = NT / G4;
+        const int g4 = tid % G4, tr = tid / G4;
+        if (tr < RPR) {
+            const float4 bias4 = *(const float4*)(net.bc + 4 * g4);
+            for (int t0 = tr; t0 < rows; t0 += 2 * RPR) {
+                float4 wv[2][KT];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int tt = min(t0 + u * RPR, T - 1);
+#pragma unroll
+                    for (int kp = 0; kp < KT; ++kp)
+                        wv[u][kp] = *(const float4*)(net.WcT + ((size_t)kp * 20 + sSt[tt + kp]) * CP + 4 * g4);
+                }
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int t = t0 + u * RPR;
+                    if (t >= rows) continue;
+                    float4 x = bias4;
+#pragma unroll
+                    for (int kp = 0; kp < KT; ++kp) { x.x += wv[u][kp].x; x.y += wv[u][kp].y; x.z += wv[u][kp].z; x.w += wv[u][kp].w; }
+                    const bool live = t < T;
+                    x.x = live ? fmaxf(x.x, 0.f) : 0.f; x.y = live ? fmaxf(x.y, 0.f) : 0.f;
+                    x.z = live ? fmaxf(x.z, 0.f) : 0.f; x.w = live ? fmaxf(x.w, 0.f) : 0.f;
+                    const uint32_t nib = (x.x > 0.f ? 1u : 0u) | (x.y > 0.f ? 2u : 0u) | (x.z > 0.f ? 4u : 0u) | (x.w > 0.f ? 8u : 0u);
+                    bf_store4(sP, RT, t, g4, x);
+                    if (nib) atomicOr(&sG[t * BW + (g4 >> 3)], nib << (4 * (g4 & 7)));
+                }
+            }
+        }
+    }
+    __syncthreads();
+    PPDE_STAMP(a.dbg, sb + 2, stamp);
+    // ---- pre2 = h1 We^T + be (six bf16 cross-term MFMAs per block); relu and the running max over t straight from the
+    //      accumulators (strict >, rows ascending: the first index wins, like torch.max)
+    bf_strips<RT>(sP, net.WeB, KS, ct_lo + wave, NT / 64, ct_hi, [&](int, int ct, const f32x4 (&acc)[RT]) {
+        const int f = ct * 16 + (lane & 15);
+        const float bias = net.be[f];
+        float m = -INFINITY;
+        int ts = 0;
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int t = rt * 16 + (lane >> 4) * 4 + j;
+                const float v = fmaxf(acc[rt][j] + bias, 0.f);
+                if (t < T && v > m) { m = v; ts = t; }
+            }
+        }
+#pragma unroll
+        for (int o = 16; o < 64; o <<= 1) {
+            const float om = __shfl_xor(m, o);
+            const int ot = __shfl_xor(ts, o);
+            if (om > m || (om == m && ot < ts)) { m = om; ts = ot; }
+        }
+        if (lane < 16) { sM[f] = m; sTs[f] = ts; }
+    });
+    __syncthreads();
+
+    PPDE_STAMP(a.dbg, sb + 3, stamp);
+    // ---- out = bd + wd . m  (fixed tree); routing coefficients replace m in LDS (as cnn_body)
+    {
+        float s = 0.f;
+        float cf[2] = {0.f, 0.f};
+        int k = 0;
+#pragma unroll
+        for (k = 0; k < 2; ++k) {
+            const int f = tid + NT * k;
+            if (f >= FP) break;
+            const float wv = f < F ? wdf[k] : 0.f, mf = sM[f];
+            s += wv * mf;
+            cf[k] = (f < F && mf > 0.f) ? a.scale * wv : 0.f;
+        }
+        if (a_shape.want_grad)
+            for (int w = tid; w < rows * BWF; w += NT) sB[w] = 0u;  // route bitmap (every wave has left the h1 planes)
+        const float tot = block_sum<NT / 64>(s, red, phase);
+        if (tid == 0) a.fitC[((size_t)slot * a_shape.n_parts + part) * a.n + b] = part < a_shape.n_nets ? tot + net.bd : tot;
+        k = 0;
+        for (int f = tid; f < FP; f += NT, ++k)
+            if (k < 2) sM[f] = cf[k];
+    }
+    PPDE_STAMP(a.dbg, sb + 4, stamp);
+    if (!a_shape.want_grad) return;
+
+    // ---- route + gate (cnn_route_rows) -> the routed gradient's split planes
+    cnn_route_rows<NT, true>(net, rows, 0, CP, 0, FP, BW, (float*)sP, sB, sG, sM, sTs, sStart, sList, (int*)(red + 12));
+    PPDE_STAMP(a.dbg, sb + 5, stamp);
+    PPDE_STAMP(a.dbg, sb + 7, stamp);
+    PPDE_WG_STAMP(a.dbg, wg_lin, 2);
+    // ---- O[t][kappa*20 + c] = sum_o dpre1[t][o] Wc[o][c][kappa]: strips stay in registers until every wave is done reading
+    constexpr int NKEEP = (JP / 16 + NT / 64 - 1) / (NT / 64);     // strips per wave: 1 for five taps, 2 for eight
+    static_assert(NKEEP <= 2, "at most two backward strips per wave");
+    f32x4 keep[NKEEP][RT];
+    bf_strips<RT>(sP, net.WfB, KS, wave, NT / 64, JP / 16, [&](int i, int, const f32x4 (&acc)[RT]) {
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+            if (NKEEP == 1 || i == 0) keep[0][rt] = acc[rt];
+            else keep[NKEEP - 1][rt] = acc[rt];
+        }
+    });
+    __syncthreads();
+    float* sO = (float*)sP;
+#pragma unroll
+    for (int i = 0; i < NKEEP; ++i) {
+        const int ct = wave + i * (NT / 64);
+        const int j = ct * 16 + (lane & 15);
+        if (ct < JP / 16 && j < J) {
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) sO[(rt * 16 + (lane >> 4) * 4 + q) * OS + j] = keep[i][rt][q];
+            }
+        }
+    }
+    __syncthreads();
+    PPDE_STAMP(a.dbg, sb + 8, stamp);
+    // ---- transposed convolution: dx[p][c] = sum_kappa O[p - kappa][kappa*20 + c]   (as cnn_body)
+    float* out = a.gradC + (((size_t)slot * a_shape.n_parts + part) * a.n + b) * g.N;
+    for (int e0 = tid; e0 < g.N; e0 += 2 * NT) {
+        float x[2][KT];
+        int pp[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int e = min(e0 + NT * u, g.N - 1);
+            const int p = e / 20, c = e - 20 * p;
+            pp[u] = p;
+#pragma unroll
+            for (int kp = 0; kp < KT; ++kp) x[u][kp] = sO[min(max(p - kp, 0), T - 1) * OS + kp * 20 + c];
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+#pragma unroll
+            for (int kp = 0; kp < KT; ++kp) use_here(x[u][kp]);
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            float v = 0.f;
+#pragma unroll
+            for (int kp = 0; kp < KT; ++kp) v += (pp[u] - kp >= 0 && pp[u] - kp < T) ? x[u][kp] : 0.f;
+            if (e0 + NT * u < g.N) out[e0 + NT * u] = v;
+        }
+    }
+    PPDE_STAMP(a.dbg, sb + 9, stamp);
+    PPDE_WG_STAMP(a.dbg, wg_lin, 3);
+}
+
+// BF: the split-precision body (bf16 matrix pipe) instead of the exact-fp32 MFMA one
+template <int RT, int KT, int NT = CNN_NT, bool BF = false>
 __global__ __launch_bounds__(NT, 2) void k_cnn(CnnArgs a) {
     warm_kernargs<sizeof(CnnArgs)>();
     extern __shared__ unsigned char smem_raw[];
-    cnn_body<RT, KT, NT>(a, blockIdx.x, blockIdx.y, gridDim.x, gridDim.y, smem_raw);
+    if constexpr (BF) cnn_body_bf<RT, KT, NT>(a, blockIdx.x, blockIdx.y, gridDim.x, gridDim.y, smem_raw);
+    else cnn_body<RT, KT, NT>(a, blockIdx.x, blockIdx.y, gridDim.x, gridDim.y, smem_raw);
 }
 // =====================================================================================================
 // Long sequences (the [T x C] activations of one chain do not fit LDS next to the routed gradient, e.g. GFP,

@@ -3,7 +3,10 @@
 // Replaces the body of PPDE_PAS.run's loop (reference ppde/protein_samplers/ppde.py:65-153):
 //   k_propose : :67-116  path length, mutation-cap mask (ppde/utils.py:5-28), proposal logits, the
 //                        safe_logits_to_probs -> Categorical normalisation chain (ppde/utils.py:106-111),
-//                        one categorical draw per sub-step by the exponential race (torch.multinomial),
+//                        one categorical draw per sub-step -- replaying caller-supplied noise (rng_mode 0): the flat
+//                        exponential race over all L*20 entries, arg-max p / q, as torch.multinomial draws it; on the
+//                        device RNG: the SAME categorical drawn in two levels (residue by a race over the L residue
+//                        masses, then the letter by a race inside that residue: L + 20 variates instead of L*20) --,
 //                        forward log-probabilities, state update
 //   k_accept  : :122-153 reverse-path log-probabilities on grad(y) (no masks), log acceptance ratio,
 //                        accept/reject, histories, running best (ppde.py:172-183), mutation-cap reset
@@ -101,7 +104,13 @@ struct RowLds {
     int* mv;        // moves of the current path: (residue, new letter) pairs [2 * 128]
     uint8_t* St;    // letters of the start state [L]
     uint8_t* Wt;    // wild-type letters         [L]
+    float4* Pv;     // clamped probabilities of the current sub-step [N/4]          (two-level draw, device RNG)
+    float* qv;      // reciprocal race variates of PAS_QS sub-steps [PAS_QS][LQ]     (two-level draw, device RNG)
 };
+// sub-steps of race variates parked in LDS at a time (two-level draw); row = 4*ceil(L/4) residue entries + 20 letter entries
+#define PAS_QS 4
+__host__ __device__ inline int pas_rb(int L) { return (L + 3) >> 2; }
+__host__ __device__ inline int pas_lq(int L) { return 4 * pas_rb(L) + PPDE_A; }
 
 __device__ __forceinline__ RowLds carve_lds(unsigned char* base, const Geom& g) {
     RowLds r;
@@ -111,10 +120,12 @@ __device__ __forceinline__ RowLds carve_lds(unsigned char* base, const Geom& g) 
     r.mv = (int*)(r.xb + 8 * PPDE_NW);
     r.St = (uint8_t*)(r.mv + 256);
     r.Wt = r.St + ((g.L + 15) & ~15);
+    r.Pv = (float4*)(r.Wt + ((g.L + 15) & ~15));
+    r.qv = (float*)(r.Pv + g.N / 4);
     return r;
 }
 __host__ __device__ inline size_t pas_lds_bytes(const Geom& g) {
-    return (size_t)g.N * 4 + 16 * PPDE_NW * 4 + 1024 + 2 * (size_t)((g.L + 15) & ~15);
+    return (size_t)g.N * 4 + 16 * PPDE_NW * 4 + 1024 + 2 * (size_t)((g.L + 15) & ~15) + (size_t)g.N * 4 + (size_t)PAS_QS * pas_lq(g.L) * 4;
 }
 
 // a state byte in both forms: the row (CNN, chain kernels) and, for residues of the padded Potts window, its T4 slot
@@ -489,6 +500,41 @@ __device__ __forceinline__ void race_variates(const PasArgs& a, int b, int it, i
         }
     }
 }
+// Two-level draw (device RNG): the categorical over the L*20 entries of a row is drawn as residue l* by an exponential race over
+// the residue masses P_l = sum_k p[l][k], then letter k* by a race over p[l*][.] -- the same law as the flat race (P(l*, k*) =
+// P_l / S * p[l*][k*] / P_l), every entry's probability still carried at full relative precision (the 2^-23 floor entries
+// included), with L + 20 variates per sub-step instead of L*20. Philox counter (chain, iteration, 2 + s, 0x10000 + j) yields
+// the variates of residues 4j..4j+3, (.., 0x20000 + j) those of letters 4j..4j+3. They do not depend on the state: the
+// variates of sub-steps s0 .. s0+ns-1 are drawn by the first ns * (ceil(L/4) + 5) threads in one go and parked in LDS as
+// RECIPROCALS (the race compares p * rcp(q), as the flat device race did).
+__device__ __forceinline__ float4 exp1_rcp4(const U4& rr) {
+    return make_float4(__builtin_amdgcn_rcpf(exp1_from_bits(rr.x)), __builtin_amdgcn_rcpf(exp1_from_bits(rr.y)),
+                       __builtin_amdgcn_rcpf(exp1_from_bits(rr.z)), __builtin_amdgcn_rcpf(exp1_from_bits(rr.w)));
+}
+__device__ __forceinline__ void fill_race_variates(const PasArgs& a, const RowLds& lds, int b, int it, int s0, int ns) {
+    const int RB = pas_rb(a.g.L), CPS = RB + PPDE_A / 4, LQ = pas_lq(a.g.L);
+    const int total = ns * CPS;
+    const uint32_t gchain = a.key.chain_lo + (uint32_t)b;
+    for (int c = threadIdx.x; c < total; c += PPDE_BLOCK) {
+        const int sb = c / CPS, j = c - sb * CPS;
+        const uint32_t blk = j < RB ? 0x10000u + (uint32_t)j : 0x20000u + (uint32_t)(j - RB);
+        const U4 rr = philox4x32_10(U4{gchain, (uint32_t)it, (uint32_t)(2 + s0 + sb), blk}, a.key.k0, a.key.k1);
+        *(float4*)(lds.qv + ((s0 + sb) % PAS_QS) * LQ + 4 * j) = exp1_rcp4(rr);
+    }
+}
+// wave-wide arg-max of (value, index) pairs with the smallest index winning an exact tie; returns the winning LANE
+__device__ __forceinline__ int wave_argmax_lane(float bv, int bi) {
+    const float vmax = wave_max(bv);
+    unsigned long long tie = __ballot(bv == vmax);
+    if (__popcll(tie) > 1) {
+        int mi = (bv == vmax) ? bi : 0x7fffffff;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) mi = min(mi, __shfl_xor(mi, o));
+        tie = __ballot(bv == vmax && bi == mi);
+    }
+    return __builtin_amdgcn_readfirstlane(__ffsll((long long)tie) - 1);
+}
+
 // Path length and first sub-step's variates: issued at kernel entry, behind the row's global loads
 template <int GPT>
 struct ProposePrefetch {
@@ -498,15 +544,16 @@ struct ProposePrefetch {
     float4 q0[GPT];
 };
 template <int GPT, bool HOSTQ>
-__device__ __forceinline__ ProposePrefetch<GPT> propose_prefetch(const PasArgs& a, int b, int it) {
+__device__ __forceinline__ ProposePrefetch<GPT> propose_prefetch(const PasArgs& a, const RowLds& lds, int b, int it) {
     ProposePrefetch<GPT> p;
     if constexpr (HOSTQ) p.Ub = a.U_in[b + opaque_zero()];
     else p.Ub = pathlen_from_bits(philox4x32_10(U4{a.key.chain_lo + (uint32_t)b, (uint32_t)it, 0u, 0u}, a.key.k0, a.key.k1).x, a.pas);
     p.Uraw = p.Ub;
     p.Ub = min(max(p.Ub, 1), min(a.mu_max, a.mu_cap));
     p.dist = rec_of(a, b + opaque_zero())->dist_cur;
-    race_variates<GPT, HOSTQ>(a, b, it, 0, p.q0);
-    return p;
+    if constexpr (HOSTQ) race_variates<GPT, true>(a, b, it, 0, p.q0);
+    else fill_race_variates(a, lds, b, it, 0, min(PAS_QS, a.mu_max));   // (the first PAS_QS sub-steps' variates, whatever U is:
+    return p;                                                           //  no dependence on the path-length draw)
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -525,8 +572,10 @@ __device__ __forceinline__ void propose_body(const PasArgs& a, const RowLds& lds
     // a supplied path length beyond the supplied noise block (rng_mode 0): flagged, never read past the block
     if (tid == 0 && pp.Uraw > a.mu_cap) flag_error(a.err_flag, 2);
     float4 q[GPT];
+    if constexpr (EXACT) {
 #pragma unroll
-    for (int r = 0; r < GPT; ++r) q[r] = pp.q0[r];
+        for (int r = 0; r < GPT; ++r) q[r] = pp.q0[r];
+    }
 
     int pend_l = 0, pend_k = 0;                      // the last move, not yet applied to lds.St
     constexpr bool exact_race = EXACT;             // (a compile-time switch: as a run-time branch in this loop it cost k_propose 0.55 us)
@@ -546,15 +595,59 @@ __device__ __forceinline__ void propose_body(const PasArgs& a, const RowLds& lds
             if (tid == 0) flag_error(a.err_flag, 1);
             m = 0.f; S1 = 1.f;
         }
-        // next sub-step's race variates: state independent, so the Philox + log chains overlap with pass 2
+        // next sub-step's race variates (replay mode: loads from the caller's block; they overlap with pass 2)
         float4 qn[GPT];
-        if (s + 1 < Ub) race_variates<GPT, EXACT>(a, b, it, s + 1, qn);
+        if constexpr (EXACT) { if (s + 1 < Ub) race_variates<GPT, true>(a, b, it, s + 1, qn); }
+        // device RNG: the next PAS_QS sub-steps' variates (every wave has left the previous sub-step's draw behind the barrier
+        // above; the barrier below publishes them)
+        else if (s > 0 && (s % PAS_QS) == 0) fill_race_variates(a, lds, b, it, s, min(PAS_QS, Ub - s));
         // ---- softmax -> clamp (ppde/utils.py:106-111): p = clamp(exp(z - m) / S1), exp(z - m) = e * exp(m_w - m); the
         //      exponential race arg-max of p / q (torch.multinomial) and the clamped row sum S3 in one pass + one
         //      barrier. Each thread keeps its best entry (value, flat index, probability; strict > in index order: the
         //      first index wins a tie), the wave its best lane, the workgroup its best wave.
         const float c = scale * (1.0f / S1);
-        float s3 = 0.f, bv = -1.f, bp = 0.f;
+        float s3 = 0.f;
+        int win;
+        float pwin;
+        if constexpr (!EXACT) {
+            // ---- device RNG: two-level draw. Pass 2 leaves the clamped probabilities in LDS; behind the barrier EVERY wave
+            //      evaluates both races from LDS (same data, same operations: the same winner in every wave, no third barrier)
+#pragma unroll
+            for (int r = 0; r < GPT; ++r) {
+                if (!R.valid[r]) continue;
+                float4 p;
+                p.x = clampp(e[r].x * c); p.y = clampp(e[r].y * c); p.z = clampp(e[r].z * c); p.w = clampp(e[r].w * c);
+                s3 += p.x; s3 += p.y; s3 += p.z; s3 += p.w;
+                lds.Pv[tid + r * PPDE_BLOCK] = p;
+            }
+            const float s3w = wave_sum(s3);
+            if (lane == 0) lds.xb[8 * (tid >> 6)] = s3w;
+            __syncthreads();
+            const float* qs = lds.qv + (s % PAS_QS) * pas_lq(g.L);
+            float bv = -1.f;
+            int bl = 0;
+            for (int l = lane; l < g.L; l += 64) {          // residue masses in letter order, race value P_l * rcp(q_l)
+                const float4* pv = lds.Pv + 5 * l;
+                const float4 p0 = pv[0], p1 = pv[1], p2 = pv[2], p3 = pv[3], p4 = pv[4];
+                const float rq = qs[l];
+                float P = p0.x; P += p0.y; P += p0.z; P += p0.w;
+                P += p1.x; P += p1.y; P += p1.z; P += p1.w;
+                P += p2.x; P += p2.y; P += p2.z; P += p2.w;
+                P += p3.x; P += p3.y; P += p3.z; P += p3.w;
+                P += p4.x; P += p4.y; P += p4.z; P += p4.w;
+                const float v = P * rq;
+                if (v > bv) { bv = v; bl = l; }             // (strict >, ascending l: the first index wins a tie)
+            }
+            const int lstar = min(__builtin_amdgcn_readlane(bl, wave_argmax_lane(bv, bl)), g.L - 1);
+            const int kl = min(lane, PPDE_A - 1);
+            const float pk = ((const float*)lds.Pv)[lstar * PPDE_A + kl];
+            const float vk = lane < PPDE_A ? pk * qs[4 * pas_rb(g.L) + kl] : -1.f;
+            const int kstar = wave_argmax_lane(vk, lane);     // (lane = letter)
+            win = lstar * PPDE_A + kstar;
+            pwin = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, pk), kstar));
+            s3 = row8_sum(lane < PPDE_NW ? lds.xb[8 * (lane & (PPDE_NW - 1))] : 0.f);
+        } else {
+        float bv = -1.f, bp = 0.f;
         int bi = 0;
 #pragma unroll
         for (int r = 0; r < GPT; ++r) {
@@ -596,8 +689,6 @@ __device__ __forceinline__ void propose_body(const PasArgs& a, const RowLds& lds
             }
         }
         __syncthreads();
-        int win;
-        float pwin;
         {
             const float* x = lds.xb + 8 * (lane & (PPDE_NW - 1));
             s3 = row8_sum(lane < PPDE_NW ? x[0] : 0.f);
@@ -616,6 +707,7 @@ __device__ __forceinline__ void propose_body(const PasArgs& a, const RowLds& lds
             const int W = __builtin_amdgcn_readfirstlane(__ffsll((long long)tie) - 1);
             win = min(__builtin_amdgcn_readlane(i8, W), g.N - 1);
             pwin = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, p8), W));
+        }
         }
         PPDE_STAMP(a.dbg, 12 + 4 * min(s, 1), stamp);
         const int ls = win / 20, ks = win - 20 * ls;
@@ -641,9 +733,11 @@ __device__ __forceinline__ void propose_body(const PasArgs& a, const RowLds& lds
             rec_logp(rc, a.mu_max)[s] = logp;
             if (a.tr_flat) a.tr_flat[((size_t)it * a.mu_max + s) * a.n + b] = win;
         }
-        if (s + 1 < Ub) {
+        if constexpr (EXACT) {
+            if (s + 1 < Ub) {
 #pragma unroll
-            for (int r = 0; r < GPT; ++r) q[r] = qn[r];
+                for (int r = 0; r < GPT; ++r) q[r] = qn[r];
+            }
         }
         PPDE_STAMP(a.dbg, 13 + 4 * min(s, 1), stamp);
     }
@@ -676,7 +770,7 @@ __global__ __launch_bounds__(PPDE_BLOCK) void k_propose(PasArgs a) {
     RowRegs<GPT> R;
     const int it = iteration_of(a);
     const RowLetters<GPT> rl = row_issue<GPT>(a.g, current_grad_row(a, b), a.cur + (size_t)b * a.g.Ls, a.wt, R);
-    const ProposePrefetch<GPT> pp = propose_prefetch<GPT, EXACT>(a, b, it);
+    const ProposePrefetch<GPT> pp = propose_prefetch<GPT, EXACT>(a, lds, b, it);
     row_commit<GPT>(lds, a.g, rl, R);
     PPDE_STAMP(a.dbg, 9, stamp);
     propose_body<GPT, EXACT>(a, lds, R, b, it, __builtin_amdgcn_readfirstlane(pp.dist), pp, stamp);
@@ -941,7 +1035,7 @@ __global__ __launch_bounds__(PPDE_BLOCK) void k_accept_propose(PasArgs a) {
     RowRegs<GPT> R;
     const RowLetters<GPT> rl = row_issue<GPT>(g, slot_row(a, 1, b), a.cur + (size_t)b * g.Ls, a.wt, R);
     const AcceptPrefetch pf = accept_prefetch(a, lds, b, it);
-    const ProposePrefetch<GPT> pp = propose_prefetch<GPT, false>(a, b, it + 1);
+    const ProposePrefetch<GPT> pp = propose_prefetch<GPT, false>(a, lds, b, it + 1);
     accept_stage_path(a, lds, pf);
     row_commit<GPT>(lds, g, rl, R);
     const AcceptOut o = accept_body<GPT>(a, lds, R, b, it, pf, stamp);
@@ -1062,14 +1156,20 @@ __global__ void k_mut_distance(const uint8_t* __restrict__ st, const uint8_t* __
     c = wave_sum(c);
     if ((threadIdx.x & 63) == 0) dist[b] = (int)c;
 }
-// Device RNG inspection
+// Device RNG inspection: the Exp(1) race variates of sub-step s as the two-level draw consumes them (fill_race_variates):
+// q[b][0 .. L) the residue race, q[b][L .. L+20) the letter race, the rest of the row 1.0
 __global__ void k_philox_dump(RngKey key, int it, int s, int pas, int n, int N, float* q, float* u, int* U) {
-    const int b = blockIdx.x;
+    const int b = blockIdx.x, L = N / PPDE_A;
     const uint32_t gchain = key.chain_lo + (uint32_t)b;
-    for (int g4 = threadIdx.x; g4 < N / 4; g4 += blockDim.x) {
-        const U4 r = philox4x32_10(U4{gchain, (uint32_t)it, (uint32_t)(2 + s), (uint32_t)g4}, key.k0, key.k1);
-        float4 v = make_float4(exp1_from_bits(r.x), exp1_from_bits(r.y), exp1_from_bits(r.z), exp1_from_bits(r.w));
-        *(float4*)(q + (size_t)b * N + 4 * g4) = v;
+    for (int i = threadIdx.x; i < N; i += blockDim.x) {
+        float v = 1.0f;
+        if (i < L + PPDE_A) {
+            const int e = i < L ? i : i - L;
+            const U4 r = philox4x32_10(U4{gchain, (uint32_t)it, (uint32_t)(2 + s), (i < L ? 0x10000u : 0x20000u) + (uint32_t)(e >> 2)}, key.k0, key.k1);
+            const uint32_t w = (e & 3) == 0 ? r.x : (e & 3) == 1 ? r.y : (e & 3) == 2 ? r.z : r.w;
+            v = exp1_from_bits(w);
+        }
+        q[(size_t)b * N + i] = v;
     }
     if (threadIdx.x == 0) {
         u[b] = unif_from_bits(philox4x32_10(U4{gchain, (uint32_t)it, 1u, 0u}, key.k0, key.k1).x);

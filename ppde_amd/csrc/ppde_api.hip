@@ -248,10 +248,19 @@ static int launch_potts(const ppde_model* m, const States& st, int n, const Eval
     return PPDE_OK;
 }
 
+// Both dense contractions of the CNN on the bf16 matrix pipe (split-precision, cnn.h bf_strips): the default.
+// PPDE_CNN_BF16=0 keeps the exact-fp32 MFMA kernels (v_mfma_f32_16x16x4_f32).
+static bool cnn_bf16() {
+    static const bool on = []() { const char* e = getenv("PPDE_CNN_BF16"); return !e || atoi(e) != 0; }();   // tuning knob
+    return on;
+}
+static size_t cnn_single_lds(const ppde_model* m) {
+    return cnn_bf16() ? cnn_bf_lds_bytes(m->T, m->CP, m->FP, m->J, m->L) : cnn_lds_bytes(m->T, m->CP, m->FP, m->J, m->L);
+}
 static bool cnn_single_launch(const ppde_model* m) {
     static const int chunked_override = []() { const char* e = getenv("PPDE_CNN_CHUNKED"); return e ? atoi(e) : -1; }();   // tuning knob
     if (chunked_override == 1) return false;
-    const size_t lds = cnn_lds_bytes(m->T, m->CP, m->FP, m->J, m->L);
+    const size_t lds = cnn_single_lds(m);
     if (cnn_rows(m->T) > 16 * CNN_MAX_RT || lds > 160 * 1024 || m->FP > 512) return false;   // (cnn_body keeps two features per thread)
     // Where only ONE workgroup of the single-launch kernel fits a CU (L >= 100), the chunked path (two to four
     // workgroups per CU, balanced grids) is faster: UBE4B, L = 104: 166 us/step against 214 (180 with an 8-wave
@@ -326,10 +335,13 @@ static int launch_cnn(const ppde_model* m, const States& st, int n, const EvalTa
         HIPCHK(hipGetLastError());
         return PPDE_OK;
     }
-    size_t lds = cnn_lds_bytes(m->T, m->CP, m->FP, m->J, m->L);
+    size_t lds = cnn_single_lds(m);
     const dim3 grid(n_sub, a.n_parts);
+    const bool bf = cnn_bf16();
 #define PPDE_CNN(RTV)                                                                           \
-    if (m->KT == 5) hipLaunchKernelGGL((k_cnn<RTV, 5>), grid, dim3(CNN_NT), lds, s, a);           \
+    if (bf && m->KT == 5) hipLaunchKernelGGL((k_cnn<RTV, 5, CNN_NT, true>), grid, dim3(CNN_NT), lds, s, a);           \
+    else if (bf) hipLaunchKernelGGL((k_cnn<RTV, CNN_MAX_K, CNN_NT, true>), grid, dim3(CNN_NT), lds, s, a); \
+    else if (m->KT == 5) hipLaunchKernelGGL((k_cnn<RTV, 5>), grid, dim3(CNN_NT), lds, s, a);           \
     else hipLaunchKernelGGL((k_cnn<RTV, CNN_MAX_K>), grid, dim3(CNN_NT), lds, s, a);
     switch (cnn_rows(m->T) / 16) {
         case 1: PPDE_CNN(1) break;
@@ -361,7 +373,7 @@ struct ExpertsArgs {
 };
 // PABP: the CNN's shape pinned to the PABP_YEAST networks' (L = 96: 96 channels, 192 features, 5 taps, three networks in four
 // output rows, gradients wanted), so that every trip count of cnn_body is a compile-time constant (as pin_config in pas.h)
-template <int RT, int NG, bool PABP = false>
+template <int RT, int NG, bool PABP = false, bool BF = false>
 __global__ __launch_bounds__(CNN_NT, 2) void k_experts(ExpertsArgs a) {
     warm_kernargs<sizeof(ExpertsArgs)>();
 
@@ -369,7 +381,8 @@ __global__ __launch_bounds__(CNN_NT, 2) void k_experts(ExpertsArgs a) {
     const int w = blockIdx.x, n_cnn = a.cnn_bx * a.cnn_ni;
     if (w < n_cnn) {
         const int ni = w / a.cnn_bx;
-        cnn_body<RT, 5, CNN_NT, PABP>(a.c, w - ni * a.cnn_bx, ni, a.cnn_bx, a.cnn_ni, (unsigned char*)smem_experts);
+        if constexpr (BF) cnn_body_bf<RT, 5, CNN_NT, PABP>(a.c, w - ni * a.cnn_bx, ni, a.cnn_bx, a.cnn_ni, (unsigned char*)smem_experts);
+        else cnn_body<RT, 5, CNN_NT, PABP>(a.c, w - ni * a.cnn_bx, ni, a.cnn_bx, a.cnn_ni, (unsigned char*)smem_experts);
     } else {
         if (threadIdx.x >= 256) return;          // a Potts tile is the work of four waves (the barrier counts live waves only)
         const int v = xcd_contiguous(w - n_cnn, a.potts_items);
@@ -383,7 +396,8 @@ static int launch_experts_fused(const ppde_model* m, const States& st, int n, co
     static const bool enabled = []() { const char* e = getenv("PPDE_FUSE_EXPERTS"); return !e || atoi(e) != 0; }();
     const int NG = potts_ng_for(n_sub);
     if (!enabled || !cnn_single_launch(m) || m->KT != 5 || NG > 2 || g_potts_events) return PPDE_OK;
-    const size_t lds_c = cnn_lds_bytes(m->T, m->CP, m->FP, m->J, m->L), lds_p = potts_lds_bytes(m->g.NC, NG);
+    const size_t lds_c = cnn_single_lds(m), lds_p = potts_lds_bytes(m->g.NC, NG);
+    const bool bf = cnn_bf16();
     if (lds_p > lds_c || 2 * lds_c > 160 * 1024 || m->g.NC > 8) return PPDE_OK;   // (needs the free second slot)
     ExpertsArgs a{};
     CnnArgs& c = a.c;
@@ -406,13 +420,16 @@ static int launch_experts_fused(const ppde_model* m, const States& st, int n, co
     static const bool shape_spec = []() { const char* e = getenv("PPDE_CNN_SPEC"); return !e || atoi(e) != 0; }();   // tuning knob
     if (shape_spec && NG == 2 && m->L == 96 && m->g.NC == 5 && c.C == 96 && c.CP == 96 && c.K == 5 && c.F == 192 && c.FP == 192 && c.T == 92 && c.J == 100 &&
         c.JP == 112 && c.n_nets == 3 && c.n_parts == 4) {
-        hipLaunchKernelGGL((k_experts<6, 2, true>), grid, dim3(CNN_NT), lds_c, s, a);
+        if (bf) hipLaunchKernelGGL((k_experts<6, 2, true, true>), grid, dim3(CNN_NT), lds_c, s, a);
+        else hipLaunchKernelGGL((k_experts<6, 2, true>), grid, dim3(CNN_NT), lds_c, s, a);
         HIPCHK(hipGetLastError());
         *done = true;
         return PPDE_OK;
     }
 #define PPDE_EX(RTV)                                                                              \
-    if (NG == 1) hipLaunchKernelGGL((k_experts<RTV, 1>), grid, dim3(CNN_NT), lds_c, s, a);         \
+    if (bf && NG == 1) hipLaunchKernelGGL((k_experts<RTV, 1, false, true>), grid, dim3(CNN_NT), lds_c, s, a);         \
+    else if (bf) hipLaunchKernelGGL((k_experts<RTV, 2, false, true>), grid, dim3(CNN_NT), lds_c, s, a); \
+    else if (NG == 1) hipLaunchKernelGGL((k_experts<RTV, 1>), grid, dim3(CNN_NT), lds_c, s, a);         \
     else hipLaunchKernelGGL((k_experts<RTV, 2>), grid, dim3(CNN_NT), lds_c, s, a);
     switch (cnn_rows(m->T) / 16) {
         case 1: PPDE_EX(1) break;
@@ -763,6 +780,28 @@ int ppde_model_set_cnn(ppde_model* m, int n_nets, int C, int K, int F, const flo
         if ((rc = up(be, &p))) return rc; nt.be = p;
         if ((rc = up(wd, &p))) return rc; nt.wd = p;
         if ((rc = up(Wf, &p))) return rc; nt.Wf = p;
+        // the same two matrices as MFMA B fragments of their exact three-term bf16 split (cnn.h bf_strips):
+        // [strip of 16 columns][k step of 32][term][lane] x 8 bf16, lane = (column l & 15, k = 8 (l >> 4) + j)
+        auto frags = [&](const std::vector<float>& W, int ldw, int ncols, const uint4** out) -> int {   // W[k][col], k < CP
+            const int KS = CP / 32, NS = ncols / 16;
+            std::vector<uint16_t> fr((size_t)NS * KS * 3 * 64 * 8, 0);
+            for (int ct = 0; ct < NS; ++ct)
+                for (int ks = 0; ks < KS; ++ks)
+                    for (int l = 0; l < 64; ++l)
+                        for (int j = 0; j < 8; ++j) {
+                            uint16_t t3[3];
+                            bf16_split3_host(W[(size_t)(ks * 32 + 8 * (l >> 4) + j) * ldw + ct * 16 + (l & 15)], t3);
+                            for (int t = 0; t < 3; ++t) fr[((((size_t)ct * KS + ks) * 3 + t) * 64 + l) * 8 + j] = t3[t];
+                        }
+            uint16_t* d = nullptr;
+            HIPCHK(dalloc(&d, fr.size()));
+            HIPCHK(hipMemcpy(d, fr.data(), fr.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+            m->cnn_allocs.push_back(d);
+            *out = (const uint4*)d;
+            return PPDE_OK;
+        };
+        if ((rc = frags(WeT, FP, FP, &nt.WeB))) return rc;
+        if ((rc = frags(Wf, JP, JP, &nt.WfB))) return rc;
         nt.bd = dec_b[k][0];
     }
     free_scratch(m);
