@@ -44,10 +44,10 @@ MFMA_F32_PEAK_TF = 157.3     # dense fp32 matrix peak (MI355X_MICROARCH.md)
 def parse():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
-    p.add_argument("--steps", type=int, default=2000)
-    p.add_argument("--warmup", type=int, default=200)
+    p.add_argument("--steps", type=int, default=None, help="timed iterations per block (default: 2000; transformer workload: 20)")
+    p.add_argument("--warmup", type=int, default=None, help="untimed iterations before the first block (default: 200; transformer workload: 3)")
     p.add_argument("--repeats", type=int, default=5, help="timed blocks of --steps iterations; the median is reported")
-    p.add_argument("--chains", type=int, default=128, help="chains per GPU")
+    p.add_argument("--chains", type=int, default=None, help="chains per GPU (default: 128; transformer workload: 256, BASELINE configs[4])")
     p.add_argument("--workload", default="potts", choices=["potts", "potts+cnn", "transformer"],
                    help="potts = BASELINE configs[1] (Potts-only PoE); potts+cnn = configs[2] (lamda=5); "
                         "transformer = configs[4] (ESM2-style unsupervised expert + supervised CNN, UBE4B, 256 chains)")
@@ -85,7 +85,24 @@ def launch_ranks(args):
     return subprocess.run(cmd, env=env).returncode
 
 
-def build_model(workload, device, protein="PABP"):
+def resolve_defaults(args):
+    """Per-workload defaults of the arguments left unset (None), so that every value can also be asked for explicitly."""
+    tf = args.workload == "transformer"
+    if args.steps is None:
+        args.steps = 20 if tf else 2000
+    if args.warmup is None:
+        args.warmup = 3 if tf else 200
+    if args.chains is None:
+        args.chains = 256 if tf else 128
+    return args
+
+
+def env_flag(name):
+    """Knobs of this script are off unless set to something other than '' / '0' (as the library's atoi-style knobs)."""
+    return os.environ.get(name, "0") not in ("", "0")
+
+
+def build_model(workload, device, protein="PABP", lamda=5.0):
     from ppde_amd import synthetic
     from ppde_amd.encoding import seqs_to_idx
     from ppde_amd.energy import HipModel
@@ -99,7 +116,7 @@ def build_model(workload, device, protein="PABP"):
     if workload == "potts+cnn":
         cnn = [synthetic.make_cnn_state(len(seq), s) for s in range(3)]
         m.set_cnn(cnn)
-        m.set_lamda(5.0)
+        m.set_lamda(lamda)
     return m, wt, J, h, i0, Lp, cnn
 
 
@@ -225,7 +242,7 @@ def cpu_baseline(args, wt, J, h, i0, Lp, cnn, n):
 
 
 def main():
-    args = parse()
+    args = resolve_defaults(parse())
     if args.gpus > 1 and "RANK" not in os.environ:
         sys.exit(launch_ranks(args))
     import torch
@@ -235,14 +252,14 @@ def main():
     if world != args.gpus:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: refusing to report a value for a different rank count")
     backend = os.environ.get("PPDE_BENCH_BACKEND", "nccl")          # "gloo" + PPDE_BENCH_ONE_GPU=1: rehearse N ranks on one card
-    if os.environ.get("PPDE_BENCH_ONE_GPU"):
+    if env_flag("PPDE_BENCH_ONE_GPU"):
         local = 0
     if args.workload == "transformer":
         import bench_transformer
         return bench_transformer.main(args, rank, world, local, backend)
     # PPDE_BENCH_FORCE_DIST=1 (with PPDE_COLLECTIVES_AT_WORLD_1=1): a ONE-rank process group, so that a one-GPU box executes
     # the RCCL branch (init, barrier, all_reduce, the population gather) before an 8-GPU node ever sees it
-    dist_on = world > 1 or bool(os.environ.get("PPDE_BENCH_FORCE_DIST"))
+    dist_on = world > 1 or env_flag("PPDE_BENCH_FORCE_DIST")
     if dist_on:
         import torch.distributed as dist
         torch.cuda.set_device(local)

@@ -49,7 +49,7 @@ def measure(args, rank, world, local, backend, steps, warmup, repeats, with_cpu,
     def barrier():
         if world > 1:
             torch.distributed.barrier()
-    n = args.chains if args.chains != 128 else 256
+    n = args.chains
     name = [k for k in synthetic.PROTEINS if k.startswith("UBE4B")][0]
     _, seq, _ = synthetic.PROTEINS[name]
     wt = seqs_to_idx([seq])[0]
@@ -188,9 +188,7 @@ def rocprof_frac(tag, kernel_substr, work_per_launch, peak=None):
 
 def main(args, rank, world, local, backend):
     import torch
-    steps = args.steps if args.steps != 2000 else 20            # (the defaults of the Potts workload would run for minutes)
-    warmup = args.warmup if args.warmup != 200 else 3
-    out = measure(args, rank, world, local, backend, steps, warmup, min(args.repeats, 3), False if args.no_cpu_baseline else "minibatch")
+    out = measure(args, rank, world, local, backend, args.steps, args.warmup, min(args.repeats, 3), False if args.no_cpu_baseline else "minibatch")
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:

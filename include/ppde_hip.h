@@ -230,7 +230,9 @@ int ppde_chains_graph_stats(ppde_chains* c, int32_t* captures, int32_t* captures
 int ppde_chains_trace(ppde_chains* c, int32_t* flat, uint8_t* accepted, float* log_acc, int32_t* U);
 
 /* Device RNG inspection (tests): fills q_dev [n, L*20], u_dev [n], U_dev [n] with what iteration `it`,
- * sub-step `s` would use in rng_mode 1. */
+ * sub-step `s` would use in rng_mode 1. The device RNG draws the categorical of a sub-step in two levels (residue, then
+ * letter: the same law as the reference's flat race, ppde.py:106-110, with L + 20 variates instead of L*20): row b of q_dev
+ * holds the Exp(1) variates of the residue race in [0, L), those of the letter race in [L, L + 20), and 1.0 beyond. */
 int ppde_chains_philox_dump(ppde_chains* c, int it, int s, float* q_dev, float* u_dev, int32_t* U_dev);
 
 /* Timing hooks for bench.py: average duration in microseconds of the Potts energy+gradient kernel over

@@ -212,8 +212,41 @@ def categorical_probs(z):
 
 
 def race_sample(p_hat, q):
-    """One categorical draw per row by the exponential race: argmax_j p_j / q_j with q_j ~ Exp(1)."""
-    return torch.argmax(p_hat / q, dim=-1)
+    """One categorical draw per row by the exponential race.
+
+    q [n, L*A]: the flat race, argmax_j p_j / q_j with q_j ~ Exp(1) -- what torch.multinomial does (ppde.py:109) and what
+    the HIP path does when it replays caller-supplied noise.
+    q [n, L + A]: the TWO-LEVEL form the HIP path uses on its device RNG (ppde_amd/csrc/pas.h): residue l* by a race over the
+    residue masses P_l = sum_k p[l, k] with q[:, :L], then letter k* by a race over p[l*, :] with q[:, L:]. Same law:
+    P(l*, k*) = (P_l / sum P) * (p[l*, k*] / P_l) = p_hat[l*, k*]."""
+    n, N = p_hat.shape
+    if q.shape[-1] == N:
+        return torch.argmax(p_hat / q, dim=-1)
+    L = N // A
+    assert q.shape[-1] == L + A, "race variates: [n, L*A] (flat race) or [n, L + A] (two-level draw)"
+    pl = p_hat.reshape(n, L, A)
+    t = ((pl[..., 0:4] + pl[..., 4:8]) + (pl[..., 8:12] + pl[..., 12:16])) + pl[..., 16:20]     # the kernel's summation tree
+    mass = (t[..., 0] + t[..., 1]) + (t[..., 2] + t[..., 3])
+    res = torch.argmax(mass / q[:, :L], dim=-1)
+    let = torch.argmax(pl[torch.arange(n), res] / q[:, L:], dim=-1)
+    return res * A + let
+
+
+def race_gap(p_hat_row, q_row, picked):
+    """How close index `picked` came to winning the race the oracle ran on one row: 1 - value(picked) / value(winner) at the
+    level (flat / residue / letter) where `picked` lost; 0 if it is the winner."""
+    N = p_hat_row.shape[-1]
+    if q_row.shape[-1] == N:
+        v = p_hat_row / q_row
+        return 1.0 - float(v[int(picked)] / v.max())
+    L = N // A
+    pl = p_hat_row.reshape(L, A)
+    vres = pl.sum(-1) / q_row[:L]
+    lp, kp = int(picked) // A, int(picked) % A
+    if int(torch.argmax(vres)) != lp:
+        return 1.0 - float(vres[lp] / vres.max())
+    vlet = pl[lp] / q_row[L:]
+    return 1.0 - float(vlet[kp] / vlet.max())
 
 
 def log_prob_at(p_hat, flat):
@@ -252,7 +285,7 @@ def pas_iteration(energy, idx_cur, idx_reject, wt_idx, U, q, u, min_pos, max_pos
 
     idx_cur     int64 [n, L]  state the iteration starts from
     idx_reject  int64 [n, L]  state a rejected chain falls back to (== idx_cur unless paper_results)
-    U           int64 [n]     path lengths;  q fp32 [max_u, n, L*A];  u fp32 [n]
+    U           int64 [n]     path lengths;  q fp32 [max_u, n, L*A] (flat race) or [max_u, n, L + A] (two-level draw);  u fp32 [n]
     Returns a dict with the new state and every intermediate the parity tests look at (keep_probs: also the forward
     proposal distributions `p_fwd` [max_u, n, L*A], from which a test can read how close a draw was to a tie).
     """
@@ -372,3 +405,35 @@ def philox4x32(counter, key):
             c = np.stack([hi1 ^ c[..., 1] ^ k[..., 0], lo1, hi0 ^ c[..., 3] ^ k[..., 1], lo0], axis=-1)
             k = np.stack([k[..., 0] + _W0, k[..., 1] + _W1], axis=-1)
     return c
+
+
+def device_race_variates(seed, chain0, n, it, s, L):
+    """The Exp(1) race variates the HIP path's device RNG draws for sub-step `s` of iteration `it` (pas.h fill_race_variates),
+    restated: fp32 [n, L + A] = residue race [:, :L], letter race [:, L:]. Counter (chain, it, 2 + s, 0x10000 + j) -> residues
+    4j..4j+3, (.., 0x20000 + j) -> letters 4j..4j+3; Exp(1) = -log(u), u = (bits >> 9 + 0.5) * 2^-23."""
+    k = np.array([seed & 0xffffffff, (seed >> 32) & 0xffffffff], dtype=np.uint32)
+    chain = (chain0 + np.arange(n)).astype(np.uint32)
+
+    def blocks(base, count):
+        nb = (count + 3) // 4
+        ctr = np.zeros((n, nb, 4), dtype=np.uint32)
+        ctr[..., 0] = chain[:, None]; ctr[..., 1] = it; ctr[..., 2] = 2 + s; ctr[..., 3] = base + np.arange(nb)[None]
+        r = philox4x32(ctr, k).reshape(n, nb * 4)[:, :count]
+        return -np.log(((r >> 9).astype(np.float32) + np.float32(0.5)) * np.float32(2.0 ** -23))
+
+    return np.concatenate([blocks(0x10000, L), blocks(0x20000, A)], axis=1).astype(np.float32)
+
+
+def device_noise(seed, chain0, n, it, pas_length, L):
+    """Everything the HIP path's device RNG draws for iteration `it` of chains chain0 .. chain0+n-1, restated on the CPU:
+    (U int64 [n], q fp32 [2*pas-1, n, L + A] two-level race variates, u fp32 [n]) -- the tuple run() / pas_iteration() take.
+    Path length: counter (chain, it, 0, 0), 1 + floor(bits * (2 pas - 1) / 2^32); accept uniform: counter (chain, it, 1, 0),
+    24 bits; race variates: device_race_variates."""
+    k = np.array([seed & 0xffffffff, (seed >> 32) & 0xffffffff], dtype=np.uint32)
+    chain = (chain0 + np.arange(n)).astype(np.uint32)
+    c0 = np.zeros((n, 4), dtype=np.uint32); c0[:, 0] = chain; c0[:, 1] = it
+    U = 1 + ((philox4x32(c0, k)[:, 0].astype(np.uint64) * np.uint64(2 * pas_length - 1)) >> np.uint64(32)).astype(np.int64)
+    c1 = c0.copy(); c1[:, 2] = 1
+    u = (philox4x32(c1, k)[:, 0] >> 8).astype(np.float32) * np.float32(2.0 ** -24)
+    q = np.stack([device_race_variates(seed, chain0, n, it, s, L) for s in range(2 * pas_length - 1)], 0)
+    return torch.as_tensor(U), torch.as_tensor(q), torch.as_tensor(u)

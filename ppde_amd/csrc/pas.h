@@ -151,6 +151,13 @@ struct RowSrc {
     const float4* t;            // transformer row (or NULL)
 };
 __device__ __forceinline__ float4 add4(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+// One 16-byte LDS read (ds_read_b128). A float4 is a struct of four floats to the optimiser: loaded through its own type it can be
+// taken apart into dword reads (measured: ds_read_b96 + ds_read2_b32 with 4-way bank conflicts at an 80-byte lane stride).
+typedef float pas_v4f __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 lds_load4(const float4* p) {
+    const pas_v4f v = *(const pas_v4f*)p;
+    return make_float4(v.x, v.y, v.z, v.w);
+}
 // (every index into c[] is a compile-time constant: a run-time index would send the struct to scratch memory)
 __device__ __forceinline__ float4 row_value(const RowSrc& r, int g4) {
     float4 v;
@@ -523,8 +530,8 @@ __device__ __forceinline__ void fill_race_variates(const PasArgs& a, const RowLd
     }
 }
 // wave-wide arg-max of (value, index) pairs with the smallest index winning an exact tie; returns the winning LANE
-__device__ __forceinline__ int wave_argmax_lane(float bv, int bi) {
-    const float vmax = wave_max(bv);
+__device__ __forceinline__ int wave_argmax_lane(float bv, int bi, float& vmax) {
+    vmax = wave_max(bv);
     unsigned long long tie = __ballot(bv == vmax);
     if (__popcll(tie) > 1) {
         int mi = (bv == vmax) ? bi : 0x7fffffff;
@@ -572,10 +579,8 @@ __device__ __forceinline__ void propose_body(const PasArgs& a, const RowLds& lds
     // a supplied path length beyond the supplied noise block (rng_mode 0): flagged, never read past the block
     if (tid == 0 && pp.Uraw > a.mu_cap) flag_error(a.err_flag, 2);
     float4 q[GPT];
-    if constexpr (EXACT) {
 #pragma unroll
-        for (int r = 0; r < GPT; ++r) q[r] = pp.q0[r];
-    }
+    for (int r = 0; r < GPT; ++r) q[r] = pp.q0[r];
 
     int pend_l = 0, pend_k = 0;                      // the last move, not yet applied to lds.St
     constexpr bool exact_race = EXACT;             // (a compile-time switch: as a run-time branch in this loop it cost k_propose 0.55 us)
@@ -595,59 +600,15 @@ __device__ __forceinline__ void propose_body(const PasArgs& a, const RowLds& lds
             if (tid == 0) flag_error(a.err_flag, 1);
             m = 0.f; S1 = 1.f;
         }
-        // next sub-step's race variates (replay mode: loads from the caller's block; they overlap with pass 2)
+        // next sub-step's race variates: state independent, so the Philox + log chains overlap with pass 2
         float4 qn[GPT];
-        if constexpr (EXACT) { if (s + 1 < Ub) race_variates<GPT, true>(a, b, it, s + 1, qn); }
-        // device RNG: the next PAS_QS sub-steps' variates (every wave has left the previous sub-step's draw behind the barrier
-        // above; the barrier below publishes them)
-        else if (s > 0 && (s % PAS_QS) == 0) fill_race_variates(a, lds, b, it, s, min(PAS_QS, Ub - s));
+        if (s + 1 < Ub) race_variates<GPT, EXACT>(a, b, it, s + 1, qn);
         // ---- softmax -> clamp (ppde/utils.py:106-111): p = clamp(exp(z - m) / S1), exp(z - m) = e * exp(m_w - m); the
         //      exponential race arg-max of p / q (torch.multinomial) and the clamped row sum S3 in one pass + one
         //      barrier. Each thread keeps its best entry (value, flat index, probability; strict > in index order: the
         //      first index wins a tie), the wave its best lane, the workgroup its best wave.
         const float c = scale * (1.0f / S1);
-        float s3 = 0.f;
-        int win;
-        float pwin;
-        if constexpr (!EXACT) {
-            // ---- device RNG: two-level draw. Pass 2 leaves the clamped probabilities in LDS; behind the barrier EVERY wave
-            //      evaluates both races from LDS (same data, same operations: the same winner in every wave, no third barrier)
-#pragma unroll
-            for (int r = 0; r < GPT; ++r) {
-                if (!R.valid[r]) continue;
-                float4 p;
-                p.x = clampp(e[r].x * c); p.y = clampp(e[r].y * c); p.z = clampp(e[r].z * c); p.w = clampp(e[r].w * c);
-                s3 += p.x; s3 += p.y; s3 += p.z; s3 += p.w;
-                lds.Pv[tid + r * PPDE_BLOCK] = p;
-            }
-            const float s3w = wave_sum(s3);
-            if (lane == 0) lds.xb[8 * (tid >> 6)] = s3w;
-            __syncthreads();
-            const float* qs = lds.qv + (s % PAS_QS) * pas_lq(g.L);
-            float bv = -1.f;
-            int bl = 0;
-            for (int l = lane; l < g.L; l += 64) {          // residue masses in letter order, race value P_l * rcp(q_l)
-                const float4* pv = lds.Pv + 5 * l;
-                const float4 p0 = pv[0], p1 = pv[1], p2 = pv[2], p3 = pv[3], p4 = pv[4];
-                const float rq = qs[l];
-                float P = p0.x; P += p0.y; P += p0.z; P += p0.w;
-                P += p1.x; P += p1.y; P += p1.z; P += p1.w;
-                P += p2.x; P += p2.y; P += p2.z; P += p2.w;
-                P += p3.x; P += p3.y; P += p3.z; P += p3.w;
-                P += p4.x; P += p4.y; P += p4.z; P += p4.w;
-                const float v = P * rq;
-                if (v > bv) { bv = v; bl = l; }             // (strict >, ascending l: the first index wins a tie)
-            }
-            const int lstar = min(__builtin_amdgcn_readlane(bl, wave_argmax_lane(bv, bl)), g.L - 1);
-            const int kl = min(lane, PPDE_A - 1);
-            const float pk = ((const float*)lds.Pv)[lstar * PPDE_A + kl];
-            const float vk = lane < PPDE_A ? pk * qs[4 * pas_rb(g.L) + kl] : -1.f;
-            const int kstar = wave_argmax_lane(vk, lane);     // (lane = letter)
-            win = lstar * PPDE_A + kstar;
-            pwin = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, pk), kstar));
-            s3 = row8_sum(lane < PPDE_NW ? lds.xb[8 * (lane & (PPDE_NW - 1))] : 0.f);
-        } else {
-        float bv = -1.f, bp = 0.f;
+        float s3 = 0.f, bv = -1.f, bp = 0.f;
         int bi = 0;
 #pragma unroll
         for (int r = 0; r < GPT; ++r) {
@@ -689,6 +650,8 @@ __device__ __forceinline__ void propose_body(const PasArgs& a, const RowLds& lds
             }
         }
         __syncthreads();
+        int win;
+        float pwin;
         {
             const float* x = lds.xb + 8 * (lane & (PPDE_NW - 1));
             s3 = row8_sum(lane < PPDE_NW ? x[0] : 0.f);
@@ -707,7 +670,6 @@ __device__ __forceinline__ void propose_body(const PasArgs& a, const RowLds& lds
             const int W = __builtin_amdgcn_readfirstlane(__ffsll((long long)tie) - 1);
             win = min(__builtin_amdgcn_readlane(i8, W), g.N - 1);
             pwin = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, p8), W));
-        }
         }
         PPDE_STAMP(a.dbg, 12 + 4 * min(s, 1), stamp);
         const int ls = win / 20, ks = win - 20 * ls;
@@ -733,15 +695,182 @@ __device__ __forceinline__ void propose_body(const PasArgs& a, const RowLds& lds
             rec_logp(rc, a.mu_max)[s] = logp;
             if (a.tr_flat) a.tr_flat[((size_t)it * a.mu_max + s) * a.n + b] = win;
         }
-        if constexpr (EXACT) {
-            if (s + 1 < Ub) {
+        if (s + 1 < Ub) {
 #pragma unroll
-                for (int r = 0; r < GPT; ++r) q[r] = qn[r];
-            }
+            for (int r = 0; r < GPT; ++r) q[r] = qn[r];
         }
         PPDE_STAMP(a.dbg, 13 + 4 * min(s, 1), stamp);
     }
     PPDE_STAMP(a.dbg, 18, stamp);
+    if (tid == 0) {
+        ChainRec* rc = rec_of(a, b);
+        rc->Ucur = Ub;
+        rc->dist_prop = dist;
+        if (a.tr_U) a.tr_U[(size_t)it * a.n + b] = Ub;
+        for (int s = Ub; s < a.mu_max; ++s) {
+            rec_flat(rc)[s] = -1;
+            if (a.tr_flat) a.tr_flat[((size_t)it * a.mu_max + s) * a.n + b] = -1;
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < GPT; ++r)
+        if (R.valid[r] && R.kb[r] == 0) store_letter(a.prop, a.propT, g, a.n_pad, b, R.l[r], (uint8_t)R.cur[r]);
+    PPDE_STAMP(a.dbg, 19, stamp);
+}
+
+// ------------------------------------------------------------------------------------------------
+// The forward path on the DEVICE RNG (rng_mode 1): the same categorical per sub-step as propose_body, drawn in two levels
+// (fill_race_variates) and organised around what bounds these kernels, instruction issue (two waves per SIMD, ~400
+// instructions per wave and sub-step in the flat form):
+//  * a FIXED softmax reference for the whole path. The gradient row is frozen along the path and a logit is
+//    (g[l][k] - g[l][current letter]) / 2, so half the largest spread of an admissible residue's 20 entries bounds every logit
+//    of every sub-step from above (and 0, the current letter's logit, is reached): exp(z - mref) never overflows, no maximum
+//    is reduced per sub-step, and softmax(z) = exp(z - mref) / sum exp(z - mref) whatever the reference is;
+//  * a move changes the logits of ONE residue (and, with a mutation cap, possibly the cap's mask): after the first sub-step
+//    only the wave(s) holding that residue re-evaluate their exponentials and their partial sum, the others go straight to
+//    the barrier;
+//  * the clamp, the residue masses, both races and the clamped row sum S3 are the work of ceil(L / 64) "race waves" (wave w:
+//    residues 64 w .. 64 w + 63, one per lane), each followed by the letter race inside ITS candidate residue (the letter
+//    variates do not depend on the residue, so racing them speculatively per candidate draws from the same law); the records
+//    (race value, residue, letter, probability, partial S3) meet behind the second barrier, where every wave picks the
+//    winner. Two barriers per sub-step, as before.
+// The winner's forward log-probability (a division and a logarithm) is evaluated after the loop, one sub-step per thread.
+template <int GPT>
+__device__ __forceinline__ void propose_body_dev(const PasArgs& a, const RowLds& lds, RowRegs<GPT>& R, int b, int it, int dist0,
+                                                 const ProposePrefetch<GPT>& pp, bool stamp) {
+    int dist = dist0;
+    const Geom g = a.g;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const float* G = (const float*)lds.G;
+    const int Ub = __builtin_amdgcn_readfirstlane(pp.Ub);
+    float mref = 0.f;
+    {
+        float d = 0.f;
+        for (int l = a.min_pos + lane; l <= a.max_pos; l += 64) {
+            const float4* gp = lds.G + 5 * l;
+            const float4 g0 = lds_load4(gp), g1 = lds_load4(gp + 1), g2 = lds_load4(gp + 2), g3 = lds_load4(gp + 3), g4 = lds_load4(gp + 4);
+            const float mx = fmaxf(fmaxf(fmaxf(fmaxf(g0.x, g0.y), fmaxf(g0.z, g0.w)), fmaxf(fmaxf(g1.x, g1.y), fmaxf(g1.z, g1.w))),
+                                   fmaxf(fmaxf(fmaxf(fmaxf(g2.x, g2.y), fmaxf(g2.z, g2.w)), fmaxf(fmaxf(g3.x, g3.y), fmaxf(g3.z, g3.w))),
+                                         fmaxf(fmaxf(g4.x, g4.y), fmaxf(g4.z, g4.w))));
+            const float mn = fminf(fminf(fminf(fminf(g0.x, g0.y), fminf(g0.z, g0.w)), fminf(fminf(g1.x, g1.y), fminf(g1.z, g1.w))),
+                                   fminf(fminf(fminf(fminf(g2.x, g2.y), fminf(g2.z, g2.w)), fminf(fminf(g3.x, g3.y), fminf(g3.z, g3.w))),
+                                         fminf(fminf(g4.x, g4.y), fminf(g4.z, g4.w))));
+            d = fmaxf(d, (mx - mn) * 0.5f);
+        }
+        // (beyond 64 the reference stops following the spread: logits up to 64 + 88 still evaluate, and whatever underflows
+        //  against a reference of 64 lies below the 2^-23 clamp floor of the categorical anyway)
+        mref = fminf(wave_max(d), 64.f);
+    }
+    const int NWR = (g.L + 63) >> 6;                 // race waves (L <= 307: at most five)
+    const int LQ = pas_lq(g.L), RB4 = 4 * pas_rb(g.L);
+    float* dpw = (float*)lds.mv;                     // deferred log-probabilities: winner's probability and S3 per sub-step
+    float* ds3 = dpw + 128;
+    int pend_l = 0, pend_k = 0;                      // the last move, not yet applied to lds.St
+    int ls_prev = -1;
+    bool capped_prev = false;
+    float4 e[GPT];                                   // this thread's exponentials (kept across sub-steps)
+    for (int s = 0; s < Ub; ++s) {
+        const bool capped = dist >= a.thr;
+        // ---- pass 1 (only where something changed): z = (g - g[current letter]) / 2 with the forward masks (ppde.py:98-104),
+        //      e = exp(z - mref) -> LDS, the wave's partial sum of them
+        bool upd = (s == 0);                         // (the first sub-step: every wave, also one without a valid lane, posts its sum)
+#pragma unroll
+        for (int r = 0; r < GPT; ++r) upd |= R.valid[r] & ((R.l[r] == ls_prev) | (capped != capped_prev));
+        PPDE_STAMP(a.dbg, 10 + 4 * min(s, 1), stamp);
+        if (__any(upd)) {
+            float sm = 0.f;
+#pragma unroll
+            for (int r = 0; r < GPT; ++r) {
+                e[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (!R.valid[r]) continue;
+                const float4 z = forward_logits(a, G, R.gv[r], R.l[r], R.kb[r], R.cur[r], R.wt[r], capped);
+                e[r].x = expf(z.x - mref); e[r].y = expf(z.y - mref); e[r].z = expf(z.z - mref); e[r].w = expf(z.w - mref);
+                sm += e[r].x; sm += e[r].y; sm += e[r].z; sm += e[r].w;
+                lds.Pv[tid + r * PPDE_BLOCK] = e[r];
+            }
+            const float sw = wave_sum(sm);
+            if (lane == 0) lds.xa[wave] = sw;
+        }
+        // the next PAS_QS sub-steps' variates (the race waves finished with the previous ones before the last barrier)
+        if (s > 0 && (s % PAS_QS) == 0) fill_race_variates(a, lds, b, it, s, min(PAS_QS, Ub - s));
+        __syncthreads();
+        if (tid == 0 && s > 0) lds.St[pend_l] = (uint8_t)pend_k;   // every wave has left the previous sub-step
+        PPDE_STAMP(a.dbg, 11 + 4 * min(s, 1), stamp);
+        // ---- race waves: softmax -> clamp (ppde/utils.py:106-111) of one residue per lane, its mass, both races, partial S3
+        if (wave < NWR) {
+            float S1 = row8_sum(lane < PPDE_NW ? lds.xa[lane & (PPDE_NW - 1)] : 0.f);
+            if (!(S1 > 0.f && S1 < INFINITY)) {       // no admissible move (or a non-finite gradient): the reference raises here
+                if (tid == 0) flag_error(a.err_flag, 1);
+                S1 = 1.f;
+            }
+            const float c = 1.0f / S1;
+            const float* qs = lds.qv + (s % PAS_QS) * LQ;
+            const int l = wave * 64 + lane;
+            const bool ok = l < g.L;
+            const int la = ok ? l : g.L - 1;
+            const float4* pe = lds.Pv + 5 * la;
+            float4 p0 = lds_load4(pe), p1 = lds_load4(pe + 1), p2 = lds_load4(pe + 2), p3 = lds_load4(pe + 3), p4 = lds_load4(pe + 4);
+            const float rq = qs[la];
+            auto clamp4 = [&](float4& p) {
+                p.x = __builtin_amdgcn_fmed3f(p.x * c, PPDE_EPS, 1.0f - PPDE_EPS); p.y = __builtin_amdgcn_fmed3f(p.y * c, PPDE_EPS, 1.0f - PPDE_EPS);
+                p.z = __builtin_amdgcn_fmed3f(p.z * c, PPDE_EPS, 1.0f - PPDE_EPS); p.w = __builtin_amdgcn_fmed3f(p.w * c, PPDE_EPS, 1.0f - PPDE_EPS);
+            };
+            clamp4(p0); clamp4(p1); clamp4(p2); clamp4(p3); clamp4(p4);
+            const float4 t = add4(add4(add4(p0, p1), add4(p2, p3)), p4);
+            const float P = (t.x + t.y) + (t.z + t.w);            // residue mass, a fixed tree over its 20 letters
+            const float S3w = wave_sum(ok ? P : 0.f);
+            float vw;
+            const int wl = wave_argmax_lane(ok ? P * rq : -1.f, l, vw);      // (lanes ascend with the residue: the first wins a tie)
+            const int lw = min(wave * 64 + wl, g.L - 1);
+            // the letter inside this wave's candidate residue (lane = letter)
+            const int kl = min(lane, PPDE_A - 1);
+            const float pk = __builtin_amdgcn_fmed3f(((const float*)lds.Pv)[lw * PPDE_A + kl] * c, PPDE_EPS, 1.0f - PPDE_EPS);
+            float vk;
+            const int kw = wave_argmax_lane(lane < PPDE_A ? pk * qs[RB4 + kl] : -1.f, lane, vk);
+            const float pw = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, pk), kw));
+            if (lane == 0) {
+                *(float4*)(lds.xb + 8 * wave) = make_float4(vw, __int_as_float(lw), __int_as_float(kw), pw);
+                lds.xb[8 * wave + 4] = S3w;
+            }
+        }
+        __syncthreads();
+        // ---- every wave: the winner among the race waves' candidates (records ascend with the residue: the first maximum has
+        //      the smallest index)
+        int win;
+        {
+            const float rv = lane < NWR ? lds.xb[8 * (lane & 7)] : -1.f;
+            const float vm = row8_max(rv);
+            const int W = __builtin_amdgcn_readfirstlane(__ffsll((long long)__ballot(lane < NWR && rv == vm)) - 1) & 7;
+            const float4 rec = *(const float4*)(lds.xb + 8 * W);
+            win = min(__float_as_int(rec.y), g.L - 1) * PPDE_A + min(__float_as_int(rec.z), PPDE_A - 1);
+            if (tid == 0) {                          // for the forward log-probability, Categorical.log_prob = log(clamp(p / S3))
+                float s3 = 0.f;
+                for (int w = 0; w < NWR; ++w) s3 += lds.xb[8 * w + 4];
+                dpw[s] = rec.w; ds3[s] = s3;
+            }
+        }
+        PPDE_STAMP(a.dbg, 12 + 4 * min(s, 1), stamp);
+        const int ls = win / 20, ks = win - 20 * ls;
+        const int old = lds.St[ls];                  // (lds.St follows the path: the previous move was applied behind the first barrier)
+        const int wlt = lds.Wt[ls];
+#pragma unroll
+        for (int r = 0; r < GPT; ++r)
+            if (R.l[r] == ls) R.cur[r] = ks;
+        dist += (int)(ks != wlt) - (int)(old != wlt);
+        pend_l = ls; pend_k = ks;
+        ls_prev = ls; capped_prev = capped;
+        if (tid == 0) {
+            rec_flat(rec_of(a, b))[s] = win;
+            if (a.tr_flat) a.tr_flat[((size_t)it * a.mu_max + s) * a.n + b] = win;
+        }
+        PPDE_STAMP(a.dbg, 13 + 4 * min(s, 1), stamp);
+    }
+    PPDE_STAMP(a.dbg, 18, stamp);
+    // forward log-probabilities of the path: a masked entry keeps 2^-23 after the clamp (ppde/utils.py:106-111), so it CAN win
+    // a race; its log-probability is log(2^-23 / S3) like any other entry's
+    if (a.mu_max > 64) __syncthreads();              // (paths longer than a wavefront: thread 0's last entries must be visible to wave 1)
+    if (tid < Ub) rec_logp(rec_of(a, b), a.mu_max)[tid] = logf(clampp(dpw[tid] / ds3[tid]));
     if (tid == 0) {
         ChainRec* rc = rec_of(a, b);
         rc->Ucur = Ub;
@@ -773,7 +902,8 @@ __global__ __launch_bounds__(PPDE_BLOCK) void k_propose(PasArgs a) {
     const ProposePrefetch<GPT> pp = propose_prefetch<GPT, EXACT>(a, lds, b, it);
     row_commit<GPT>(lds, a.g, rl, R);
     PPDE_STAMP(a.dbg, 9, stamp);
-    propose_body<GPT, EXACT>(a, lds, R, b, it, __builtin_amdgcn_readfirstlane(pp.dist), pp, stamp);
+    if constexpr (EXACT) propose_body<GPT, true>(a, lds, R, b, it, __builtin_amdgcn_readfirstlane(pp.dist), pp, stamp);
+    else propose_body_dev<GPT>(a, lds, R, b, it, __builtin_amdgcn_readfirstlane(pp.dist), pp, stamp);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1054,7 +1184,7 @@ __global__ __launch_bounds__(PPDE_BLOCK) void k_accept_propose(PasArgs a) {
     for (int r = 0; r < GPT; ++r)
         if (R.valid[r] && R.kb[r] == 0) lds.St[R.l[r]] = (uint8_t)R.cur[r];
     __syncthreads();
-    propose_body<GPT, false>(a, lds, R, b, it + 1, o.dist, pp, stamp);   // (fused launches exist on the device RNG only)
+    propose_body_dev<GPT>(a, lds, R, b, it + 1, o.dist, pp, stamp);   // (fused launches exist on the device RNG only)
 }
 
 // history row 0 and the running best from the initial population (ppde.py:38-47): one wave per chain

@@ -1,6 +1,7 @@
 // Host side of the C ABI declared in include/ppde_hip.h: device memory ownership, weight re-layout,
 // kernel launches, hipGraph capture of the iteration loop.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -176,7 +177,10 @@ struct EvalTargets {
 static int potts_ng_for(int n) { return n <= 64 ? 1 : 2; }
 
 
-// When set, every Potts launch is bracketed by a pair of events taken from this pool (in-situ timing).
+// When set, every Potts launch carries a (start, stop) event pair taken from this pool (in-situ timing): the launch goes
+// through hipExtLaunchKernelGGL, which attaches the events to the DISPATCH ITSELF -- the kernel's own begin / end timestamps as
+// the command processor records them, the same source rocprofv3's kernel trace reads -- with no extra packet on the stream (an
+// hipEventRecord pair around the launch adds two barrier packets and ~2 us to what it measures).
 struct EventPool {
     std::vector<hipEvent_t> ev;
     size_t used = 0;
@@ -188,8 +192,12 @@ static int launch_potts(const ppde_model* m, const States& st, int n, const Eval
                         int b_off = 0, int n_sub = -1) {
     if (n_sub < 0) n_sub = n;
     EventPool* ep = g_potts_events;
-    if (ep && ep->used + 2 <= ep->ev.size()) HIPCHK(hipEventRecord(ep->ev[ep->used++], s));
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    if (ep && ep->used + 2 <= ep->ev.size()) { ev0 = ep->ev[ep->used++]; ev1 = ep->ev[ep->used++]; }
     else ep = nullptr;
+    // one launch form for every instantiation: plain, or with the dispatch's own start / stop events
+#define PPDE_PL(K) do { if (ep) hipExtLaunchKernelGGL(K, grid, dim3(256), (uint32_t)lds, s, ev0, ev1, 0, a, nby); \
+                        else hipLaunchKernelGGL(K, grid, dim3(256), lds, s, a, nby); } while (0)
     ARGCHK(st.T && st.n_pad >= n + 256, "the states have no transposed copy for the Potts kernel");
     PottsArgs a{};
     a.b_off = b_off; a.n_sub = n_sub; a.dbg = t.dbg;
@@ -215,16 +223,16 @@ static int launch_potts(const ppde_model* m, const States& st, int n, const Eval
         const bool g4 = potts_groups(m->g.NC) <= 4;             // letters of <= 4 chunk groups per wave: 5 workgroups per CU
         bool launched = false;
         if (nc_spec && g4) {
-#define PPDE_PR(v) case v: if (NG == 1) hipLaunchKernelGGL((potts_energy_grad_kernel<1, true, 4, v>), grid, dim3(256), lds, s, a, nby); \
-                           else hipLaunchKernelGGL((potts_energy_grad_kernel<2, true, 4, v>), grid, dim3(256), lds, s, a, nby); launched = true; break;
+#define PPDE_PR(v) case v: if (NG == 1) PPDE_PL((potts_energy_grad_kernel<1, true, 4, v>)); \
+                           else PPDE_PL((potts_energy_grad_kernel<2, true, 4, v>)); launched = true; break;
             switch (m->g.NC) { PPDE_PR(9) PPDE_PR(10) PPDE_PR(11) PPDE_PR(12) PPDE_PR(13) PPDE_PR(14) PPDE_PR(15) PPDE_PR(16) default: break; }
 #undef PPDE_PR
         }
         if (launched) { }
-        else if (NG == 1 && g4) hipLaunchKernelGGL((potts_energy_grad_kernel<1, true, 4>), grid, dim3(256), lds, s, a, nby);
-        else if (NG == 1) hipLaunchKernelGGL((potts_energy_grad_kernel<1, true, 8>), grid, dim3(256), lds, s, a, nby);
-        else if (g4) hipLaunchKernelGGL((potts_energy_grad_kernel<2, true, 4>), grid, dim3(256), lds, s, a, nby);
-        else hipLaunchKernelGGL((potts_energy_grad_kernel<2, true, 8>), grid, dim3(256), lds, s, a, nby);
+        else if (NG == 1 && g4) PPDE_PL((potts_energy_grad_kernel<1, true, 4>));
+        else if (NG == 1) PPDE_PL((potts_energy_grad_kernel<1, true, 8>));
+        else if (g4) PPDE_PL((potts_energy_grad_kernel<2, true, 4>));
+        else PPDE_PL((potts_energy_grad_kernel<2, true, 8>));
     } else {
         ARGCHK(m->g.NC <= 8, "Potts window too long for the resident-slab kernel (the ring variant takes it)");
         const size_t lds = potts_lds_bytes(m->g.NC, NG);
@@ -232,19 +240,19 @@ static int launch_potts(const ppde_model* m, const States& st, int n, const Eval
         const dim3 grid(tiles * nby);
         bool launched = false;
         if (nc_spec && NG <= 2) {
-#define PPDE_PS(v) case v: if (NG == 1) hipLaunchKernelGGL((potts_energy_grad_kernel<1, false, 2, v>), grid, dim3(256), lds, s, a, nby); \
-                           else hipLaunchKernelGGL((potts_energy_grad_kernel<2, false, 2, v>), grid, dim3(256), lds, s, a, nby); launched = true; break;
+#define PPDE_PS(v) case v: if (NG == 1) PPDE_PL((potts_energy_grad_kernel<1, false, 2, v>)); \
+                           else PPDE_PL((potts_energy_grad_kernel<2, false, 2, v>)); launched = true; break;
             switch (m->g.NC) { PPDE_PS(1) PPDE_PS(2) PPDE_PS(3) PPDE_PS(4) PPDE_PS(5) PPDE_PS(6) PPDE_PS(7) PPDE_PS(8) default: break; }
 #undef PPDE_PS
         }
         if (!launched) switch (NG) {
-            case 1: hipLaunchKernelGGL(potts_energy_grad_kernel<1>, grid, dim3(256), lds, s, a, nby); break;
-            case 2: hipLaunchKernelGGL(potts_energy_grad_kernel<2>, grid, dim3(256), lds, s, a, nby); break;
-            default: hipLaunchKernelGGL(potts_energy_grad_kernel<4>, grid, dim3(256), lds, s, a, nby); break;
+            case 1: PPDE_PL(potts_energy_grad_kernel<1>); break;
+            case 2: PPDE_PL(potts_energy_grad_kernel<2>); break;
+            default: PPDE_PL(potts_energy_grad_kernel<4>); break;
         }
     }
+#undef PPDE_PL
     HIPCHK(hipGetLastError());
-    if (ep) HIPCHK(hipEventRecord(ep->ev[ep->used++], s));
     return PPDE_OK;
 }
 

@@ -13,7 +13,9 @@ import torch.distributed as dist
 # PPDE_COLLECTIVES_AT_WORLD_1=1: run the collectives below even in a process group of ONE rank (where they are the
 # identity). It lets a one-GPU box execute the RCCL path end to end -- library load, communicator set-up, host -> device
 # staging, all_gather / broadcast, the way back -- before an 8-GPU node ever sees it (tests/test_host_gpu.py).
-FORCE_AT_WORLD_1 = bool(os.environ.get("PPDE_COLLECTIVES_AT_WORLD_1"))
+def force_at_world_1():
+    """Read at every call (not at import), '' and '0' mean off -- as the library's atoi-style knobs."""
+    return os.environ.get("PPDE_COLLECTIVES_AT_WORLD_1", "0") not in ("", "0")
 
 
 def world():
@@ -25,7 +27,7 @@ def world():
 def active():
     """True when the collectives below actually communicate: more than one rank, or forced at world size 1."""
     _, ws = world()
-    return ws > 1 or (FORCE_AT_WORLD_1 and dist.is_available() and dist.is_initialized())
+    return ws > 1 or (force_at_world_1() and dist.is_available() and dist.is_initialized())
 
 
 def shard_range(n, rank, world_size):

@@ -124,13 +124,15 @@ class Chains:
         return dict(captures=a.value, captures_in_run=b.value, replayed_steps=r.value, eager_steps=e.value)
 
     def philox_dump(self, it, s):
-        dev, n, N = self.model.device, self.n, self.model.L * 20
-        q = torch.empty(n, N, device=dev)
+        """What the device RNG draws for sub-step s of iteration it: (q [n, L + 20] Exp(1) race variates of the two-level draw --
+        residue race [:, :L], letter race [:, L:] --, u [n] accept uniforms, U [n] path lengths)."""
+        dev, n, L = self.model.device, self.n, self.model.L
+        q = torch.empty(n, L * 20, device=dev)
         u = torch.empty(n, device=dev)
         U = torch.empty(n, dtype=torch.int32, device=dev)
         torch.cuda.current_stream(dev).synchronize()
         _hip.check(self.lib.ppde_chains_philox_dump(self.handle, int(it), int(s), _hip.ptr(q), _hip.ptr(u), _hip.ptr(U)))
-        return q, u, U
+        return q[:, :L + 20].contiguous(), u, U
 
     def time_potts_in_situ(self, iters=200):
         """Mean duration (us) of the Potts kernel launches inside `iters` real iterations, and how many were timed."""

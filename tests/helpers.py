@@ -110,8 +110,7 @@ def compare_runs_up_to_near_ties(tr, ref, noise, gap_tol, acc_tol):
             d = tr["flat"][t, s]
             o = out["flat"][s].numpy()
             for b in np.nonzero(live & (d != o))[0]:
-                v = out["p_fwd"][s][b] / q[s][b]
-                gap = 1.0 - float(v[int(d[b])] / v.max())
+                gap = orc.race_gap(out["p_fwd"][s][b], q[s][b], int(d[b]))
                 assert gap <= gap_tol, f"chain {b} iteration {t} sub-step {s}: device drew {int(d[b])}, oracle {int(o[b])}, race gap {gap:.3e}"
                 parted[b] = True
                 notes.append((int(b), t, f"draw {s}", gap))

@@ -36,6 +36,9 @@ hipError_t hipLaunchKernel(const void*, dim3 g, dim3 b, void**, size_t sh, hipSt
     if (g.x == 0 || g.y == 0 || g.z == 0 || b.x == 0 || b.x * b.y * b.z > 1024 || sh > 160 * 1024) return hipErrorInvalidConfiguration;
     return hipSuccess;
 }
+hipError_t hipExtLaunchKernel(const void* f, dim3 g, dim3 b, void** args, size_t sh, hipStream_t st, hipEvent_t, hipEvent_t, int) {
+    return hipLaunchKernel(f, g, b, args, sh, st);
+}
 hipError_t hipGetDeviceCount(int* n) { *n = 1; return hipSuccess; }
 hipError_t hipSetDevice(int d) { return d == 0 ? hipSuccess : hipErrorInvalidDevice; }
 hipError_t hipGetLastError() { return hipSuccess; }

@@ -243,10 +243,8 @@ def test_philox_stream_matches_numpy():
         q, u, U = ch.philox_dump(it, s)
         k = np.array([seed & 0xffffffff, seed >> 32], dtype=np.uint32)
         chain = (off + np.arange(n)).astype(np.uint32)
-        ctr = np.zeros((n, N // 4, 4), dtype=np.uint32)
-        ctr[..., 0] = chain[:, None]; ctr[..., 1] = it; ctr[..., 2] = 2 + s; ctr[..., 3] = np.arange(N // 4)[None]
-        r = orc.philox4x32(ctr, k).reshape(n, N)
-        qe = -np.log(((r >> 9).astype(np.float32) + np.float32(0.5)) * np.float32(2.0 ** -23))
+        qe = orc.device_race_variates(seed, off, n, it, s, N // 20)          # two-level draw: L residue + 20 letter variates
+        assert q.shape == (n, N // 20 + 20)
         assert np.abs(q.cpu().numpy() - qe).max() <= 4e-7 * np.abs(qe).max() + 1e-12
         c1 = np.zeros((n, 4), dtype=np.uint32); c1[:, 0] = chain; c1[:, 1] = it; c1[:, 2] = 1
         ue = (orc.philox4x32(c1, k)[:, 0] >> 8).astype(np.float32) * np.float32(2.0 ** -24)
@@ -256,14 +254,14 @@ def test_philox_stream_matches_numpy():
         assert np.array_equal(U.cpu().numpy().astype(np.int64), Ue)
 
 
-def _philox_run(m, n, T, pas, nmut, paper, i0, Lp, wt_idx, off=0, rows=None, **kw):
+def _philox_run(m, n, T, pas, nmut, paper, i0, Lp, wt_idx, off=0, rows=None, which=3, trace=True, **kw):
     from ppde_amd.sampler import Chains
     lo, hi = rows if rows else (0, n)
-    ch = Chains(m, hi - lo, T, pas, nmut, paper, i0, i0 + Lp - 1, 3, 1, trace=True, random_chain=0,
+    ch = Chains(m, hi - lo, T, pas, nmut, paper, i0, i0 + Lp - 1, which, 1, trace=trace, random_chain=0,
                 seed=99, chain_offset=off + lo, **kw)
     ch.init(torch.as_tensor(np.tile(wt_idx, (hi - lo, 1))).cuda())
     ch.run(T)
-    return ch, ch.trace(), ch.collect()
+    return ch, ch.trace() if trace else None, ch.collect()
 
 
 def test_philox_mode_vs_oracle_and_invariances():
@@ -324,18 +322,20 @@ def test_specialised_chain_kernels_equal_the_general_ones(which, nmut, reuse):
     assert (res[0]["energy_history"][1:] != res[0]["energy_history"][:-1]).any()
 
 
-def test_full_size_properties():
-    """BASELINE config sizes (128 chains, PABP, 1000 steps): properties that need no oracle run."""
+@pytest.mark.parametrize("which", [1, 3])
+def test_full_size_properties(which):
+    """BASELINE config sizes (128 chains, PABP; which = 1: config 2's Potts product of experts, 3: config 3's Potts + CNN):
+    properties that need no oracle run, and every way of issuing the same run gives the same bits."""
     fx, J, h, i0, wt_idx, cnn, m = _philox_setup()
     n, T, Lp, L = 128, 300, J.shape[0], wt_idx.shape[0]
-    ch, tr, res = _philox_run(m, n, T, 2, 10, False, i0, Lp, wt_idx)
+    ch, tr, res = _philox_run(m, n, T, 2, 10, False, i0, Lp, wt_idx, which=which)
     eh = res["energy_history"]
     assert np.isfinite(eh).all()
     assert np.array_equal(res["best_energy"], eh.max(0))                        # running best == max over history
     assert np.array_equal(res["best_step"], eh.argmax(0))                       # first index on ties
     assert (res["best_idx"] < 20).all()
     # the recorded best state really has the recorded best energy
-    e, f, _ = m.energy_grad(torch.as_tensor(res["best_idx"]).cuda(), 3, want_grad=False)
+    e, f, _ = m.energy_grad(torch.as_tensor(res["best_idx"]).cuda(), which, want_grad=False)
     assert np.array_equal(e.cpu().numpy(), res["best_energy"])
     assert np.array_equal(f.cpu().numpy(), res["best_fitness"])
     # a rejected step repeats the previous energy exactly; an accepted one generally changes it
@@ -343,15 +343,48 @@ def test_full_size_properties():
     pk = ch.peek()
     assert (pk["dist"] < 10).all()                                              # mutation cap enforced after every step
     # a rejected step repeats the energy it started from: the previous row, or the wild type's after a cap reset
-    e_wt = m.energy_grad(torch.as_tensor(wt_idx).reshape(1, -1).cuda(), 3, want_grad=False)[0].cpu().numpy()[0]
+    e_wt = m.energy_grad(torch.as_tensor(wt_idx).reshape(1, -1).cuda(), which, want_grad=False)[0].cpu().numpy()[0]
     same = (eh[1:] == eh[:-1]) | (eh[1:] == e_wt)
     assert same[~acc].all()
     assert 0.02 < acc.mean() < 0.98
     # 100-iteration graph replays + the eager remainder == every iteration launched eagerly
-    _, tr2, res2 = _philox_run(m, n, T, 2, 10, False, i0, Lp, wt_idx, use_graph=False)
+    _, tr2, res2 = _philox_run(m, n, T, 2, 10, False, i0, Lp, wt_idx, which=which, use_graph=False)
     for k in ("energy_history", "fitness_history", "best_idx", "best_step"):
         assert np.array_equal(res[k], res2[k]), k
     assert np.array_equal(tr["flat"], tr2["flat"]) and np.array_equal(tr["accepted"], tr2["accepted"])
+    # the way bench.py issues it: no trace buffers (the specialised chain kernels), graph replay, either evaluation policy
+    for reuse in (False, True):
+        _, _, res3 = _philox_run(m, n, T, 2, 10, False, i0, Lp, wt_idx, which=which, trace=False, reuse_grad=reuse, use_graph=True)
+        for k in ("energy_history", "fitness_history", "best_idx", "best_step", "random_traj"):
+            assert np.array_equal(res[k], res3[k]), (reuse, k)
+
+
+def test_config2_composition_against_the_oracle():
+    """BASELINE config 2 exactly as bench.py runs it -- 128 chains, Potts-only product of experts (which = 1), PABP geometry,
+    no mutation cap, device RNG, re-evaluating policy, hipGraph replay, no trace buffers: the stand-alone Potts kernel and the
+    specialised k_propose / k_accept instantiations -- against the oracle fed with the device's own noise (T = 20)."""
+    fx, J, h, i0, wt_idx, cnn, m = _philox_setup()
+    n, T, pas, Lp = 128, 20, 2, J.shape[0]
+    ch, tr, res = _philox_run(m, n, T, pas, 0, False, i0, Lp, wt_idx, which=1, reuse_grad=False, use_graph=False)
+    from helpers import device_noise
+    noise = device_noise(ch, T, pas)
+    en = oracle_energy(J, h, i0, wt_idx, None, 0.0)
+    ref = orc.run(en, np.tile(wt_idx.astype(np.int64), (n, 1)), wt_idx, lambda t: noise[t], T, i0, i0 + Lp - 1, pas, 0, False, trace=True)
+    for t in range(T):
+        U = noise[t][0].numpy()
+        assert np.array_equal(tr["U"][t], U)
+        for s in range(int(U.max())):
+            act = s < U
+            assert np.array_equal(tr["flat"][t, s][act], ref["traces"][t]["flat"][s].numpy()[act]), (t, s)
+    assert np.array_equal(tr["accepted"].astype(bool), ref["accepted"].numpy())
+    assert np.abs(res["energy_history"] - ref["energy_history"].numpy()).max() <= 2e-5
+    assert np.array_equal(res["best_idx"], ref["best_idx"].numpy())
+    assert (res["fitness_history"] == 0).all()                                  # no supervised expert in this energy
+    for reuse in (False, True):                                                 # the untraced, graph-replayed runs bench.py times
+        ch3, _, res3 = _philox_run(m, n, T, pas, 0, False, i0, Lp, wt_idx, which=1, trace=False, reuse_grad=reuse, use_graph=True)
+        assert ch3.graph_stats()["replayed_steps"] == T
+        for k in ("energy_history", "fitness_history", "best_idx", "best_step", "random_traj"):
+            assert np.array_equal(res[k], res3[k]), (reuse, k)
 
 
 def test_error_paths():
@@ -413,11 +446,11 @@ def test_masked_entry_winning_the_race_keeps_the_clamp_probability():
     from ppde_amd.energy import HipModel
     from ppde_amd.sampler import Chains
     from ppde_amd import synthetic
-    L, Lp, i0, n, T, pas, lo, hi = 64, 4, 49, 64, 40, 3, 29, 36
+    L, Lp, i0, n, T, pas, lo, hi = 64, 4, 49, 128, 40, 3, 29, 36
     wt = np.random.default_rng(19).integers(0, 20, L).astype(np.uint8)
     J, h = synthetic.make_potts(Lp, seed=19)
     m = HipModel(wt, "cuda:0"); m.set_potts(J, h, i0); m.set_lamda(0.0)
-    ch = Chains(m, n, T, pas, 0, False, lo, hi, 1, 1, trace=True, random_chain=0, seed=1019, use_graph=False)
+    ch = Chains(m, n, T, pas, 0, False, lo, hi, 1, 1, trace=True, random_chain=0, seed=1020, use_graph=False)
     ch.init(torch.as_tensor(np.tile(wt, (n, 1))).cuda())
     ch.run(T)
     tr, res = ch.trace(), ch.collect()

@@ -44,9 +44,12 @@ def _case(L, Lp, i0, positions, pas, nmut, with_cnn, lam, seed, hip=True):
     return m, wt, K, states, en
 
 
-def test_exact_kernel_against_the_oracles_own_sampler():
+@pytest.mark.parametrize("two_level", [False, True])
+def test_exact_kernel_against_the_oracles_own_sampler(two_level):
     """The enumeration (helpers.exact_pas_kernel) checked without a GPU: 40 000 oracle chains on torch's CPU noise, one
-    iteration from two start states, against rows of K."""
+    iteration from two start states, against rows of K -- with the reference's flat race (L*20 variates per draw) and with
+    the two-level draw the HIP path uses on its device RNG (residue, then letter: L + 20 variates; oracle race_sample): the
+    enumeration is built with the flat race, so this also checks that both draws have the same law, clamp-floor leak included."""
     import ppde_oracle as orc
     L, positions, pas = 6, [3], 2
     _, wt, K, states, en = _case(L, 5, 1, positions, pas, 0, False, 0.0, seed=31, hip=False)
@@ -54,7 +57,7 @@ def test_exact_kernel_against_the_oracles_own_sampler():
     assert np.allclose(K.sum(1), 1.0) and (K >= 0).all() and K[:, S].max() < 1e-3
     gen = torch.Generator().manual_seed(5)
     for start in (int(wt[3]), (int(wt[3]) + 10) % 20):
-        U, q, u = orc.draw_noise_torch(n, L * 20, pas, generator=gen)
+        U, q, u = orc.draw_noise_torch(n, L + 20 if two_level else L * 20, pas, generator=gen)
         x = states[start].repeat(n, 1)
         out = orc.pas_iteration(en, x, x, torch.as_tensor(wt.astype(np.int64)), U.reshape(-1), q, u, 3, 3, np.iinfo(np.int32).max)
         idx = out["idx"].numpy()
@@ -70,6 +73,7 @@ def test_exact_kernel_against_the_oracles_own_sampler():
     ("two residues, single moves", 7, 6, 0, [2, 3], 1, 0, False, 0.0),
     ("one residue, Potts + CNN", 8, 6, 1, [4], 2, 0, True, 2.0),
     ("two residues, mutation cap 2", 7, 6, 0, [2, 3], 1, 2, False, 0.0),
+    ("one residue beyond the first 64 (second round of the residue race), paths of 1-3 moves", 70, 6, 62, [66], 2, 0, False, 0.0),
 ])
 def test_distribution_after_T_iterations_equals_the_exact_chain(name, L, Lp, i0, positions, pas, nmut, with_cnn, lam):
     from ppde_amd.sampler import Chains
