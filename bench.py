@@ -147,13 +147,16 @@ def cnn_useful_flops(n, L, nets=3, K=5):
     return nets * 2.0 * n * T * C * (F + K * 20)
 
 
-def also_config3(args, device, rank):
-    """BASELINE configs[2] (PABP Potts + supervised CNN, lamda = 5, 128 chains) in a few short blocks, for the N = 1 line."""
+def also_poe(args, device, rank, protein="PABP", lamda=5.0, steps=200, warm=40, reps=3, what="BASELINE configs[2]"):
+    """A Potts + supervised CNN product of experts in a few short blocks, for the N = 1 line: BASELINE configs[2] (PABP, lamda = 5,
+    128 chains) and the per-GPU share of configs[3] as the reference would run it (GFP, 128 chains, lamda = 15: energy.py:104
+    evaluates the CNN whatever lamda is, README.md:65-72 recommends 15 for GFP)."""
     import torch
     from ppde_amd.sampler import Chains
     from bench_transformer import rocprof_frac
-    m, wt, J, h, i0, Lp, cnn = build_model("potts+cnn", device, "PABP")
-    n, L, steps, warm, reps = 128, wt.shape[0], 200, 40, 3
+    m, wt, J, h, i0, Lp, cnn = build_model("potts+cnn", device, protein, lamda)
+    n, L = 128, wt.shape[0]
+    pname = {"PABP": "PABP_YEAST", "UBE4B": "UBE4B_MOUSE", "GFP": "GFP_AEQVI"}[protein]
     out = {}
     for reuse in (False, True):
         ch = Chains(m, n, warm + reps * steps + 8, args.pas, args.nmut, False, i0, i0 + Lp - 1, 3, 1, reuse_grad=reuse, random_chain=0,
@@ -171,32 +174,76 @@ def also_config3(args, device, rank):
             dts.append(time.perf_counter() - t0)
         dt = float(np.median(dts))
         if not reuse:
-            us = ch.time_experts(200)
+            us = ch.time_experts(200 if protein == "PABP" else 50)
             fl = cnn_useful_flops(n, L)
+            single = protein == "PABP"
             out.update(value=steps / dt, unit="steps/s", ms_per_step=dt / steps * 1e3, steps=steps, warmup=warm,
                        timed_blocks={"repeats": reps, "statistic": "median", "ms_per_block": [round(x * 1e3, 3) for x in dts]},
-                       workload=f"PABP_YEAST Potts + supervised CNN product of experts (lamda=5), L={L}, L'={Lp}, {n} chains, "
-                                f"pas_length={args.pas}, device Philox RNG, hipGraph replay", dtype="f32",
-                       roofline={"kernel": "k_experts (Potts tiles + 3-network CNN forward/backward in one launch)", "bound": "mfma",
-                                 "achieved": fl / (us * 1e-6) / 1e12, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
+                       workload=f"{pname} Potts + supervised CNN product of experts (lamda={lamda:g}), L={L}, L'={Lp}, {n} chains, "
+                                f"pas_length={args.pas}, device Philox RNG, hipGraph replay ({what})", dtype="f32 (CNN contractions: exact 3-term bf16 split on the bf16 matrix pipe, fp32 accumulate)",
+                       roofline={"kernel": "k_experts (Potts tiles + 3-network CNN forward/backward in one launch)" if single else
+                                           "all experts of one evaluation (Potts ring kernel + CNN forward chunks + CNN backward chunks)",
+                                 "bound": "mfma", "achieved": fl / (us * 1e-6) / 1e12, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
                                  "frac": fl / (us * 1e-6) / 1e12 / MFMA_F32_PEAK_TF, "traffic": None,
-                                 "algorithmic_flops_per_launch": fl, "avg_launch_us": us, "launches_timed": 200,
-                                 "rocprof": rocprof_frac("config3", "k_experts", fl, MFMA_F32_PEAK_TF * 1e12)})
+                                 "peak_note": "priced against the dense fp32 matrix peak the arithmetic is specified in (the kernels issue six "
+                                              "bf16 MFMAs per fp32 block: 6/16 of the bf16 pipe's time, so this fraction can exceed the fp32 pipe's)",
+                                 "algorithmic_flops_per_launch": fl, "avg_launch_us": us, "launches_timed": 200 if protein == "PABP" else 50,
+                                 "committed_profile": committed_profile("config3" if single else "gfp_cnn", "k_experts" if single else "k_cnn_fwd_chunk",
+                                                                        fl if single else None, MFMA_F32_PEAK_TF * 1e12, us if single else None)})
             assert np.isfinite(ch.collect()["energy_history"]).all()
         else:
             out["value_reuse_grad"] = steps / dt
         del ch
-    if not args.no_cpu_baseline:
+    if not args.no_cpu_baseline and protein == "PABP":
         a2 = argparse.Namespace(**{**vars(args), "cpu_seconds": 8.0})
         out["cpu_baseline"] = cpu_baseline(a2, wt, J, h, i0, Lp, cnn, n)
     return out
 
 
+def committed_profile(tag, kernel, work, peak, live_us):
+    """The same kernel's average in the newest committed rocprofv3 table (profiles/rNN_<tag>_kernel_stats.csv): a constant read
+    from that file, marked stale when it is more than 10 % away from what this run measured (a kernel changed after the profile)."""
+    from bench_transformer import rocprof_frac
+    st = rocprof_frac(tag, kernel, work, peak)
+    if st and live_us:
+        st["consistent_with_this_run"] = bool(abs(st["avg_launch_us"] - live_us) <= 0.10 * live_us)
+    return st
+
+
+def torch_rng_value(args, m, wt, i0, Lp, n, which, overlap=False, T=(50, 350)):
+    """The same workload as a drop-in user runs it (swap the imports, keep the command line): PPDE_PAS.run with
+    its default ppde_rng='torch' -- U, q, u drawn on the host with torch's CPU generator in the reference's order
+    (ppde.py:67, :109, :138) and uploaded, the trajectory the reference's seed gives. steps/s from the difference of a long and
+    a short run (construction, first log line and final collect cancel)."""
+    import contextlib
+    import io
+    import torch
+    from ppde_amd.encoding import idx_to_onehot
+    from ppde_amd.sampler import PPDE_PAS
+    a = argparse.Namespace(ppde_pas_length=args.pas, nmut_threshold=args.nmut, paper_results=False, ppde_rng="torch", seed=1,
+                           ppde_overlap_noise=overlap)
+    energy = type("Energy", (), {"model": m, "which": which})()
+    x0 = torch.from_numpy(idx_to_onehot(np.tile(wt, (n, 1)))).float().to(m.device)
+
+    def run(T):
+        torch.manual_seed(1)
+        np.random.seed(1)
+        s = PPDE_PAS(a)
+        t0 = time.perf_counter()
+        with contextlib.redirect_stdout(io.StringIO()):
+            s.run(x0, T, energy, i0, i0 + Lp - 1, lambda x: torch.zeros(x.shape[0]), log_every=10 ** 9)
+        return time.perf_counter() - t0
+
+    run(T[0])
+    t1, t2 = run(T[0]), run(T[1])
+    return (T[1] - T[0]) / max(t2 - t1, 1e-9)
+
+
 def also_config5(args, rank, local):
     """BASELINE configs[4] (UBE4B transformer product of experts, 256 chains) in a few short blocks, for the N = 1 line."""
     import bench_transformer
-    a5 = argparse.Namespace(**{**vars(args), "chains": 128, "reuse_grad": 0})
-    d = bench_transformer.measure(a5, rank, 1, local, "nccl", steps=4, warmup=1, repeats=3, with_cpu=False if args.no_cpu_baseline else "sample",
+    a5 = argparse.Namespace(**{**vars(args), "chains": 256, "reuse_grad": 0})
+    d = bench_transformer.measure(a5, rank, 1, local, "nccl", steps=4, warmup=1, repeats=3, with_cpu=False if args.no_cpu_baseline else "minibatch",
                                   other_policy=False)
     keep = ("value", "unit", "ms_per_step", "steps", "warmup", "timed_blocks", "dtype", "roofline", "evaluation", "cpu_baseline")
     out = {k: d[k] for k in keep if k in d}
@@ -313,19 +360,18 @@ def main():
     dt_other = float(np.median(dts_other))
     del ch_other
 
-    # dominant kernel: potts_energy_grad, timed live with HIP events on the stream it is launched on: 500 launches
-    # between one event pair (this is what rocprofv3's per-kernel average reports too: in its trace a kernel's
-    # interval starts where its predecessor ends). For the record also an event pair around EVERY launch inside
-    # real, eagerly launched iterations; that figure includes the two event packets themselves.
+    # dominant kernel: potts_energy_grad, timed live IN SITU: every Potts launch of IN_SITU real, eagerly launched iterations
+    # carries its own start / stop events (hipExtLaunchKernelGGL: the dispatch's begin / end timestamps as the command
+    # processor records them -- the source rocprofv3's kernel trace reads, so this is the figure profiles/ reproduces). Beside
+    # it, for the record: 500 launches back to back between one event pair (no dependent kernel in front of any of them).
     pk_situ_us, pk_launches = ch.time_potts_in_situ(IN_SITU)
     pk_us = ch.time_potts_kernel(500)
     alg_bytes = potts_alg_bytes(n, L, Lp)
-    achieved = alg_bytes / (pk_us * 1e-6) / 1e9
+    achieved = alg_bytes / (pk_situ_us * 1e-6) / 1e9
     traffic, traffic_source = load_traffic(args.protein)
 
-    from bench_transformer import rocprof_frac
     tag = {("potts", "PABP"): "config2", ("potts+cnn", "PABP"): "config3", ("potts", "GFP"): "gfp", ("potts", "UBE4B"): "ube4b"}.get((args.workload, args.protein))
-    rocprof = rocprof_frac(tag, "potts_energy_grad_kernel", alg_bytes, HBM_PEAK_GBS * 1e9) if tag and n == 128 else None
+    rocprof = committed_profile(tag, "potts_energy_grad_kernel", alg_bytes, HBM_PEAK_GBS * 1e9, pk_situ_us) if tag and n == 128 else None
 
     res = ch.collect()
     assert np.isfinite(res["energy_history"]).all()
@@ -362,7 +408,8 @@ def main():
         roofline_large = {"kernel": "potts_energy_grad_kernel (ring variant)", "workload": f"GFP_AEQVI window L'={Lpg}, {n} chains",
                           "bound": "hbm", "achieved": ab / (us * 1e-6) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                           "frac": ab / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, "traffic": tr, "traffic_source": trs,
-                          "algorithmic_bytes_per_launch": ab, "avg_launch_us": us, "launches_timed": 300}
+                          "algorithmic_bytes_per_launch": ab, "avg_launch_us": us, "launches_timed": 300,
+                          "timing": "300 launches back to back between one event pair"}
         del chg, mg
 
     if rank == 0:
@@ -394,9 +441,10 @@ def main():
                          "traffic_note": "FETCH_SIZE/WRITE_SIZE count L2<->fabric requests: at this size the couplings stay "
                                          "resident in the 256 MB Infinity Cache (MALL) between launches, so this is fabric "
                                          "traffic, not DRAM traffic",
-                         "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_us": pk_us, "launches_timed": 500,
-                         "avg_launch_us_event_pair_per_launch_in_situ": pk_situ_us,
-                         "rocprof": rocprof},
+                         "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_us": pk_situ_us, "launches_timed": pk_launches,
+                         "timing": "in situ: the dispatch's own start / stop timestamps of every Potts launch inside real iterations",
+                         "avg_launch_us_back_to_back": pk_us, "frac_back_to_back": alg_bytes / (pk_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                         "committed_profile": rocprof},
             ("value_reuse_grad" if not args.reuse_grad else "value_reevaluate"): world * args.steps / dt_other,
         }
         if roofline_large:
@@ -409,12 +457,26 @@ def main():
             out["cpu_baseline"] = cpu_baseline(args, wt, J, h, i0, Lp, cnn, n)
         # BASELINE configs[2] and configs[4] under the same clock: a few short median-of-3 blocks each (N = 1 default workload only)
         if world == 1 and not dist_on and args.workload == "potts" and args.protein == "PABP" and n == 128 and not args.no_also:
+            out["value_torch_rng"] = torch_rng_value(args, m, wt, i0, Lp, n, which)
+            out["value_torch_rng_overlapped_upload"] = torch_rng_value(args, m, wt, i0, Lp, n, which, overlap=True)
+            t0 = time.perf_counter()
+            from ppde_amd.noise import draw_chunk
+            draw_chunk(40, n, L * 20, args.pas)
+            out["torch_rng_host_draw_ceiling"] = 40 / (time.perf_counter() - t0)
+            out["value_torch_rng_note"] = ("steps/s of the same workload through PPDE_PAS.run with its default ppde_rng='torch' (what a drop-in user "
+                                           "runs: host-drawn U, q, u in the reference's order, replaying the reference's trajectory; gradient reuse). "
+                                           "torch_rng_host_draw_ceiling = iterations/s at which this box's host cores draw that noise alone "
+                                           "(torch's CPU exponential_, n * L*20 * max_u variates per iteration): the mode's ceiling. "
+                                           "value_torch_rng_overlapped_upload = with args.ppde_overlap_noise (next chunk drawn and uploaded while "
+                                           "the previous one runs; opt-in)")
             del m
-            also = {"config3": also_config3(args, device, rank)}
+            also = {"config3": also_poe(args, device, rank)}
             if out.get("cpu_baseline") and also["config3"].get("cpu_baseline"):
                 out["cpu_baseline"]["value_with_cnn"] = also["config3"]["cpu_baseline"]["value"]
                 out["cpu_baseline"]["sample"] += (" With the supervised CNN evaluated as the reference does (timed for also.config3, lamda = 5: "
                                                   "the same work as lamda = 0): value_with_cnn.")
+            also["config4_share"] = also_poe(args, device, rank, "GFP", 15.0, steps=60, warm=20, reps=3,
+                                             what="the per-GPU share of BASELINE configs[3] as the reference would run it")
             also["config5"] = also_config5(args, rank, local)
             out["also"] = also
         print(json.dumps(out), flush=True)

@@ -143,7 +143,8 @@ def measure(args, rank, world, local, backend, steps, warmup, repeats, with_cpu,
         out["value_reuse_grad" if not args.reuse_grad else "value_reevaluate"] = world * steps / dt_other
     stats = rocprof_frac("transformer", "tf_gemm160<3>" if use160 else "tf_gemm_nt<3,", 2.0 * M * F * D, MFMA_F16_PEAK_TF * 1e12)   # <3 ...> = the bias + GELU epilogue (fc1)
     if stats:
-        out["roofline"]["rocprof"] = stats
+        stats["consistent_with_this_run"] = bool(abs(stats["avg_launch_us"] - us.value) <= 0.10 * us.value)
+        out["roofline"]["committed_profile"] = stats
     if world > 1:
         out["backend"] = backend
     if world == 1 and with_cpu:
@@ -168,8 +169,9 @@ def measure(args, rank, world, local, backend, steps, warmup, repeats, with_cpu,
 
 def rocprof_frac(tag, kernel_substr, work_per_launch, peak=None):
     """Average duration of a kernel from the newest committed profiles/rNN_<tag>_kernel_stats.csv (rocprofv3 --kernel-trace
-    --stats of the same bench command, scripts/collect_profiles.sh), and the roofline fraction it gives: a constant read
-    from that file, printed next to the live event-pair figure so that the line reproduces from profiles/."""
+    --stats of the same bench command, scripts/collect_profiles.sh), and the roofline fraction it gives: a CONSTANT read
+    from that file (nothing ties it to the kernels at HEAD: the callers mark it `consistent_with_this_run` only when it lies
+    within 10 % of the live figure), printed next to the live one so that the line can be checked against profiles/."""
     import csv
     import glob
     files = sorted(glob.glob(os.path.join(REPO, "profiles", f"r[0-9][0-9]_{tag}_kernel_stats.csv")))
@@ -182,7 +184,7 @@ def rocprof_frac(tag, kernel_substr, work_per_launch, peak=None):
     us = float(r["AverageNs"]) / 1e3
     out = {"file": "profiles/" + os.path.basename(files[-1]), "kernel": r["Name"], "launches": int(r["Calls"]), "avg_launch_us": us}
     if work_per_launch and peak:
-        out["frac_rocprof"] = work_per_launch / (us * 1e-6) / peak
+        out["frac_from_committed_profile"] = work_per_launch / (us * 1e-6) / peak
     return out
 
 

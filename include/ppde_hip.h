@@ -206,6 +206,13 @@ int ppde_chains_run(ppde_chains* c, int steps, const int32_t* U_dev, const float
 
 /* Block until enqueued work is done; reports PPDE_ERR_NUMERIC if a proposal row degenerated. */
 int ppde_chains_sync(ppde_chains* c);
+
+/* Markers for callers that pipeline rng_mode 0 (the noise of chunk i+1 is drawn and uploaded while chunk i runs; the reference
+ * draws its noise inside the loop, ppde.py:67,109,138): ppde_chains_mark records marker `slot` (0 or 1) behind everything
+ * enqueued so far, ppde_chains_wait_mark blocks until that point has been reached (at once if the marker was never
+ * recorded) -- i.e. until the kernels that read a noise buffer are done and it may be overwritten. */
+int ppde_chains_mark(ppde_chains* c, int slot);
+int ppde_chains_wait_mark(ppde_chains* c, int slot);
 int ppde_chains_steps_done(ppde_chains* c);
 
 /* Current population (after the mutation-cap reset) and what the reference logs every log_every

@@ -60,6 +60,8 @@ SIGNATURES = {
     "ppde_chains_run": (_i, [_p, _i, _p, _p, _p, _p]),
     "ppde_chains_sync": (_i, [_p]),
     "ppde_chains_steps_done": (_i, [_p]),
+    "ppde_chains_mark": (_i, [_p, _i]),
+    "ppde_chains_wait_mark": (_i, [_p, _i]),
     "ppde_chains_peek": (_i, [_p, _p, _p, _p, _p, _p]),
     "ppde_chains_collect": (_i, [_p, _p, _p, _p, _p, _p, _p, _p]),
     "ppde_chains_trace": (_i, [_p, _p, _p, _p, _p]),

@@ -966,6 +966,8 @@ struct ppde_chains {
     // graph replay: segments of different lengths, longest first, captured once by ppde_chains_init
     struct GraphSeg { hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr; int len = 0; };
     std::vector<GraphSeg> graphs;
+    hipEvent_t marks[2] = {nullptr, nullptr};    // ppde_chains_mark / ppde_chains_wait_mark
+    bool mark_set[2] = {false, false};
     int n_captures = 0, n_captures_in_run = 0;   // graphs captured in all / inside ppde_chains_run (must stay 0)
     long long n_replayed_steps = 0, n_eager_steps = 0;
     std::vector<void*> allocs;
@@ -1250,6 +1252,7 @@ int ppde_chains_destroy(ppde_chains* c) {
     if (c->h_err) hipHostFree(c->h_err);
     for (hipStream_t st : c->streams) if (st) hipStreamDestroy(st);
     for (hipEvent_t ev : c->events) if (ev) hipEventDestroy(ev);
+    for (hipEvent_t ev : c->marks) if (ev) hipEventDestroy(ev);
     delete c;
     return PPDE_OK;
 }
@@ -1386,6 +1389,23 @@ int ppde_chains_sync(ppde_chains* c) {
 }
 
 int ppde_chains_steps_done(ppde_chains* c) { return c ? c->steps_done : PPDE_ERR_INVALID; }
+
+int ppde_chains_mark(ppde_chains* c, int slot) {
+    ARGCHK(c && (slot == 0 || slot == 1), "marker slot must be 0 or 1");
+    HIPCHK(hipSetDevice(c->device));
+    if (!c->marks[slot]) HIPCHK(hipEventCreateWithFlags(&c->marks[slot], hipEventDisableTiming));
+    HIPCHK(hipEventRecord(c->marks[slot], c->stream));
+    c->mark_set[slot] = true;
+    return PPDE_OK;
+}
+
+int ppde_chains_wait_mark(ppde_chains* c, int slot) {
+    ARGCHK(c && (slot == 0 || slot == 1), "marker slot must be 0 or 1");
+    if (!c->mark_set[slot]) return PPDE_OK;
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipEventSynchronize(c->marks[slot]));
+    return PPDE_OK;
+}
 
 int ppde_chains_peek(ppde_chains* c, uint8_t* idx, float* energy, float* fitness, uint8_t* accepted, int32_t* dist) {
     ARGCHK(c && c->initialised, "chains not initialised");

@@ -14,6 +14,11 @@ Extra, optional attributes on `args` (absent in the reference, defaults keep its
     ppde_reuse_grad     True (default): energy/gradient of the current state are carried over from the previous
                         iteration instead of being recomputed (bit-identical results).
     ppde_use_graph      True (default): replay iterations from a captured hipGraph in philox mode.
+    ppde_overlap_noise  False (default): in 'torch' mode draw, upload, run and wait chunk by chunk. True: the noise of the next
+                        chunk of iterations is drawn and uploaded from pinned memory while the previous chunk runs on the GPU
+                        (same generator, same draw order: same trajectory). Measured slower at 128 chains (profiles/
+                        r04_experiments.md): an iteration's GPU work is ~20 us against ~13 ms of torch's CPU exponential_, so
+                        there is nothing to hide and the pinned staging copy costs more than it saves.
     ppde_streams        1 (default). >1: philox mode cuts the chains into this many sub-populations whose iterations run on
                         separate HIP streams and overlap on the GPU (independent chains: results unchanged).
     ppde_cpu_alias      False (default): state histories hold the pre-reset state (reference on cuda);
@@ -87,6 +92,18 @@ class Chains:
     def sync(self):
         _hip.check(self.lib.ppde_chains_sync(self.handle))
 
+    def run_enqueue(self, steps, U_dev, q_dev, u_dev, max_u):
+        """Enqueue `steps` iterations on caller-supplied noise ALREADY on the device and return at once: the caller keeps the
+        buffers alive and untouched until a marker recorded behind this call has been reached (mark / wait_mark)."""
+        mu = np.ascontiguousarray(np.asarray(max_u, dtype=np.int32))
+        _hip.check(self.lib.ppde_chains_run(self.handle, int(steps), _hip.ptr(U_dev), _hip.ptr(q_dev), _hip.ptr(u_dev), _hip.ptr(mu)))
+
+    def mark(self, slot):
+        _hip.check(self.lib.ppde_chains_mark(self.handle, int(slot)))
+
+    def wait_mark(self, slot):
+        _hip.check(self.lib.ppde_chains_wait_mark(self.handle, int(slot)))
+
     @property
     def steps_done(self):
         return self.lib.ppde_chains_steps_done(self.handle)
@@ -152,6 +169,38 @@ class Chains:
         return v.value
 
 
+class NoisePipe:
+    """Replay mode (`ppde_rng='torch'`) without serialising host and device: the reference draws U, q, u inside its loop with
+    torch's CPU generator (ppde.py:67, :109, :138); here chunk i + 1 is drawn (same generator, same order: noise.draw_chunk)
+    and uploaded from pinned memory on a copy stream while the kernels of chunk i run. Two host and two device buffer sets;
+    a set is rewritten only after the marker behind the kernels that read it has been reached. What remains in series is
+    torch's own `exponential_` (the ceiling of this mode: ~n * L*20 * E[max_u] variates per iteration on the host cores)."""
+
+    def __init__(self, chains, k_max, n, N, mu_max):
+        dev = chains.model.device
+        self.chains, self.k_max, self.i = chains, int(k_max), 0
+        mk = lambda shape, dt: (torch.empty(shape, dtype=dt).pin_memory(), torch.empty(shape, dtype=dt, device=dev))
+        self.U = [mk((k_max, n), torch.int32) for _ in range(2)]
+        self.q = [mk((k_max * mu_max, n, N), torch.float32) for _ in range(2)]
+        self.u = [mk((k_max, n), torch.float32) for _ in range(2)]
+        self.copy_stream = torch.cuda.Stream(dev)
+
+    def push(self, k, noise):
+        """Upload the noise of k iterations (noise.draw_chunk's tuple) and enqueue them."""
+        U, q, u, mus = noise
+        slot = self.i & 1
+        self.i += 1
+        self.chains.wait_mark(slot)                      # the kernels that read this set two chunks ago are done
+        rows = int(q.shape[0])
+        (hU, dU), (hq, dq), (hu, du) = self.U[slot], self.q[slot], self.u[slot]
+        hU[:k].copy_(U); hq[:rows].copy_(q); hu[:k].copy_(u)
+        with torch.cuda.stream(self.copy_stream):
+            dU[:k].copy_(hU[:k], non_blocking=True); dq[:rows].copy_(hq[:rows], non_blocking=True); du[:k].copy_(hu[:k], non_blocking=True)
+        self.copy_stream.synchronize()                   # (the previous chunk's kernels keep running meanwhile)
+        self.chains.run_enqueue(k, dU, dq, du, mus)
+        self.chains.mark(slot)
+
+
 class PPDE_PAS(BaseSampler):
     def __init__(self, args):
         super().__init__()
@@ -171,7 +220,8 @@ class PPDE_PAS(BaseSampler):
         self.cpu_alias = getattr(args, "ppde_cpu_alias", False)
         self.shard = getattr(args, "ppde_shard", False)
         self.trace = getattr(args, "ppde_trace", False)
-        self.noise_bytes = 96 << 20         # host->device noise is uploaded in chunks of about this size
+        self.noise_bytes = getattr(args, "ppde_noise_bytes", 48 << 20)   # host->device noise is uploaded in chunks of about this size
+        self.overlap = getattr(args, "ppde_overlap_noise", False)   # True: pipeline the noise upload (NoisePipe)
         self.last_chains = None
 
     def approximate_energy_change(self, score_change):
@@ -228,6 +278,7 @@ class PPDE_PAS(BaseSampler):
         log(0, first=True)
         N = L * 20
         done = 0
+        pipe = None
         while done < num_steps:
             # next iteration index i with i > 0 and (i+1) % log_every == 0  ->  stop after i+1 steps
             stop = min(num_steps, ((done // log_every) + 1) * log_every) if log_every > 0 else num_steps
@@ -235,10 +286,17 @@ class PPDE_PAS(BaseSampler):
                 if self.rng == "torch":
                     per_it = self.ppde_pas_length * 2 * n * N * 4 + 1
                     kmax = max(1, int(self.noise_bytes // per_it))
+                    if self.overlap and pipe is None:
+                        pipe = NoisePipe(chains, kmax, n, N, 2 * self.ppde_pas_length - 1)
                     while done < stop:
                         k = min(kmax, stop - done)
-                        chains.run(k, draw_chunk(k, n_global, N, self.ppde_pas_length, rows=(lo, hi)))
+                        noise = draw_chunk(k, n_global, N, self.ppde_pas_length, rows=(lo, hi))
+                        if pipe is not None:
+                            pipe.push(k, noise)              # returns once the chunk is enqueued; the next draw overlaps it
+                        else:
+                            chains.run(k, noise)
                         done += k
+                    chains.sync()                            # once per log_every block
                 else:
                     chains.run(stop - done)
                     done = stop

@@ -91,7 +91,12 @@ int sequence(int L, int Lp, int win, bool with_tf, bool verbose, int tf_dim = 12
         std::vector<int32_t> U((size_t)steps * n, 2), mu(steps, 3);
         for (int t = 0; t < steps; ++t) U[(size_t)t * n] = 3;
         std::vector<float> q((size_t)steps * 3 * n * N, 1.0f), u((size_t)steps * n, 0.5f);
+        TRY(ppde_chains_wait_mark(c0, 1));            // never recorded: returns at once
         TRY(ppde_chains_run(c0, steps, U.data(), q.data(), u.data(), mu.data()));
+        TRY(ppde_chains_mark(c0, 0));
+        TRY(ppde_chains_mark(c0, 0));                 // (re-recording reuses the event)
+        TRY(ppde_chains_wait_mark(c0, 0));
+        if (ppde_chains_mark(c0, 2) == PPDE_OK) { fprintf(stderr, "marker slot 2 accepted\n"); status = 97; goto done; }
         TRY(ppde_chains_sync(c0));
         std::vector<int32_t> flat((size_t)steps * 3 * n), Ut((size_t)steps * n), dist(n);
         std::vector<uint8_t> acc((size_t)steps * n), pidx((size_t)n * L), pacc(n);

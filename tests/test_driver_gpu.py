@@ -57,6 +57,15 @@ def test_driver_reproduces_reference_cli_run():
         assert np.abs(ld("pred_fitness_scores.npy") - fx["pred_fitness"]).max() <= 1e-5
         assert np.abs(ld("oracle_fitness_scores.npy") - fx["oracle_fitness"]).max() <= 2e-5
         assert np.abs(ld("potts_scores.npy") - fx["potts_scores"]).max() <= 3e-5
+        # the same command with the noise upload pipelined (args.ppde_overlap_noise: next chunk drawn and uploaded while the previous
+        # one runs; chunks of two iterations here, so both buffer sets and their markers turn over many times): the same bits
+        args2 = drv.build_parser().parse_args(argv)
+        args2.ppde_reuse_grad, args2.ppde_overlap_noise, args2.ppde_noise_bytes = True, True, 2 * (2 * 2 * 16 * 1920 * 4 + 1)
+        args2.run_signature = "overlap"                                            # (its own results directory)
+        with contextlib.redirect_stdout(io.StringIO()):
+            out2 = drv.main(args2)
+        for f in ("population.npy", "energy_history.npy", "fitness_history.npy", "energy_scores.npy"):
+            assert np.array_equal(ld(f), np.load(os.path.join(out2, f))), f
     # the log lines the reference prints (ppde.py:54-57,164-166; directed_evolution.py:74)
     mine = [l for l in buf.getvalue().splitlines() if l.startswith("[Iteration") or l.startswith("WT protein")]
     ref = [str(l) for l in fx["log"]]
