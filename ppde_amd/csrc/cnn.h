@@ -791,10 +791,23 @@ __global__ __launch_bounds__(NT, 2) void k_cnn(CnnArgs a) {
 // 69 KB). With 96-row chunks a CU held one 4-wave workgroup at a time (fwd 341 us, bwd 300 us per launch at GFP).
 #define CNN_FCH_RT 4                                  // forward: 64 rows per chunk
 #define CNN_BCH_RT 3                                  // backward: 48-row windows
-__host__ __device__ inline int cnn_fwd_chunks(int T) { return (T + CNN_FCH_RT * 16 - 1) / (CNN_FCH_RT * 16); }
+__host__ __device__ inline int cnn_fwd_chunks(int T, int RT = CNN_FCH_RT) { return (T + RT * 16 - 1) / (RT * 16); }
 __host__ __device__ inline int cnn_bwd_out_per_chunk(int KT) { return CNN_BCH_RT * 16 - (KT - 1); }
 __host__ __device__ inline int cnn_bwd_chunks(int L, int KT) { return (L + cnn_bwd_out_per_chunk(KT) - 1) / cnn_bwd_out_per_chunk(KT); }
 __host__ __device__ inline size_t cnn_fwd_chunk_lds(int CP) { return (size_t)CNN_FCH_RT * 16 * (cnn_astride(CP) + (CP + 31) / 32) * 4 + 256; }
+// split-precision forms (bf_strips): the chunk's rows as three-plane bf16 images. Forward: 64-row chunks while two workgroups fit
+// a CU (up to 128 padded channels: 48 KB), 48-row chunks beyond (GFP, 256 channels: 72 KB). Backward: the routed gradient's planes,
+// O takes their storage once every wave has read them (as cnn_body_bf).
+__host__ __device__ inline int cnn_bf_fwd_rt(int CP) { return CP <= 128 ? 4 : 3; }
+__host__ __device__ inline size_t cnn_bf_fwd_chunk_lds(int CP) {
+    const size_t RT = cnn_bf_fwd_rt(CP);
+    return RT * 3 * (CP / 32) * 1024 + RT * 16 * ((CP + 31) / 32) * 4 + 256;
+}
+__host__ __device__ inline size_t cnn_bf_bwd_chunk_lds(int CP, int FP, int J) {
+    const size_t rows = CNN_BCH_RT * 16;
+    const size_t planes = (size_t)CNN_BCH_RT * 3 * (CP / 32) * 1024, so = rows * J * 4;
+    return (planes > so ? planes : so) + rows * ((CP + 31) / 32) * 4 + (size_t)FP * 12 + 512;
+}
 __host__ __device__ inline size_t cnn_bwd_chunk_lds(int CP, int FP, int J) {
     const size_t rows = CNN_BCH_RT * 16;
     return rows * cnn_astride(CP) * 4 + rows * J * 4 + rows * ((CP + 31) / 32) * 4 + (size_t)FP * 12 + 512;   // (+ offsets, sums)
@@ -806,10 +819,11 @@ struct CnnChunkArgs {
     int* carg;          // [nets][n][NCH][FP] their rows
     uint32_t* cgate;    // [nets][n][NCH * rows][BW] ReLU gate bits of h1 (bit o of word o/32: h1[t][o] > 0)
     int NCH;
+    int frows;          // rows per forward chunk (the gate rows of a chain are contiguous over its chunks)
 };
 
 // h1 rows [t0, t0 + rows) of one chain into LDS and / or their ReLU gate bits
-template <int KT, bool WANT_H, bool WANT_BITS>
+template <int KT, bool WANT_H, bool WANT_BITS, bool BF = false>
 __device__ __forceinline__ void cnn_build_rows(const CnnNet& net, const uint8_t* sSt, int t0, int rows, int T, int CP, int AS,
                                                float* sH, uint32_t* sG, int BW) {
     const int tid = threadIdx.x;
@@ -839,7 +853,8 @@ __device__ __forceinline__ void cnn_build_rows(const CnnNet& net, const uint8_t*
                 const bool live = t >= 0 && t < T;
                 x.x = live ? fmaxf(x.x, 0.f) : 0.f; x.y = live ? fmaxf(x.y, 0.f) : 0.f;
                 x.z = live ? fmaxf(x.z, 0.f) : 0.f; x.w = live ? fmaxf(x.w, 0.f) : 0.f;
-                if constexpr (WANT_H) {
+                if constexpr (WANT_H && BF) bf_store4((unsigned char*)sH, rows / 16, r, g4, x);   // split planes (AS unused)
+                else if constexpr (WANT_H) {
                     float* hp = sH + r * AS + 4 * g4;
                     *(float2*)hp = make_float2(x.x, x.y);
                     *(float2*)(hp + 2) = make_float2(x.z, x.w);
@@ -860,21 +875,23 @@ template <int SHAPE> struct CnnChunkShape {
     static constexpr int T = SHAPE == 1 ? 100 : 233, CP = SHAPE == 1 ? 128 : 256, F = SHAPE == 1 ? 208 : 474, FP = SHAPE == 1 ? 208 : 480;
     static constexpr int J = 100, JP = 112;
 };
-template <int KT, int SHAPE = 0>      // (SHAPE != 0 is NOT used by the host for this kernel: measured slower, see launch_cnn)
+// BF: h1 as split bf16 planes and the contraction on the bf16 matrix pipe (bf_strips); RTV = row tiles per chunk
+template <int KT, int SHAPE = 0, int RTV = CNN_FCH_RT, bool BF = false>      // (SHAPE != 0 is NOT used by the host for this kernel: measured slower, see launch_cnn)
 __global__ __launch_bounds__(256, 2) void k_cnn_fwd_chunk(CnnChunkArgs ca) {
     warm_kernargs<sizeof(CnnChunkArgs)>();
     extern __shared__ unsigned char smem_raw[];
     const CnnArgs& a = ca.a;
     const Geom g = a.g;
-    constexpr int RT = CNN_FCH_RT, rows = RT * 16;
+    constexpr int RT = RTV, rows = RT * 16;
     const int b = a.b_off + blockIdx.x, ni = blockIdx.y, c = blockIdx.z, tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const CnnNet net = a.net[ni];
     const int T = SHAPE ? CnnChunkShape<SHAPE>::T : a.T, CP = SHAPE ? CnnChunkShape<SHAPE>::CP : a.CP, FP = SHAPE ? CnnChunkShape<SHAPE>::FP : a.FP;
     const int AS = cnn_astride(CP), KSP = CP / 4;
     const int BW = (CP + 31) / 32;
-    float* sH = (float*)smem_raw;
-    uint32_t* sG = (uint32_t*)(sH + (size_t)rows * AS);              // [rows][BW] gate bits of this chunk's rows
+    float* sH = (float*)smem_raw;                                    // h1 [rows][AS] fp32, or its three bf16 planes (BF)
+    uint32_t* sG = BF ? (uint32_t*)(smem_raw + (size_t)RT * 3 * (CP / 32) * 1024)
+                      : (uint32_t*)(sH + (size_t)rows * AS);         // [rows][BW] gate bits of this chunk's rows
     uint8_t* sSt = (uint8_t*)(sG + (size_t)rows * BW);               // letters t0 .. t0 + rows + KT (relative index)
     const int t0 = c * rows;
     [[maybe_unused]] const bool stamp = blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 1;
@@ -884,22 +901,19 @@ __global__ __launch_bounds__(256, 2) void k_cnn_fwd_chunk(CnnChunkArgs ca) {
         const int res = t0 + l;
         sSt[l] = res < g.L ? min((int)a.idx[(size_t)b * g.Ls + g.sh + res], 19) : 0;
     }
-    for (int e = tid; e < rows * 2; e += 256) sH[(e >> 1) * AS + CP + (e & 1)] = 0.f;
+    if constexpr (!BF)
+        for (int e = tid; e < rows * 2; e += 256) sH[(e >> 1) * AS + CP + (e & 1)] = 0.f;
     __syncthreads();
     // sSt is relative to t0 here: shift the pointer so that cnn_build_rows can index by absolute residue
     PPDE_STAMP(a.dbg, 51, stamp);
-    cnn_build_rows<KT, true, true>(net, sSt - t0, t0, rows, T, CP, AS, sH, sG, BW);
+    cnn_build_rows<KT, true, true, BF>(net, sSt - t0, t0, rows, T, CP, AS, sH, sG, BW);
     __syncthreads();
     PPDE_STAMP(a.dbg, 52, stamp);
     if (a.want_grad) {                                               // the backward windows read the gate instead of recomputing it
         uint32_t* gout = ca.cgate + ((((size_t)ni * a.n + b) * ca.NCH) + c) * rows * BW;
         for (int w = tid; w < rows * BW; w += 256) gout[w] = sG[w];
     }
-    for (int ct = wave; ct < FP / 16; ct += 4) {
-        f32x4 acc[RT];
-#pragma unroll
-        for (int rt = 0; rt < RT; ++rt) acc[rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        mfma_strip<RT>(acc, sH, AS, net.WeT, FP, ct * 16, KSP);
+    auto strip_max = [&](int ct, const f32x4 (&acc)[RT]) {
         const int f = ct * 16 + (lane & 15);
         const float bias = net.be[f];
         float m = -INFINITY;
@@ -924,11 +938,22 @@ __global__ __launch_bounds__(256, 2) void k_cnn_fwd_chunk(CnnChunkArgs ca) {
             ca.cmax[at] = m;
             ca.carg[at] = ts;
         }
+    };
+    if constexpr (BF) {
+        bf_strips<RT>(smem_raw, net.WeB, CP / 32, wave, 4, FP / 16, [&](int, int ct, const f32x4 (&acc)[RT]) { strip_max(ct, acc); });
+    } else {
+        for (int ct = wave; ct < FP / 16; ct += 4) {
+            f32x4 acc[RT];
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) acc[rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            mfma_strip<RT>(acc, sH, AS, net.WeT, FP, ct * 16, KSP);
+            strip_max(ct, acc);
+        }
     }
     PPDE_STAMP(a.dbg, 53, stamp);
 }
 
-template <int KT, int SHAPE = 0>
+template <int KT, int SHAPE = 0, bool BF = false>
 __global__ __launch_bounds__(256, 2) void k_cnn_bwd_chunk(CnnChunkArgs ca) {
     warm_kernargs<sizeof(CnnChunkArgs)>();
     extern __shared__ unsigned char smem_raw[];
@@ -942,9 +967,10 @@ __global__ __launch_bounds__(256, 2) void k_cnn_bwd_chunk(CnnChunkArgs ca) {
     const int T = SHAPE ? SH::T : a.T, CP = SHAPE ? SH::CP : a.CP, F = SHAPE ? SH::F : a.F, FP = SHAPE ? SH::FP : a.FP;
     const int J = SHAPE ? SH::J : a.J, JP = SHAPE ? SH::JP : a.JP, AS = cnn_astride(CP), KSP = CP / 4;
     const int OS = J, BW = (CP + 31) / 32;
-    float* sD = (float*)smem_raw;                                     // [rows][AS] routed gradient
-    float* sO = sD + (size_t)rows * AS;                               // [rows][J]
-    uint32_t* sG = (uint32_t*)(sO + (size_t)rows * OS);               // [rows][BW]
+    float* sD = (float*)smem_raw;                                     // [rows][AS] routed gradient (BF: its three bf16 planes)
+    const size_t bf_planes = (size_t)RT * 3 * (CP / 32) * 1024, bf_o = (size_t)rows * OS * 4, bf_region = bf_planes > bf_o ? bf_planes : bf_o;
+    float* sO = BF ? sD : sD + (size_t)rows * AS;                     // [rows][J] (BF: in the planes' storage, once they are dead)
+    uint32_t* sG = BF ? (uint32_t*)(smem_raw + bf_region) : (uint32_t*)(sO + (size_t)rows * OS);               // [rows][BW]
     float* sM = (float*)(sG + (size_t)rows * BW);                     // [FP] coefficients
     int* sTs = (int*)(sM + FP);                                       // [FP] arg-max rows
     int* sList = sTs + FP;                                            // [FP] features routed into this window, in order
@@ -981,7 +1007,7 @@ __global__ __launch_bounds__(256, 2) void k_cnn_bwd_chunk(CnnChunkArgs ca) {
     PPDE_STAMP(a.dbg, 41, stamp);
     // ---- ReLU gate bits of the window's rows, as the forward chunks left them (rows outside [0, T): zero)
     {
-        const uint32_t* gin = ca.cgate + ((size_t)ni * a.n + b) * ca.NCH * (CNN_FCH_RT * 16) * BW;
+        const uint32_t* gin = ca.cgate + ((size_t)ni * a.n + b) * ca.NCH * ca.frows * BW;
         for (int w = tid; w < rows * BW; w += 256) {
             const int t = r0 + w / BW;
             sG[w] = (t >= 0 && t < T) ? gin[(size_t)t * BW + (w % BW)] : 0u;
@@ -990,9 +1016,39 @@ __global__ __launch_bounds__(256, 2) void k_cnn_bwd_chunk(CnnChunkArgs ca) {
     __syncthreads();
     PPDE_STAMP(a.dbg, 42, stamp);
     // ---- route the features whose arg-max row lies in the window, gate (cnn_route_rows)
-    cnn_route_rows<256>(net, rows, r0, CP, AS, FP, BW, sD, (uint32_t*)sD, sG, sM, sTs, sStart, sList, sCnt);
+    cnn_route_rows<256, BF>(net, rows, r0, CP, AS, FP, BW, sD, (uint32_t*)sD, sG, sM, sTs, sStart, sList, sCnt);
     PPDE_STAMP(a.dbg, 43, stamp);
     // ---- O = dpre1 x Wf on the matrix cores
+    if constexpr (BF) {
+        constexpr int JPc = (KT * 20 + 15) & ~15, NKEEP = (JPc / 16 + 3) / 4;       // strips per wave (J = KT * 20)
+        static_assert(NKEEP <= 3, "at most three backward strips per wave");
+        // one bf_strips call per strip slot of the wave, each into its own accumulator array (a run-time choice between the
+        // arrays inside the epilogue sent them to scratch memory)
+        f32x4 keep0[RT], keep1[RT], keep2[RT];
+        auto grab = [&](f32x4 (&kp)[RT], int ct) {
+            bf_strips<RT>(smem_raw, net.WfB, CP / 32, ct, 1 << 20, JPc / 16, [&](int, int, const f32x4 (&acc)[RT]) {
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) kp[rt] = acc[rt];
+            });
+        };
+        grab(keep0, wave);
+        if constexpr (NKEEP > 1) grab(keep1, wave + 4);
+        if constexpr (NKEEP > 2) grab(keep2, wave + 8);
+        __syncthreads();                                              // every wave is done reading the planes: O takes their storage
+        auto put = [&](const f32x4 (&kp)[RT], int ct) {
+            const int j = ct * 16 + (lane & 15);
+            if (ct < JPc / 16 && j < J) {
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) sO[(rt * 16 + (lane >> 4) * 4 + q) * OS + j] = kp[rt][q];
+                }
+            }
+        };
+        put(keep0, wave);
+        if constexpr (NKEEP > 1) put(keep1, wave + 4);
+        if constexpr (NKEEP > 2) put(keep2, wave + 8);
+    } else
     for (int ct = wave; ct < JP / 16; ct += 4) {
         f32x4 acc[RT];
 #pragma unroll

@@ -286,9 +286,11 @@ static int cnn_parts(const ppde_model* m) {
     return (split && cnn_single_launch(m) && m->n_nets <= 3 && m->FP >= 32) ? m->n_nets + 1 : m->n_nets;
 }
 
-static size_t cnn_chunk_max_count(const ppde_model* m, int n) { return (size_t)m->n_nets * n * cnn_fwd_chunks(m->T) * m->FP; }
+// row tiles of a forward chunk of the long-sequence CNN path (cnn.h: 4, or 3 for the split-precision kernels beyond 128 channels)
+static int cnn_fwd_rt(const ppde_model* m) { return cnn_bf16() ? cnn_bf_fwd_rt(m->CP) : CNN_FCH_RT; }
+static size_t cnn_chunk_max_count(const ppde_model* m, int n) { return (size_t)m->n_nets * n * cnn_fwd_chunks(m->T, cnn_fwd_rt(m)) * m->FP; }
 static size_t cnn_chunk_gate_count(const ppde_model* m, int n) {
-    return (size_t)m->n_nets * n * cnn_fwd_chunks(m->T) * CNN_FCH_RT * 16 * ((m->CP + 31) / 32);
+    return (size_t)m->n_nets * n * cnn_fwd_chunks(m->T, cnn_fwd_rt(m)) * cnn_fwd_rt(m) * 16 * ((m->CP + 31) / 32);
 }
 // chunk scratch of the STATELESS API only (ppde_energy_grad); every ppde_chains owns its own (ppde_chains_create)
 static int ensure_cnn_scratch(ppde_model* m, int n) {
@@ -315,9 +317,12 @@ static int launch_cnn(const ppde_model* m, const States& st, int n, const EvalTa
     if (!cnn_single_launch(m)) {
         // long sequences: forward chunks, then merge + backward chunks
         ARGCHK(t.cmax && t.carg && t.cgate && t.cnn_cap >= n, "CNN chunk scratch not allocated for this batch size");
-        ARGCHK(cnn_fwd_chunk_lds(m->CP) <= 160 * 1024 && cnn_bwd_chunk_lds(m->CP, m->FP, m->J) <= 160 * 1024,
-               "sequence too long for the chunked CNN kernels");
-        CnnChunkArgs ca{a, t.cmax, t.carg, t.cgate, cnn_fwd_chunks(m->T)};
+        const bool bf = cnn_bf16();
+        const int frt = cnn_fwd_rt(m);
+        const size_t lds_f = bf ? cnn_bf_fwd_chunk_lds(m->CP) : cnn_fwd_chunk_lds(m->CP);
+        const size_t lds_b = bf ? cnn_bf_bwd_chunk_lds(m->CP, m->FP, m->J) : cnn_bwd_chunk_lds(m->CP, m->FP, m->J);
+        ARGCHK(lds_f <= 160 * 1024 && lds_b <= 160 * 1024, "sequence too long for the chunked CNN kernels");
+        CnnChunkArgs ca{a, t.cmax, t.carg, t.cgate, cnn_fwd_chunks(m->T, frt), frt * 16};
         const dim3 gf(n_sub, m->n_nets, ca.NCH), gb(n_sub, m->n_nets, want_grad ? cnn_bwd_chunks(m->L, m->KT) : 1);
         // the two long real proteins have instantiations with their network shape pinned (cnn.h CnnChunkShape)
         static const bool shape_spec = []() { const char* e = getenv("PPDE_CNN_SPEC"); return !e || atoi(e) != 0; }();   // tuning knob
@@ -325,20 +330,33 @@ static int launch_cnn(const ppde_model* m, const States& st, int n, const EvalTa
         const int shape = !shape_spec || !five ? 0
                           : (m->T == 100 && m->CP == 128 && m->F == 208 && m->FP == 208) ? 1
                           : (m->T == 233 && m->CP == 256 && m->F == 474 && m->FP == 480) ? 2 : 0;
+        if (bf) {
+            // split-precision chunks (bf16 matrix pipe): forward chunks of 64 rows (<= 128 channels) or 48 rows
+            if (m->KT == 5 && frt == 4) hipLaunchKernelGGL((k_cnn_fwd_chunk<5, 0, 4, true>), gf, dim3(256), lds_f, s, ca);
+            else if (m->KT == 5) hipLaunchKernelGGL((k_cnn_fwd_chunk<5, 0, 3, true>), gf, dim3(256), lds_f, s, ca);
+            else if (frt == 4) hipLaunchKernelGGL((k_cnn_fwd_chunk<CNN_MAX_K, 0, 4, true>), gf, dim3(256), lds_f, s, ca);
+            else hipLaunchKernelGGL((k_cnn_fwd_chunk<CNN_MAX_K, 0, 3, true>), gf, dim3(256), lds_f, s, ca);
+            if (shape == 1) hipLaunchKernelGGL((k_cnn_bwd_chunk<5, 1, true>), gb, dim3(256), lds_b, s, ca);
+            else if (shape == 2) hipLaunchKernelGGL((k_cnn_bwd_chunk<5, 2, true>), gb, dim3(256), lds_b, s, ca);
+            else if (m->KT == 5) hipLaunchKernelGGL((k_cnn_bwd_chunk<5, 0, true>), gb, dim3(256), lds_b, s, ca);
+            else hipLaunchKernelGGL((k_cnn_bwd_chunk<CNN_MAX_K, 0, true>), gb, dim3(256), lds_b, s, ca);
+            HIPCHK(hipGetLastError());
+            return PPDE_OK;
+        }
         // (only the BACKWARD chunks: with the trip counts known the forward chunk kernel is
         //  measured slower -- UBE4B 32.1 -> 47.3 us, GFP 244 -> 674 us per launch; the backward gains: 33.9 -> 30.1 and 125.8 -> 116.3)
         if (shape == 1) {
-            hipLaunchKernelGGL(k_cnn_fwd_chunk<5>, gf, dim3(256), cnn_fwd_chunk_lds(m->CP), s, ca);
-            hipLaunchKernelGGL((k_cnn_bwd_chunk<5, 1>), gb, dim3(256), cnn_bwd_chunk_lds(m->CP, m->FP, m->J), s, ca);
+            hipLaunchKernelGGL(k_cnn_fwd_chunk<5>, gf, dim3(256), lds_f, s, ca);
+            hipLaunchKernelGGL((k_cnn_bwd_chunk<5, 1>), gb, dim3(256), lds_b, s, ca);
         } else if (shape == 2) {
-            hipLaunchKernelGGL(k_cnn_fwd_chunk<5>, gf, dim3(256), cnn_fwd_chunk_lds(m->CP), s, ca);
-            hipLaunchKernelGGL((k_cnn_bwd_chunk<5, 2>), gb, dim3(256), cnn_bwd_chunk_lds(m->CP, m->FP, m->J), s, ca);
+            hipLaunchKernelGGL(k_cnn_fwd_chunk<5>, gf, dim3(256), lds_f, s, ca);
+            hipLaunchKernelGGL((k_cnn_bwd_chunk<5, 2>), gb, dim3(256), lds_b, s, ca);
         } else if (m->KT == 5) {
-            hipLaunchKernelGGL(k_cnn_fwd_chunk<5>, gf, dim3(256), cnn_fwd_chunk_lds(m->CP), s, ca);
-            hipLaunchKernelGGL(k_cnn_bwd_chunk<5>, gb, dim3(256), cnn_bwd_chunk_lds(m->CP, m->FP, m->J), s, ca);
+            hipLaunchKernelGGL(k_cnn_fwd_chunk<5>, gf, dim3(256), lds_f, s, ca);
+            hipLaunchKernelGGL(k_cnn_bwd_chunk<5>, gb, dim3(256), lds_b, s, ca);
         } else {
-            hipLaunchKernelGGL((k_cnn_fwd_chunk<CNN_MAX_K>), gf, dim3(256), cnn_fwd_chunk_lds(m->CP), s, ca);
-            hipLaunchKernelGGL((k_cnn_bwd_chunk<CNN_MAX_K>), gb, dim3(256), cnn_bwd_chunk_lds(m->CP, m->FP, m->J), s, ca);
+            hipLaunchKernelGGL((k_cnn_fwd_chunk<CNN_MAX_K>), gf, dim3(256), lds_f, s, ca);
+            hipLaunchKernelGGL((k_cnn_bwd_chunk<CNN_MAX_K>), gb, dim3(256), lds_b, s, ca);
         }
         HIPCHK(hipGetLastError());
         return PPDE_OK;

@@ -10,23 +10,7 @@ from ppde_amd.energy import HipModel
 from ppde_amd.encoding import idx_to_onehot
 
 
-def smallest_argmax_gap(cnn, rows):
-    """fp64 evaluation of the networks on these chains: smallest relative gap between the two largest values over t of
-    any positive feature (0 = exact tie). Below ~5e-6 two fp32 implementations may route that feature differently."""
-    x = torch.from_numpy(idx_to_onehot(rows)).double().permute(0, 2, 1)
-    best = 1.0
-    for sd in cnn:
-        W = {k: torch.as_tensor(v).double() for k, v in sd.items()}
-        pre1 = torch.nn.functional.conv1d(x, W["encoder.weight"], W["encoder.bias"])
-        best = min(best, float(pre1.abs().min()) * 10.0)     # a pre-activation at the ReLU kink (|pre1| < ~5e-7): its gate bit is implementation-defined too
-        h1 = torch.relu(pre1)
-        p2 = torch.relu(h1.permute(0, 2, 1) @ W["embedding.0.weight"].T + W["embedding.0.bias"])
-        top2 = p2.topk(2, dim=1).values
-        gap = (top2[:, 0] - top2[:, 1]) / top2[:, 0].clamp_min(1e-30)
-        pos = top2[:, 0] > 0
-        if pos.any():
-            best = min(best, float(gap[pos].min()))
-    return best
+from helpers import smallest_argmax_gap
 
 
 rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 0)

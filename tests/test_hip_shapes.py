@@ -7,7 +7,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 import ppde_oracle as orc
-from helpers import oracle_energy
+from helpers import smallest_argmax_gap, oracle_energy
 from ppde_amd import synthetic
 from ppde_amd.encoding import seqs_to_idx
 
@@ -49,7 +49,12 @@ def test_energy_grad_shapes(L, Lp, i0, with_cnn):
     scale = abs(float(en.potts.wt_H)) + 1.0
     assert np.abs(e.cpu().numpy() - eo.numpy()).max() <= 2e-6 * 8 * (scale + np.abs(eo.numpy()).max()) + 1e-5 * lam
     assert np.abs(f.cpu().numpy() - fo.numpy()).max() <= 5e-6
-    assert np.abs(g.cpu().numpy() - go.numpy()).max() <= 2e-5 * max(1.0, lam)
+    # the max over t picks a row: where two rows tie to within matmul rounding the routed gradient is implementation-defined
+    # (numerics contract); a chain may differ only if the fp64 evaluation shows such a tie in it (the 300-residue
+    # case holds one: network 1, feature 413, rows 200 / 168, relative gap 4.5e-7)
+    dg = np.abs(g.cpu().numpy() - go.numpy()).reshape(idx.shape[0], -1).max(1)
+    for b in np.nonzero(dg > 2e-5 * max(1.0, lam))[0]:
+        assert with_cnn and smallest_argmax_gap(cnn, idx[b:b + 1]) < 5e-6, (b, dg[b])
 
 
 @pytest.mark.parametrize("L,K", [(50, 3), (150, 3), (278, 3), (120, 7)])
