@@ -473,6 +473,94 @@ __device__ __forceinline__ void reverse_rows(const RowLds& lds, RowRegs<GPT>& R,
     }
 }
 
+// Device-RNG form of reverse_rows (rng_mode 1; replay mode keeps the form above, whose bits the reference's fixtures pin):
+//  * a fixed softmax reference for all rows of the path, as in propose_body_dev: half the largest spread of a residue's 20
+//    gradient entries bounds every reverse logit (no masks on the way back), so no maximum is reduced per row;
+//  * the rows of a path differ only at the residues the path moves: a wave none of whose lanes holds such a residue
+//    evaluates its exponentials ONCE and uses them for every row (the clamp and the row sums still run per row: the
+//    normalisation differs).
+template <int GPT, int NR>
+__device__ __forceinline__ void reverse_rows_dev(const RowLds& lds, RowRegs<GPT>& R, int s0, const float mref, const float e0ref,
+                                                 float& log_ratio) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* G = (const float*)lds.G;
+    const float* lpf = (const float*)(lds.mv + 128);
+    int ls[NR], ks[NR];
+    bool mine = false;
+#pragma unroll
+    for (int j = 0; j < NR; ++j) {
+        const int win = lds.mv[s0 + j];
+        ls[j] = win / 20; ks[j] = win - 20 * ls[j];
+#pragma unroll
+        for (int r = 0; r < GPT; ++r) mine |= R.valid[r] & (R.l[r] == ls[j]);
+    }
+    const bool split = __any(mine);
+    float4 e[NR][GPT];
+    float sw[NR];
+    auto row_exp = [&](int j) {
+        float sm = 0.f;
+#pragma unroll
+        for (int r = 0; r < GPT; ++r) {
+            e[j][r] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (!R.valid[r]) continue;
+            const float gc = G[R.l[r] * 20 + R.cur[r]];
+            const float4 gv = R.gv[r];
+            e[j][r].x = expf((gv.x - gc) * 0.5f - mref); e[j][r].y = expf((gv.y - gc) * 0.5f - mref);
+            e[j][r].z = expf((gv.z - gc) * 0.5f - mref); e[j][r].w = expf((gv.w - gc) * 0.5f - mref);
+            sm += e[j][r].x; sm += e[j][r].y; sm += e[j][r].z; sm += e[j][r].w;
+        }
+        sw[j] = wave_sum(sm);
+    };
+    if (split) {
+#pragma unroll
+        for (int j = 0; j < NR; ++j) {
+#pragma unroll
+            for (int r = 0; r < GPT; ++r)
+                if (R.l[r] == ls[j]) R.cur[r] = ks[j];          // state after sub-step s0 + j
+            row_exp(j);
+        }
+    } else {                                                     // (no lane's residue moves: one evaluation for all rows)
+        row_exp(0);
+#pragma unroll
+        for (int j = 1; j < NR; ++j) {
+            sw[j] = sw[0];
+#pragma unroll
+            for (int r = 0; r < GPT; ++r) e[j][r] = e[0][r];
+        }
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (int j = 0; j < NR; ++j) lds.xa[wave * PAS_SB + j] = sw[j];
+    }
+    __syncthreads();
+    float inv[NR], s3w[NR];
+#pragma unroll
+    for (int j = 0; j < NR; ++j) {
+        const float S1 = row8_sum(lane < PPDE_NW ? lds.xa[(lane & (PPDE_NW - 1)) * PAS_SB + j] : 0.f);
+        inv[j] = 1.0f / S1;
+        float s3 = 0.f;
+#pragma unroll
+        for (int r = 0; r < GPT; ++r) {
+            if (!R.valid[r]) continue;
+            s3 += clampp(e[j][r].x * inv[j]); s3 += clampp(e[j][r].y * inv[j]);
+            s3 += clampp(e[j][r].z * inv[j]); s3 += clampp(e[j][r].w * inv[j]);
+        }
+        s3w[j] = wave_sum(s3);
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (int j = 0; j < NR; ++j) lds.xb[8 * wave + j] = s3w[j];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < NR; ++j) {
+        // the recorded move under the reverse proposal: its residue now holds letter ks, so the logit is exactly 0
+        const float pwin = clampp(e0ref * inv[j]);
+        const float S3 = row8_sum(lane < PPDE_NW ? lds.xb[8 * (lane & (PPDE_NW - 1)) + j] : 0.f);
+        log_ratio += logf(clampp(pwin / S3)) - lpf[s0 + j];
+    }
+}
+
 // logits of one 4-letter group of residue l: (g - g[current letter]) / 2 with the forward masks
 __device__ __forceinline__ float4 forward_logits(const PasArgs& a, const float* G, float4 gv, int l, int kb, int cur, int wt,
                                                  bool capped) {
@@ -1018,7 +1106,7 @@ __device__ __forceinline__ void accept_stage_path(const PasArgs& a, const RowLds
 
 // Reverse path, accept/reject, records (ppde.py:122-153). Expects lds.G = gradient at the proposal, lds.St = x,
 // R.cur = x's letters, lds.mv / lpf filled by accept_prefetch. On return R.cur holds the proposal's letters.
-template <int GPT>
+template <int GPT, bool DEV = false>
 __device__ __forceinline__ AcceptOut accept_body(const PasArgs& a, const RowLds& lds, RowRegs<GPT>& R, int b, int it,
                                                  const AcceptPrefetch& pf, bool stamp) {
     const Geom g = a.g;
@@ -1035,6 +1123,29 @@ __device__ __forceinline__ AcceptOut accept_body(const PasArgs& a, const RowLds&
     float log_ratio = 0.f;
     // The reverse rows of a path are independent of each other (gradient at y, states along the recorded path), so
     // up to PAS_SB of them are evaluated per pass: two barriers per pass instead of two per sub-step.
+    if constexpr (DEV) {
+        // fixed softmax reference of the whole reverse path (see reverse_rows_dev): every wave derives it from the staged row
+        float d = 0.f;
+        for (int l = tid & 63; l < g.L; l += 64) {
+            const float4* gp = lds.G + 5 * l;
+            const float4 g0 = lds_load4(gp), g1 = lds_load4(gp + 1), g2 = lds_load4(gp + 2), g3 = lds_load4(gp + 3), g4 = lds_load4(gp + 4);
+            const float mx = fmaxf(fmaxf(fmaxf(fmaxf(g0.x, g0.y), fmaxf(g0.z, g0.w)), fmaxf(fmaxf(g1.x, g1.y), fmaxf(g1.z, g1.w))),
+                                   fmaxf(fmaxf(fmaxf(fmaxf(g2.x, g2.y), fmaxf(g2.z, g2.w)), fmaxf(fmaxf(g3.x, g3.y), fmaxf(g3.z, g3.w))),
+                                         fmaxf(fmaxf(g4.x, g4.y), fmaxf(g4.z, g4.w))));
+            const float mn = fminf(fminf(fminf(fminf(g0.x, g0.y), fminf(g0.z, g0.w)), fminf(fminf(g1.x, g1.y), fminf(g1.z, g1.w))),
+                                   fminf(fminf(fminf(fminf(g2.x, g2.y), fminf(g2.z, g2.w)), fminf(fminf(g3.x, g3.y), fminf(g3.z, g3.w))),
+                                         fminf(fminf(g4.x, g4.y), fminf(g4.z, g4.w))));
+            d = fmaxf(d, (mx - mn) * 0.5f);
+        }
+        const float mref = fminf(wave_max(d), 64.f);
+        const float e0ref = expf(0.f - mref);
+        for (int s0 = 0; s0 < Ub; s0 += PAS_SB) {
+            const int nrows = Ub - s0;
+            if (nrows >= 3) reverse_rows_dev<GPT, 3>(lds, R, s0, mref, e0ref, log_ratio);
+            else if (nrows == 2) reverse_rows_dev<GPT, 2>(lds, R, s0, mref, e0ref, log_ratio);
+            else reverse_rows_dev<GPT, 1>(lds, R, s0, mref, e0ref, log_ratio);
+        }
+    } else
     for (int s0 = 0; s0 < Ub; s0 += PAS_SB) {
         const int nrows = Ub - s0;
         if (nrows >= 3) reverse_rows<GPT, 3>(lds, R, s0, log_ratio);
@@ -1124,7 +1235,8 @@ __device__ __forceinline__ void commit_current_row(const PasArgs& a, const RowLd
     }
 }
 
-template <int GPT, int SPEC = 0>
+// DEV: the device-RNG arithmetic of the reverse path (reverse_rows_dev); the specialised instantiations imply it
+template <int GPT, int SPEC = 0, bool DEV = (SPEC != 0)>
 __global__ __launch_bounds__(PPDE_BLOCK) void k_accept(PasArgs a) {
     args_up_front(a);
     pin_config<SPEC>(a);
@@ -1143,7 +1255,7 @@ __global__ __launch_bounds__(PPDE_BLOCK) void k_accept(PasArgs a) {
     PPDE_STAMP(a.dbg, 32, stamp);
     row_commit<GPT>(lds, a.g, rl, R);
     PPDE_STAMP(a.dbg, 33, stamp);
-    const AcceptOut o = accept_body<GPT>(a, lds, R, b, it, pf, stamp);
+    const AcceptOut o = accept_body<GPT, DEV>(a, lds, R, b, it, pf, stamp);
     if (a.reuse) commit_current_row<GPT>(a, lds, R, b, o, false);
 }
 
@@ -1168,7 +1280,7 @@ __global__ __launch_bounds__(PPDE_BLOCK) void k_accept_propose(PasArgs a) {
     const ProposePrefetch<GPT> pp = propose_prefetch<GPT, false>(a, lds, b, it + 1);
     accept_stage_path(a, lds, pf);
     row_commit<GPT>(lds, g, rl, R);
-    const AcceptOut o = accept_body<GPT>(a, lds, R, b, it, pf, stamp);
+    const AcceptOut o = accept_body<GPT, true>(a, lds, R, b, it, pf, stamp);
     // ---- the state and gradient the chain continues from
     const uint8_t* rej = a.paper ? a.fb_state + (size_t)b * a.fb_state_stride : nullptr;
     __syncthreads();                                 // everyone is done reading lds.G / lds.St of the accept phase

@@ -1069,7 +1069,8 @@ static int launch_chain_kernel(ppde_chains* c, ChainKernel which, const PasArgs&
                 if constexpr (!policy) hipLaunchKernelGGL((k_accept_propose<GP, SP>), dim3(n_sub), dim3(PPDE_BLOCK), lds, s, a);
             } else if constexpr (policy || SP == 0) {
                 if (which == KP_PROPOSE) hipLaunchKernelGGL((k_propose<GP, false, SP>), dim3(n_sub), dim3(PPDE_BLOCK), lds, s, a);
-                else hipLaunchKernelGGL((k_accept<GP, SP>), dim3(n_sub), dim3(PPDE_BLOCK), lds, s, a);
+                else if (SP != 0 || a.rng_mode == 1) hipLaunchKernelGGL((k_accept<GP, SP, true>), dim3(n_sub), dim3(PPDE_BLOCK), lds, s, a);
+                else hipLaunchKernelGGL((k_accept<GP, 0, false>), dim3(n_sub), dim3(PPDE_BLOCK), lds, s, a);   // replay: the reference's bits
             }
         });
     });

@@ -288,7 +288,7 @@ def test_tfpoe_ube4b_150m_shapes_vs_combined_oracle():
     raw = np.abs(eo_.numpy() - lam * fo.numpy()) + abs(en.tf.wt_score)
     assert observed("tfpoe_ube4b_150m:e", np.abs(e.cpu().numpy() - eo_.numpy()), 2 * 2e-3 * (1 + raw) + 5e-6 * lam) <= 1.0
     assert observed("tfpoe_ube4b_150m:grad", np.abs(g.cpu().numpy() - go.numpy()).max(), 3e-2 * np.abs(go.numpy()).max()) <= 1.0
-    assert float(e[0]) == lam * float(fit[0])                   # wild type: Delta score exactly 0
+    assert float(e[0]) == float(np.float32(lam) * np.float32(float(fit[0])))   # wild type: Delta score exactly 0 (e = 0 + lamda * fit in fp32)
 
 
 def test_config5_full_size_properties():
@@ -318,7 +318,7 @@ def test_config5_full_size_properties():
     eh = a["energy_history"]
     assert np.isfinite(eh).all() and np.array_equal(a["best_energy"], eh.max(0)) and np.array_equal(a["best_step"], eh.argmax(0))
     e_wt, f_wt, _ = m.energy_grad(torch.as_tensor(wt[None]).cuda(), 6, want_grad=False)
-    assert np.all(eh[0] == float(e_wt[0])) and float(e_wt[0]) == lam * float(f_wt[0])
+    assert np.all(eh[0] == float(e_wt[0])) and float(e_wt[0]) == float(np.float32(lam) * np.float32(float(f_wt[0])))
     e_b, f_b, _ = m.energy_grad(torch.as_tensor(a["best_idx"]).cuda(), 6, want_grad=False)
     assert np.array_equal(e_b.cpu().numpy(), a["best_energy"]) and np.array_equal(f_b.cpu().numpy(), a["best_fitness"])
     assert (pka["dist"] < 10).all() and 0.0 < tra["accepted"].mean() < 1.0
