@@ -312,21 +312,48 @@ __device__ __forceinline__ RowLetters<GPT> row_issue(const Geom& g, const RowSrc
     q.st = state_row[g.sh + t]; q.wt = wt_row[g.sh + t];
     return q;
 }
-template <int GPT>
-__device__ __forceinline__ void row_commit(const RowLds& lds, const Geom& g, const RowLetters<GPT>& q, RowRegs<GPT>& R) {
+// SPREAD (device-RNG kernels): also returns the fixed softmax reference of the launch -- half the spread (maximum - minimum) of the
+// staged row's entries at residues lo .. hi, capped at 64. A logit is (g[l][k] - g[l][current letter]) / 2 and the row is frozen
+// along the path, so this bounds every logit of every sub-step from above while 0 (a current letter's logit) is always reached:
+// exp(z - mref) never overflows, no maximum has to be reduced per sub-step, and softmax(z) = exp(z - mref) / sum exp(z - mref)
+// whatever the reference is. (Beyond 64 it stops following the spread: logits up to 64 + 88 still evaluate, and what underflows
+// against a reference of 64 lies below the 2^-23 clamp floor of the categorical anyway.) The per-wave extrema travel through
+// the staging barrier that is there anyway.
+template <int GPT, bool SPREAD = false>
+__device__ __forceinline__ float row_commit(const RowLds& lds, const Geom& g, const RowLetters<GPT>& q, RowRegs<GPT>& R,
+                                            int lo = 0, int hi = 0) {
     const int tid = threadIdx.x;
+    float mx = -INFINITY, mn = INFINITY;
 #pragma unroll
     for (int r = 0; r < GPT; ++r) {
         R.gv[r] = R.valid[r] ? row_parts_sum(q.parts[r], q.nc, q.has_p, q.has_t) : make_float4(0.f, 0.f, 0.f, 0.f);
         if (R.valid[r]) lds.G[tid + r * PPDE_BLOCK] = R.gv[r];
+        if constexpr (SPREAD) {
+            if (R.valid[r] && R.l[r] >= lo && R.l[r] <= hi) {
+                mx = fmaxf(mx, fmaxf(fmaxf(R.gv[r].x, R.gv[r].y), fmaxf(R.gv[r].z, R.gv[r].w)));
+                mn = fminf(mn, fminf(fminf(R.gv[r].x, R.gv[r].y), fminf(R.gv[r].z, R.gv[r].w)));
+            }
+        }
     }
     if (tid < g.L) { lds.St[tid] = q.st; lds.Wt[tid] = q.wt; }
+    if constexpr (SPREAD) {
+        const float wmx = wave_max(mx), wmn = -wave_max(-mn);
+        if ((tid & 63) == 0) { lds.xa[tid >> 6] = wmx; lds.xa[PPDE_NW + (tid >> 6)] = wmn; }
+    }
     __syncthreads();
 #pragma unroll
     for (int r = 0; r < GPT; ++r) {
         R.cur[r] = lds.St[R.l[r]];
         R.wt[r] = lds.Wt[R.l[r]];
     }
+    if constexpr (SPREAD) {
+        const int lane = tid & 63;
+        const float a = lane < PPDE_NW ? lds.xa[lane & (PPDE_NW - 1)] : -INFINITY;
+        const float b = lane < PPDE_NW ? -lds.xa[PPDE_NW + (lane & (PPDE_NW - 1))] : -INFINITY;
+        const float spread = row8_max(a) + row8_max(b);            // max - min (NaN / inf rows end in the S1 check of the sub-steps)
+        return fminf(fmaxf(spread * 0.5f, 0.f), 64.f);
+    }
+    return 0.f;
 }
 template <int GPT>
 __device__ __forceinline__ void load_row(const RowLds& lds, const Geom& g, const RowSrc& src, const uint8_t* state_row,
@@ -825,31 +852,13 @@ __device__ __forceinline__ void propose_body(const PasArgs& a, const RowLds& lds
 // The winner's forward log-probability (a division and a logarithm) is evaluated after the loop, one sub-step per thread.
 template <int GPT>
 __device__ __forceinline__ void propose_body_dev(const PasArgs& a, const RowLds& lds, RowRegs<GPT>& R, int b, int it, int dist0,
-                                                 const ProposePrefetch<GPT>& pp, bool stamp) {
+                                                 const ProposePrefetch<GPT>& pp, bool stamp, const float mref) {
     int dist = dist0;
     const Geom g = a.g;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const float* G = (const float*)lds.G;
     const int Ub = __builtin_amdgcn_readfirstlane(pp.Ub);
-    float mref = 0.f;
-    {
-        float d = 0.f;
-        for (int l = a.min_pos + lane; l <= a.max_pos; l += 64) {
-            const float4* gp = lds.G + 5 * l;
-            const float4 g0 = lds_load4(gp), g1 = lds_load4(gp + 1), g2 = lds_load4(gp + 2), g3 = lds_load4(gp + 3), g4 = lds_load4(gp + 4);
-            const float mx = fmaxf(fmaxf(fmaxf(fmaxf(g0.x, g0.y), fmaxf(g0.z, g0.w)), fmaxf(fmaxf(g1.x, g1.y), fmaxf(g1.z, g1.w))),
-                                   fmaxf(fmaxf(fmaxf(fmaxf(g2.x, g2.y), fmaxf(g2.z, g2.w)), fmaxf(fmaxf(g3.x, g3.y), fmaxf(g3.z, g3.w))),
-                                         fmaxf(fmaxf(g4.x, g4.y), fmaxf(g4.z, g4.w))));
-            const float mn = fminf(fminf(fminf(fminf(g0.x, g0.y), fminf(g0.z, g0.w)), fminf(fminf(g1.x, g1.y), fminf(g1.z, g1.w))),
-                                   fminf(fminf(fminf(fminf(g2.x, g2.y), fminf(g2.z, g2.w)), fminf(fminf(g3.x, g3.y), fminf(g3.z, g3.w))),
-                                         fminf(fminf(g4.x, g4.y), fminf(g4.z, g4.w))));
-            d = fmaxf(d, (mx - mn) * 0.5f);
-        }
-        // (beyond 64 the reference stops following the spread: logits up to 64 + 88 still evaluate, and whatever underflows
-        //  against a reference of 64 lies below the 2^-23 clamp floor of the categorical anyway)
-        mref = fminf(wave_max(d), 64.f);
-    }
     const int NWR = (g.L + 63) >> 6;                 // race waves (L <= 307: at most five)
     const int LQ = pas_lq(g.L), RB4 = 4 * pas_rb(g.L);
     float* dpw = (float*)lds.mv;                     // deferred log-probabilities: winner's probability and S3 per sub-step
@@ -988,10 +997,10 @@ __global__ __launch_bounds__(PPDE_BLOCK) void k_propose(PasArgs a) {
     const int it = iteration_of(a);
     const RowLetters<GPT> rl = row_issue<GPT>(a.g, current_grad_row(a, b), a.cur + (size_t)b * a.g.Ls, a.wt, R);
     const ProposePrefetch<GPT> pp = propose_prefetch<GPT, EXACT>(a, lds, b, it);
-    row_commit<GPT>(lds, a.g, rl, R);
+    const float mref = row_commit<GPT, !EXACT>(lds, a.g, rl, R, a.min_pos, a.max_pos);
     PPDE_STAMP(a.dbg, 9, stamp);
     if constexpr (EXACT) propose_body<GPT, true>(a, lds, R, b, it, __builtin_amdgcn_readfirstlane(pp.dist), pp, stamp);
-    else propose_body_dev<GPT>(a, lds, R, b, it, __builtin_amdgcn_readfirstlane(pp.dist), pp, stamp);
+    else propose_body_dev<GPT>(a, lds, R, b, it, __builtin_amdgcn_readfirstlane(pp.dist), pp, stamp, mref);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1108,7 +1117,7 @@ __device__ __forceinline__ void accept_stage_path(const PasArgs& a, const RowLds
 // R.cur = x's letters, lds.mv / lpf filled by accept_prefetch. On return R.cur holds the proposal's letters.
 template <int GPT, bool DEV = false>
 __device__ __forceinline__ AcceptOut accept_body(const PasArgs& a, const RowLds& lds, RowRegs<GPT>& R, int b, int it,
-                                                 const AcceptPrefetch& pf, bool stamp) {
+                                                 const AcceptPrefetch& pf, bool stamp, const float mref = 0.f) {
     const Geom g = a.g;
     const int tid = threadIdx.x;
     const int Ub = __builtin_amdgcn_readfirstlane(pf.Ub);
@@ -1124,20 +1133,6 @@ __device__ __forceinline__ AcceptOut accept_body(const PasArgs& a, const RowLds&
     // The reverse rows of a path are independent of each other (gradient at y, states along the recorded path), so
     // up to PAS_SB of them are evaluated per pass: two barriers per pass instead of two per sub-step.
     if constexpr (DEV) {
-        // fixed softmax reference of the whole reverse path (see reverse_rows_dev): every wave derives it from the staged row
-        float d = 0.f;
-        for (int l = tid & 63; l < g.L; l += 64) {
-            const float4* gp = lds.G + 5 * l;
-            const float4 g0 = lds_load4(gp), g1 = lds_load4(gp + 1), g2 = lds_load4(gp + 2), g3 = lds_load4(gp + 3), g4 = lds_load4(gp + 4);
-            const float mx = fmaxf(fmaxf(fmaxf(fmaxf(g0.x, g0.y), fmaxf(g0.z, g0.w)), fmaxf(fmaxf(g1.x, g1.y), fmaxf(g1.z, g1.w))),
-                                   fmaxf(fmaxf(fmaxf(fmaxf(g2.x, g2.y), fmaxf(g2.z, g2.w)), fmaxf(fmaxf(g3.x, g3.y), fmaxf(g3.z, g3.w))),
-                                         fmaxf(fmaxf(g4.x, g4.y), fmaxf(g4.z, g4.w))));
-            const float mn = fminf(fminf(fminf(fminf(g0.x, g0.y), fminf(g0.z, g0.w)), fminf(fminf(g1.x, g1.y), fminf(g1.z, g1.w))),
-                                   fminf(fminf(fminf(fminf(g2.x, g2.y), fminf(g2.z, g2.w)), fminf(fminf(g3.x, g3.y), fminf(g3.z, g3.w))),
-                                         fminf(fminf(g4.x, g4.y), fminf(g4.z, g4.w))));
-            d = fmaxf(d, (mx - mn) * 0.5f);
-        }
-        const float mref = fminf(wave_max(d), 64.f);
         const float e0ref = expf(0.f - mref);
         for (int s0 = 0; s0 < Ub; s0 += PAS_SB) {
             const int nrows = Ub - s0;
@@ -1253,9 +1248,9 @@ __global__ __launch_bounds__(PPDE_BLOCK) void k_accept(PasArgs a) {
     PPDE_STAMP(a.dbg, 31, stamp);
     accept_stage_path(a, lds, pf);
     PPDE_STAMP(a.dbg, 32, stamp);
-    row_commit<GPT>(lds, a.g, rl, R);
+    const float mref = row_commit<GPT, DEV>(lds, a.g, rl, R, 0, a.g.L - 1);      // (no masks on the way back: every residue)
     PPDE_STAMP(a.dbg, 33, stamp);
-    const AcceptOut o = accept_body<GPT, DEV>(a, lds, R, b, it, pf, stamp);
+    const AcceptOut o = accept_body<GPT, DEV>(a, lds, R, b, it, pf, stamp, mref);
     if (a.reuse) commit_current_row<GPT>(a, lds, R, b, o, false);
 }
 
@@ -1279,8 +1274,8 @@ __global__ __launch_bounds__(PPDE_BLOCK) void k_accept_propose(PasArgs a) {
     const AcceptPrefetch pf = accept_prefetch(a, lds, b, it);
     const ProposePrefetch<GPT> pp = propose_prefetch<GPT, false>(a, lds, b, it + 1);
     accept_stage_path(a, lds, pf);
-    row_commit<GPT>(lds, g, rl, R);
-    const AcceptOut o = accept_body<GPT, true>(a, lds, R, b, it, pf, stamp);
+    const float mref_y = row_commit<GPT, true>(lds, g, rl, R, 0, g.L - 1);
+    const AcceptOut o = accept_body<GPT, true>(a, lds, R, b, it, pf, stamp, mref_y);
     // ---- the state and gradient the chain continues from
     const uint8_t* rej = a.paper ? a.fb_state + (size_t)b * a.fb_state_stride : nullptr;
     __syncthreads();                                 // everyone is done reading lds.G / lds.St of the accept phase
@@ -1291,12 +1286,33 @@ __global__ __launch_bounds__(PPDE_BLOCK) void k_accept_propose(PasArgs a) {
         if (o.reset) R.cur[r] = R.wt[r];
         else if (!o.acc) R.cur[r] = rej ? (int)rej[g.sh + R.l[r]] : (int)lds.St[R.l[r]];
     }
+    // the softmax reference of the forward path: the spread of the row the chain continues from over the proposal range, exactly
+    // as k_propose derives it (maxima and minima are exact: the same value whatever the reduction order, so both evaluation
+    // policies still produce the same bits); the per-wave extrema travel through the two barriers below
+    {
+        float mx = -INFINITY, mn = INFINITY;
+#pragma unroll
+        for (int r = 0; r < GPT; ++r)
+            if (R.valid[r] && R.l[r] >= a.min_pos && R.l[r] <= a.max_pos) {
+                mx = fmaxf(mx, fmaxf(fmaxf(R.gv[r].x, R.gv[r].y), fmaxf(R.gv[r].z, R.gv[r].w)));
+                mn = fminf(mn, fminf(fminf(R.gv[r].x, R.gv[r].y), fminf(R.gv[r].z, R.gv[r].w)));
+            }
+        const float wmx = wave_max(mx), wmn = -wave_max(-mn);
+        if ((threadIdx.x & 63) == 0) { lds.xa[threadIdx.x >> 6] = wmx; lds.xa[PPDE_NW + (threadIdx.x >> 6)] = wmn; }
+    }
     __syncthreads();                                 // (reads of lds.St above precede the rewrite below)
 #pragma unroll
     for (int r = 0; r < GPT; ++r)
         if (R.valid[r] && R.kb[r] == 0) lds.St[R.l[r]] = (uint8_t)R.cur[r];
+    float mref;
+    {
+        const int lane = threadIdx.x & 63;
+        const float xa = lane < PPDE_NW ? lds.xa[lane & (PPDE_NW - 1)] : -INFINITY;
+        const float xb = lane < PPDE_NW ? -lds.xa[PPDE_NW + (lane & (PPDE_NW - 1))] : -INFINITY;
+        mref = fminf(fmaxf((row8_max(xa) + row8_max(xb)) * 0.5f, 0.f), 64.f);
+    }
     __syncthreads();
-    propose_body_dev<GPT>(a, lds, R, b, it + 1, o.dist, pp, stamp);   // (fused launches exist on the device RNG only)
+    propose_body_dev<GPT>(a, lds, R, b, it + 1, o.dist, pp, stamp, mref);   // (fused launches exist on the device RNG only)
 }
 
 // history row 0 and the running best from the initial population (ppde.py:38-47): one wave per chain
