@@ -360,10 +360,11 @@ def main():
     dt_other = float(np.median(dts_other))
     del ch_other
 
-    # dominant kernel: potts_energy_grad, timed live IN SITU: every Potts launch of IN_SITU real, eagerly launched iterations
-    # carries its own start / stop events (hipExtLaunchKernelGGL: the dispatch's begin / end timestamps as the command
-    # processor records them -- the source rocprofv3's kernel trace reads, so this is the figure profiles/ reproduces). Beside
-    # it, for the record: 500 launches back to back between one event pair (no dependent kernel in front of any of them).
+    # dominant kernel: potts_energy_grad, timed live IN SITU: every kernel of IN_SITU real, eagerly launched iterations carries
+    # a stop event bound to its dispatch (hipExtLaunchKernelGGL: the dispatch's end timestamp as the command processor records
+    # it -- the source rocprofv3's kernel trace reads), and a Potts launch is timed from its predecessor's end to its own end,
+    # which is how rocprofv3's per-kernel table accounts a dependent kernel: this is the figure profiles/ reproduces. Beside
+    # it, for the record: 500 launches back to back between one event pair (no dependent chain kernel in front of any of them).
     pk_situ_us, pk_launches = ch.time_potts_in_situ(IN_SITU)
     pk_us = ch.time_potts_kernel(500)
     alg_bytes = potts_alg_bytes(n, L, Lp)
@@ -442,7 +443,7 @@ def main():
                                          "resident in the 256 MB Infinity Cache (MALL) between launches, so this is fabric "
                                          "traffic, not DRAM traffic",
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_us": pk_situ_us, "launches_timed": pk_launches,
-                         "timing": "in situ: the dispatch's own start / stop timestamps of every Potts launch inside real iterations",
+                         "timing": "in situ: from the predecessor kernel's end to the Potts launch's end (stop events bound to the dispatches) inside real iterations",
                          "avg_launch_us_back_to_back": pk_us, "frac_back_to_back": alg_bytes / (pk_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
                          "committed_profile": rocprof},
             ("value_reuse_grad" if not args.reuse_grad else "value_reevaluate"): world * args.steps / dt_other,

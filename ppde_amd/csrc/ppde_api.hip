@@ -177,26 +177,31 @@ struct EvalTargets {
 static int potts_ng_for(int n) { return n <= 64 ? 1 : 2; }
 
 
-// When set, every Potts launch carries a (start, stop) event pair taken from this pool (in-situ timing): the launch goes
-// through hipExtLaunchKernelGGL, which attaches the events to the DISPATCH ITSELF -- the kernel's own begin / end timestamps as
-// the command processor records them, the same source rocprofv3's kernel trace reads -- with no extra packet on the stream (an
-// hipEventRecord pair around the launch adds two barrier packets and ~2 us to what it measures).
+// When set, EVERY kernel of the timed iterations (chain kernels and Potts launches) is launched through hipExtLaunchKernelGGL
+// with a STOP event from this pool bound to its dispatch: the kernel's own end timestamp as the command processor records it, the
+// source rocprofv3's kernel trace reads, with no extra packet on the stream (an hipEventRecord pair around a launch adds two
+// barrier packets and ~2 us to what it measures; a start event of hipExtLaunchKernelGGL is a marker packet of its own). A Potts
+// launch is then timed from its predecessor's end to its own end, which is how rocprofv3's per-kernel table accounts a
+// dependent kernel of a stream (its interval starts where the predecessor's ends).
 struct EventPool {
     std::vector<hipEvent_t> ev;
+    std::vector<char> is_potts;
     size_t used = 0;
     ~EventPool() { for (hipEvent_t e : ev) if (e) hipEventDestroy(e); }
+    hipEvent_t next(bool potts) {
+        if (used >= ev.size()) return nullptr;
+        is_potts[used] = potts ? 1 : 0;
+        return ev[used++];
+    }
 };
 static thread_local EventPool* g_potts_events = nullptr;
 
 static int launch_potts(const ppde_model* m, const States& st, int n, const EvalTargets& t, hipStream_t s,
                         int b_off = 0, int n_sub = -1) {
     if (n_sub < 0) n_sub = n;
-    EventPool* ep = g_potts_events;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    if (ep && ep->used + 2 <= ep->ev.size()) { ev0 = ep->ev[ep->used++]; ev1 = ep->ev[ep->used++]; }
-    else ep = nullptr;
-    // one launch form for every instantiation: plain, or with the dispatch's own start / stop events
-#define PPDE_PL(K) do { if (ep) hipExtLaunchKernelGGL(K, grid, dim3(256), (uint32_t)lds, s, ev0, ev1, 0, a, nby); \
+    hipEvent_t ev1 = g_potts_events ? g_potts_events->next(true) : nullptr;
+    // one launch form for every instantiation: plain, or with a stop event bound to the dispatch (in-situ timing)
+#define PPDE_PL(K) do { if (ev1) hipExtLaunchKernelGGL(K, grid, dim3(256), (uint32_t)lds, s, nullptr, ev1, 0, a, nby); \
                         else hipLaunchKernelGGL(K, grid, dim3(256), lds, s, a, nby); } while (0)
     ARGCHK(st.T && st.n_pad >= n + 256, "the states have no transposed copy for the Potts kernel");
     PottsArgs a{};
@@ -1056,24 +1061,28 @@ static int launch_chain_kernel(ppde_chains* c, ChainKernel which, const PasArgs&
             default: f(std::integral_constant<int, 0>{}); break;
         }
     };
+    hipEvent_t evs = g_potts_events ? g_potts_events->next(false) : nullptr;       // (in-situ timing: this kernel's end = the next Potts launch's start)
+#define PPDE_CL(K) do { if (evs) hipExtLaunchKernelGGL(K, dim3(n_sub), dim3(PPDE_BLOCK), (uint32_t)lds, s, nullptr, evs, 0, a); \
+                        else hipLaunchKernelGGL(K, dim3(n_sub), dim3(PPDE_BLOCK), lds, s, a); } while (0)
     with_gpt([&](auto G) {
         constexpr int GP = decltype(G)::value;
         if (which == KP_PROPOSE && a.rng_mode == 0) {
-            hipLaunchKernelGGL((k_propose<GP, true, 0>), dim3(n_sub), dim3(PPDE_BLOCK), lds, s, a);
+            PPDE_CL((k_propose<GP, true, 0>));
             return;
         }
         with_spec([&](auto S) {
             constexpr int SP = decltype(S)::value;
             constexpr bool policy = (SP & (PAS_SPEC_REEVAL | PAS_SPEC_REUSE)) != 0;
             if (which == KP_ACCEPT_PROPOSE) {
-                if constexpr (!policy) hipLaunchKernelGGL((k_accept_propose<GP, SP>), dim3(n_sub), dim3(PPDE_BLOCK), lds, s, a);
+                if constexpr (!policy) PPDE_CL((k_accept_propose<GP, SP>));
             } else if constexpr (policy || SP == 0) {
-                if (which == KP_PROPOSE) hipLaunchKernelGGL((k_propose<GP, false, SP>), dim3(n_sub), dim3(PPDE_BLOCK), lds, s, a);
-                else if (SP != 0 || a.rng_mode == 1) hipLaunchKernelGGL((k_accept<GP, SP, true>), dim3(n_sub), dim3(PPDE_BLOCK), lds, s, a);
-                else hipLaunchKernelGGL((k_accept<GP, 0, false>), dim3(n_sub), dim3(PPDE_BLOCK), lds, s, a);   // replay: the reference's bits
+                if (which == KP_PROPOSE) PPDE_CL((k_propose<GP, false, SP>));
+                else if (SP != 0 || a.rng_mode == 1) PPDE_CL((k_accept<GP, SP, true>));
+                else PPDE_CL((k_accept<GP, 0, false>));   // replay: the reference's bits
             }
         });
     });
+#undef PPDE_CL
     HIPCHK(hipGetLastError());
     return PPDE_OK;
 }
@@ -1522,9 +1531,11 @@ int ppde_chains_time_potts_in_situ(ppde_chains* c, int iters, float* avg_us, int
     ARGCHK(c->cfg.which & 1, "no Potts expert in this energy");
     ARGCHK(c->cfg.rng_mode == 1, "in-situ timing needs the device RNG");
     ARGCHK(c->steps_done + iters <= c->T, "run would exceed max_steps");
+    ARGCHK(c->streams.size() == 1, "in-situ timing takes consecutive dispatches of ONE stream");
     HIPCHK(hipSetDevice(c->m->device));
     EventPool pool;
-    pool.ev.assign((size_t)iters * 2 * 2 * c->streams.size(), nullptr);
+    pool.ev.assign((size_t)iters * 4 * c->streams.size() + 4, nullptr);     // every kernel of an iteration: <= 2 expert + 2 chain launches
+    pool.is_potts.assign(pool.ev.size(), 0);
     for (auto& e : pool.ev) HIPCHK(hipEventCreate(&e));
     g_potts_events = &pool;
     int rc = enqueue_block(c, nullptr, c->steps_done, iters);
@@ -1536,9 +1547,9 @@ int ppde_chains_time_potts_in_situ(ppde_chains* c, int iters, float* avg_us, int
     double tot = 0.0;
     int cnt = 0;
     if (rc == PPDE_OK)
-        for (size_t i = 0; i + 1 < pool.used; i += 2) {
+        for (size_t i = 1; i < pool.used; ++i) {                             // predecessor's end -> this Potts launch's end
             float ms = 0.f;
-            if (hipEventElapsedTime(&ms, pool.ev[i], pool.ev[i + 1]) == hipSuccess) { tot += ms; ++cnt; }
+            if (pool.is_potts[i] && hipEventElapsedTime(&ms, pool.ev[i - 1], pool.ev[i]) == hipSuccess) { tot += ms; ++cnt; }
         }
     if (rc) return rc;
     ARGCHK(cnt > 0, "no Potts launch was timed");

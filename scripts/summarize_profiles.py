@@ -67,10 +67,12 @@ def main():
         lines += [f"Potts kernel HBM-side traffic per launch = (2 x {vals['FETCH_SIZE']:.0f} + {vals['WRITE_SIZE']:.0f}) KiB "
                   f"= {hbm / 1e6:.2f} MB", ""]
     if a.mfma:
-        lines += ["Reading the MFMA pass: SQ_VALU_MFMA_BUSY_CYCLES sums, over all SIMDs, the cycles the matrix pipe is busy;",
-                  "one v_mfma_f32_16x16x4_f32 occupies it for 32 cycles, so busy / 32 = MFMA instructions issued per launch",
-                  "(k_cnn at 128 chains x 3 networks: 384 x (1728 + 1008) = 1 050 624). Divided by 1024 SIMDs and by the",
-                  "kernel's duration in cycles it is the matrix-pipe utilisation averaged over the chip.", ""]
+        lines += ["Reading the MFMA pass: SQ_VALU_MFMA_BUSY_CYCLES sums, over all SIMDs, the cycles the matrix pipe is busy.",
+                  "Round 4's CNN kernels issue v_mfma_f32_16x16x32_bf16 (16 cycles each; six per 16 x 16 x 32 block of an fp32 product):",
+                  "busy / 16 = MFMA instructions per launch (k_cnn / k_experts at 128 chains x 3 PABP networks: per chain two whole units",
+                  "of 12 + 7 strips and two half units of 6 + 7 strips, 108 MFMAs per strip = 884 736 per launch = 14 155 776 cycles).",
+                  "(Rounds 1-3: v_mfma_f32_16x16x4_f32, 32 cycles each.) Divided by 1024 SIMDs and by the kernel's duration in cycles",
+                  "it is the matrix-pipe utilisation averaged over the chip.", ""]
     if a.fetch or a.write or a.sq or a.mfma:
         open(os.path.join(OUT, f"{a.tag}_pmc.md"), "w").write("\n".join(lines))
     print("\n".join(lines))
