@@ -100,8 +100,10 @@ def measure(args, rank, world, local, backend, steps, warmup, repeats, with_cpu,
     us, nl = C.c_float(), C.c_int()
     _hip.check(_hip.load().ppde_transformer_time_fc1_in_situ(m.handle, _hip.ptr(x), n, C.byref(us), C.byref(nl)))
     us_rand = C.c_float()
-    use160 = os.environ.get("PPDE_TF_160", "1") != "0" and F % 160 == 0         # (tf_host.h: 160 x 160 tiles, rows padded to 1280)
-    M_launch = (n * L + 1279) // 1280 * 1280 if use160 else M
+    use160 = os.environ.get("PPDE_TF_160", "1") != "0" and F % 160 == 0         # (tf_host.h tf_pad_rows: 160 x 160 tiles, rows padded to 640;
+    big = os.environ.get("PPDE_TF_BIG", "0") not in ("", "0")                    #  1280 with the opt-in 256-row tiles)
+    pad = (1280 if big else 640) if use160 else (256 if big else 128)
+    M_launch = (n * L + pad - 1) // pad * pad
     gemm_name = "tf_gemm160" if use160 else "tf_gemm_nt"
     _hip.check(_hip.load().ppde_transformer_time_gemm(local, M_launch, F, D, 50, 3, C.byref(us_rand)))
     gemm_tf = 2.0 * M * F * D / (us.value * 1e-6) / 1e12

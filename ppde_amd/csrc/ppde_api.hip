@@ -697,6 +697,10 @@ int ppde_debug_transformer_read(ppde_model* m, int what, int layer, float* out_h
         case 11: src = w->dqkv; break;
         default: return fail(PPDE_ERR_INVALID, "unknown buffer id");
     }
+    // the workspace holds ONE chunk of chains (after a chunked evaluation: the last chunk); nothing beyond its buffers is read
+    const int D = m->tf->D, F = m->tf->F;
+    const size_t width = what == 1 || what == 11 ? (size_t)3 * D : what == 4 ? (size_t)F : (what == 6 || what == 7 || what == 9) ? (size_t)TF_VOCAB_PAD : (size_t)D;
+    ARGCHK((uint64_t)count <= (uint64_t)w->M_pad * width, "count exceeds the buffer (the workspace holds one chunk of chains: rows of the last chunk evaluated)");
     std::vector<half_t> h((size_t)count);
     HIPCHK(hipMemcpy(h.data(), src, (size_t)count * sizeof(half_t), hipMemcpyDeviceToHost));
     for (int64_t i = 0; i < count; ++i) out_host[i] = (float)h[(size_t)i];

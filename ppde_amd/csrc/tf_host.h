@@ -139,12 +139,19 @@ static int tf_build_model(TfModel* t, int L, const ppde_tf_weights* w) {
 // against 151 at config 5's shape); PPDE_TF_ATT_KO=0: every wave accumulates dK / dV of all keys (tf_attn_bwd)
 static bool tf_att_key_owner() { static const bool on = []() { const char* e = getenv("PPDE_TF_ATT_KO"); return !e || atoi(e) != 0; }(); return on; }
 static bool tf_use_160() { static const bool on = []() { const char* e = getenv("PPDE_TF_160"); return !e || atoi(e) != 0; }(); return on; }
-// rows of the padded token dimension: whole 256-row tiles (tf_gemm_big), and whole 160-row tiles too where those are in use
-static int tf_pad_rows(int M) { const int g = tf_use_160() ? 1280 : 256; return (M + g - 1) / g * g; }
+// rows of the padded token dimension: whole 128-row tiles, whole 160-row tiles too where those are in use (640 = lcm), and whole
+// 256-row tiles only when the opt-in 256-row GEMM is on (PPDE_TF_BIG: 1280 = lcm(160, 256)); a wild-type evaluation (104 rows)
+// then runs 640 rows instead of 1280
+static int tf_pad_rows(int M) {
+    static const bool big = []() { const char* e = getenv("PPDE_TF_BIG"); return e && atoi(e) != 0; }();
+    const int g = tf_use_160() ? (big ? 1280 : 640) : (big ? 256 : 128);
+    return (M + g - 1) / g * g;
+}
 static size_t tf_bytes_per_chain(const TfModel* t) {
     const size_t D = t->D, F = t->F, L = t->L, H = t->H;
     const size_t per_layer = L * ((D + 3 * D + D + F) * sizeof(half_t) + 4 * sizeof(float)) + H * L * sizeof(float2);
-    const size_t shared = L * ((9 * D + 2 * F + 3 * TF_VOCAB_PAD) * sizeof(half_t) + (4 + 20) * sizeof(float));
+    // (the buffers of tf_alloc_work that do not depend on the layer: 12 of width D, 2 of width F, 3 of the padded vocabulary)
+    const size_t shared = L * ((12 * D + 2 * F + 3 * TF_VOCAB_PAD) * sizeof(half_t) + (4 + 20) * sizeof(float));
     return t->layers * per_layer + shared;
 }
 static int tf_chunk_cap(const TfModel* t) {

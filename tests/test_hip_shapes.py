@@ -105,7 +105,7 @@ def test_sampler_vs_oracle_shapes(L, Lp, i0, n, with_cnn):
 
 @pytest.mark.parametrize("L,Lp,i0,with_cnn,n", [(237, 237, 0, False, 300),    # ring Potts kernel, 2 chain groups, 3 chain blocks
                                                  (96, 80, 8, True, 100),       # both experts in one launch (2 chain groups)
-                                                 (96, 80, 8, True, 300),       # 4 chain groups: separate launches
+                                                 (96, 80, 8, True, 300),       # several chain blocks of two groups in the fused launch
                                                  (104, 76, 23, True, 70),      # one single-launch CNN workgroup per CU would fit: chunked CNN instead
                                                  (237, 237, 0, True, 70)])     # chunked CNN + ring Potts
 def test_batch_composition_does_not_change_a_bit(L, Lp, i0, with_cnn, n):
@@ -167,3 +167,45 @@ def test_potts_instantiations_with_pinned_chunk_count_equal_the_general_kernels(
     assert len(res["1"]) == 2 * 22 * 3
     for k in res["1"]:
         assert np.isfinite(res["1"][k]).all() and np.array_equal(res["1"][k], res["0"][k]), k
+
+
+_CNN_KNOBS = r"""
+import sys
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[1] + "/tests"); sys.path.insert(0, sys.argv[1] + "/oracle")
+import numpy as np, torch
+from test_hip_shapes import _model
+out = {}
+for (L, Lp, i0) in ((96, 80, 8), (104, 76, 23), (237, 237, 0)):
+    m, wt, J, h, cnn = _model(L, Lp, i0, True, 3.0, seed=L)
+    for n in (3, 130):
+        idx = np.random.default_rng(L + n).integers(0, 20, (n, L)).astype(np.uint8)
+        idx[0] = wt
+        e, f, g = m.energy_grad(torch.as_tensor(idx).cuda(), 3)
+        out[f"e_{L}_{n}"], out[f"f_{L}_{n}"], out[f"g_{L}_{n}"] = e.cpu().numpy(), f.cpu().numpy(), g.cpu().numpy()
+    m.close()
+np.savez(sys.argv[2], **out)
+"""
+
+
+def test_cnn_launch_forms_give_the_same_bits():
+    """The supervised expert's kernels in their pinned (PPDE_CNN_SPEC, default) and general instantiations, fused with the Potts
+    tiles in one launch (default) or launched separately (PPDE_FUSE_EXPERTS=0): same arithmetic, so energies, fitness and
+    gradients must be bit-identical at the PABP (single launch), UBE4B and GFP (chunked) shapes."""
+    import os
+    import subprocess
+    import sys
+    import tempfile
+    REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    with tempfile.TemporaryDirectory() as d:
+        script = os.path.join(d, "cnn_knobs.py")
+        open(script, "w").write(_CNN_KNOBS)
+        for tag, env in (("default", {}), ("general", {"PPDE_CNN_SPEC": "0"}), ("unfused", {"PPDE_FUSE_EXPERTS": "0"})):
+            out = os.path.join(d, tag + ".npz")
+            r = subprocess.run([sys.executable, script, REPO, out], capture_output=True, text=True, timeout=400, env=dict(os.environ, **env))
+            assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+            res[tag] = dict(np.load(out))
+    assert len(res["default"]) == 3 * 3 * 2
+    for tag in ("general", "unfused"):
+        for k in res["default"]:
+            assert np.isfinite(res["default"][k]).all() and np.array_equal(res["default"][k], res[tag][k]), (tag, k)
