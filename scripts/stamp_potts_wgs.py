@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """Diagnostic: per-workgroup timeline of ONE Potts energy+gradient launch (stamp build, s_memrealtime at workgroup
-entry / DMAs issued / gather done / exit; 100 MHz ticks). Run on the GPU box: python scripts/stamp_potts_wgs.py [--protein=GFP]"""
+entry / DMAs issued / gather done / exit; 100 MHz ticks). Run on the GPU box: python scripts/stamp_potts_wgs.py [--protein=GFP]
+[--in-situ]. Default: a launch right behind another Potts launch (ppde_chains_time_potts_kernel); --in-situ: the proposal's
+evaluation of a real iteration, i.e. the launch right behind k_propose."""
 import ctypes as C
 import os
 import sys
@@ -21,13 +23,17 @@ from ppde_amd.sampler import Chains
 PROT = [a.split("=")[1] for a in sys.argv if a.startswith("--protein=")]
 m, wt, J, h, i0, Lp, cnn = build_model("potts", "cuda:0", PROT[0] if PROT else "PABP")
 n = 128
-ch = Chains(m, n, 8, 2, 0, False, i0, i0 + Lp - 1, 1, 1, reuse_grad=False, use_graph=False, seed=1)
+IN_SITU = "--in-situ" in sys.argv
+ch = Chains(m, n, 64, 2, 0, False, i0, i0 + Lp - 1, 1, 1, reuse_grad=False, use_graph=False, seed=1)
 ch.init(torch.as_tensor(np.tile(wt, (n, 1))).cuda())
 lib = _hip.load()
 lib.ppde_debug_read_wg_stamps.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
 nwg = min(Lp * 5, 2048)
 for rep in range(4):
-    ch.time_potts_kernel(1)            # (one warm launch + one timed launch: the records are the last launch's)
+    if IN_SITU:
+        ch.run(3); ch.sync()           # (EG(x) P EG(y) A per iteration: the records are those of the last EG(y), behind k_propose)
+    else:
+        ch.time_potts_kernel(1)        # (one warm launch + one timed launch: the records are the last launch's)
     wg = np.zeros(4 * nwg, dtype=np.uint64)
     _hip.check(lib.ppde_debug_read_wg_stamps(ch.handle, wg.ctypes.data, 4 * nwg))
     w = wg.reshape(nwg, 4).astype(np.int64)
