@@ -1197,6 +1197,7 @@ int ppde_chains_create(ppde_chains** out, ppde_model* m, const ppde_chain_config
     ARGCHK(!(cfg->which & 2) || m->has_cnn, "supervised expert not set");
     ARGCHK(cfg->chain_offset + (uint64_t)cfg->n_chains <= 0xffffffffull, "chain_offset + n_chains must fit 32 bits");
     ARGCHK(pas_lds_bytes(m->g) <= 160 * 1024 && m->g.N / 4 <= 3 * PPDE_BLOCK, "sequence too long for the chain kernels (L <= 307)");
+    ARGCHK((m->L + 63) / 64 <= PPDE_NW, "more race waves than waves in a chain workgroup");    // (pas.h propose_body_dev: one residue per lane)
     HIPCHK(hipSetDevice(m->device));
     ppde_chains* c = new ppde_chains();
     c->m = m; c->device = m->device; c->cfg = *cfg; c->n = cfg->n_chains; c->T = cfg->max_steps; c->mu_max = 2 * cfg->pas_length - 1;
