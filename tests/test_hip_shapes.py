@@ -71,7 +71,7 @@ def test_cnn_other_kernel_size(L, K):
 
 
 @pytest.mark.parametrize("L,Lp,i0,n,with_cnn", [(237, 237, 0, 24, False), (237, 237, 0, 6, True), (104, 76, 23, 20, True),
-                                                 (40, 7, 31, 1, True)])
+                                                 (40, 7, 31, 1, True), (300, 120, 50, 6, False)])
 def test_sampler_vs_oracle_shapes(L, Lp, i0, n, with_cnn):
     """Trajectories at GFP / UBE4B sizes and with a single chain, host-drawn noise into both implementations."""
     from ppde_amd.sampler import Chains
@@ -95,12 +95,33 @@ def test_sampler_vs_oracle_shapes(L, Lp, i0, n, with_cnn):
     assert np.array_equal(tr["accepted"].astype(bool), ref["accepted"].numpy())
     assert np.array_equal(res["best_idx"], ref["best_idx"].numpy())
     assert np.abs(res["energy_history"] - ref["energy_history"].numpy()).max() <= 1e-4
-    # and the device-RNG path runs at this shape (graph + fused kernels)
-    ch2 = Chains(m, n, 45, pas, nmut, False, i0, i0 + Lp - 1, 3 if with_cnn else 1, 1, seed=4)
+    # and the device-RNG path at this shape (graph + fused kernels; one to four race waves, one to three groups per thread)
+    # against the oracle fed with the device's own noise -- the two-level draw, the fixed softmax reference, the reverse path
+    from helpers import device_noise
+    T2 = 45
+    ch2 = Chains(m, n, T2, pas, nmut, False, i0, i0 + Lp - 1, 3 if with_cnn else 1, 1, seed=4, trace=True, random_chain=0)
     ch2.init(torch.as_tensor(np.tile(wt, (n, 1))).cuda())
-    ch2.run(45)
-    r2 = ch2.collect()
+    ch2.run(T2)
+    tr2, r2 = ch2.trace(), ch2.collect()
     assert np.isfinite(r2["energy_history"]).all() and np.array_equal(r2["best_energy"], r2["energy_history"].max(0))
+    noise2 = device_noise(ch2, T2, pas)
+    ref2 = orc.run(en, np.tile(wt.astype(np.int64), (n, 1)), wt, lambda t: noise2[t], T2, i0, i0 + Lp - 1, pas, nmut, False, trace=True)
+    for t in range(T2):
+        U = noise2[t][0].numpy()
+        assert np.array_equal(tr2["U"][t], U)
+        for s in range(int(U.max())):
+            act = s < U
+            assert np.array_equal(tr2["flat"][t, s][act], ref2["traces"][t]["flat"][s].numpy()[act]), (t, s)
+    assert np.array_equal(tr2["accepted"].astype(bool), ref2["accepted"].numpy())
+    assert np.array_equal(r2["best_idx"], ref2["best_idx"].numpy())
+    assert np.abs(r2["energy_history"] - ref2["energy_history"].numpy()).max() <= 1e-4
+    # the same run without trace buffers (specialised kernels, graph replay) gives the same bits
+    ch3 = Chains(m, n, T2, pas, nmut, False, i0, i0 + Lp - 1, 3 if with_cnn else 1, 1, seed=4, random_chain=0)
+    ch3.init(torch.as_tensor(np.tile(wt, (n, 1))).cuda())
+    ch3.run(T2)
+    r3 = ch3.collect()
+    for k in ("energy_history", "fitness_history", "best_idx", "best_step", "random_traj"):
+        assert np.array_equal(r2[k], r3[k]), k
 
 
 @pytest.mark.parametrize("L,Lp,i0,with_cnn,n", [(237, 237, 0, False, 300),    # ring Potts kernel, 2 chain groups, 3 chain blocks
