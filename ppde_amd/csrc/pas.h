@@ -633,11 +633,12 @@ __device__ __forceinline__ float4 exp1_rcp4(const U4& rr) {
     return make_float4(__builtin_amdgcn_rcpf(exp1_from_bits(rr.x)), __builtin_amdgcn_rcpf(exp1_from_bits(rr.y)),
                        __builtin_amdgcn_rcpf(exp1_from_bits(rr.z)), __builtin_amdgcn_rcpf(exp1_from_bits(rr.w)));
 }
-__device__ __forceinline__ void fill_race_variates(const PasArgs& a, const RowLds& lds, int b, int it, int s0, int ns) {
+__device__ __forceinline__ void fill_race_variates(const PasArgs& a, const RowLds& lds, int b, int it, int s0, int ns,
+                                                   int first = threadIdx.x, int stride = PPDE_BLOCK) {
     const int RB = pas_rb(a.g.L), CPS = RB + PPDE_A / 4, LQ = pas_lq(a.g.L);
     const int total = ns * CPS;
     const uint32_t gchain = a.key.chain_lo + (uint32_t)b;
-    for (int c = threadIdx.x; c < total; c += PPDE_BLOCK) {
+    for (int c = first; c < total; c += stride) {
         const int sb = c / CPS, j = c - sb * CPS;
         const uint32_t blk = j < RB ? 0x10000u + (uint32_t)j : 0x20000u + (uint32_t)(j - RB);
         const U4 rr = philox4x32_10(U4{gchain, (uint32_t)it, (uint32_t)(2 + s0 + sb), blk}, a.key.k0, a.key.k1);
@@ -835,21 +836,20 @@ __device__ __forceinline__ void propose_body(const PasArgs& a, const RowLds& lds
 
 // ------------------------------------------------------------------------------------------------
 // The forward path on the DEVICE RNG (rng_mode 1): the same categorical per sub-step as propose_body, drawn in two levels
-// (fill_race_variates) and organised around what bounds these kernels, instruction issue (two waves per SIMD, ~400
-// instructions per wave and sub-step in the flat form):
-//  * a FIXED softmax reference for the whole path. The gradient row is frozen along the path and a logit is
-//    (g[l][k] - g[l][current letter]) / 2, so half the largest spread of an admissible residue's 20 entries bounds every logit
-//    of every sub-step from above (and 0, the current letter's logit, is reached): exp(z - mref) never overflows, no maximum
-//    is reduced per sub-step, and softmax(z) = exp(z - mref) / sum exp(z - mref) whatever the reference is;
-//  * a move changes the logits of ONE residue (and, with a mutation cap, possibly the cap's mask): after the first sub-step
-//    only the wave(s) holding that residue re-evaluate their exponentials and their partial sum, the others go straight to
-//    the barrier;
-//  * the clamp, the residue masses, both races and the clamped row sum S3 are the work of ceil(L / 64) "race waves" (wave w:
-//    residues 64 w .. 64 w + 63, one per lane), each followed by the letter race inside ITS candidate residue (the letter
-//    variates do not depend on the residue, so racing them speculatively per candidate draws from the same law); the records
-//    (race value, residue, letter, probability, partial S3) meet behind the second barrier, where every wave picks the
-//    winner. Two barriers per sub-step, as before.
-// The winner's forward log-probability (a division and a logarithm) is evaluated after the loop, one sub-step per thread.
+// (fill_race_variates) and organised around what bounds these kernels: a sub-step is a chain of dependent reductions, and every
+// barrier or cross-wave exchange in it costs more than the arithmetic between them.
+//  * A FIXED softmax reference for the whole path (row_commit<.., true>): no maximum is reduced per sub-step, and
+//    softmax(z) = exp(z - mref) / sum exp(z - mref) whatever the reference is.
+//  * Pass 1, ONCE, all eight waves: the exponentials e = exp(z - mref) of the start state into LDS (1 920 of them at PABP size:
+//    the one part of the path with enough independent work for 512 threads). One barrier.
+//  * Everything after that runs in WAVE 0 alone, with no barrier and no exchange between waves: per sub-step it (a) re-evaluates
+//    the 20 exponentials of the residue the last move changed (lanes 0..19; a flip of the mutation cap's mask re-evaluates all),
+//    (b) corrects S1, the total of the residue masses of e, by that residue's difference (the lanes keep their residues'
+//    exponentials in registers; one residue per lane and round, a fixed tree over its 20 letters), (c) clamps (ppde/utils.py:106-111), sums the clamped masses P_l and S3, runs the residue race P_l * rcp(q_l) by DPP arg-max,
+//    (d) runs the letter race inside the winning residue (lanes 0..19), (e) applies the move to the letters in LDS.
+//    The two races draw exactly the reference's categorical: P(l*, k*) = P_l / S3 * p[l*][k*] / P_l.
+//  * The other seven waves wait at the closing barrier; then every thread writes its letters of the proposal from LDS and the
+//    winners' log-probabilities (a division and a logarithm each) are evaluated one sub-step per thread.
 template <int GPT>
 __device__ __forceinline__ void propose_body_dev(const PasArgs& a, const RowLds& lds, RowRegs<GPT>& R, int b, int it, int dist0,
                                                  const ProposePrefetch<GPT>& pp, bool stamp, const float mref) {
@@ -858,115 +858,141 @@ __device__ __forceinline__ void propose_body_dev(const PasArgs& a, const RowLds&
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const float* G = (const float*)lds.G;
+    float* E = (float*)lds.Pv;                       // the row's exponentials [L][20]
     const int Ub = __builtin_amdgcn_readfirstlane(pp.Ub);
-    const int NWR = (g.L + 63) >> 6;                 // race waves (L <= 307: at most five)
     const int LQ = pas_lq(g.L), RB4 = 4 * pas_rb(g.L);
     float* dpw = (float*)lds.mv;                     // deferred log-probabilities: winner's probability and S3 per sub-step
     float* ds3 = dpw + 128;
-    int pend_l = 0, pend_k = 0;                      // the last move, not yet applied to lds.St
-    int ls_prev = -1;
-    bool capped_prev = false;
-    float4 e[GPT];                                   // this thread's exponentials (kept across sub-steps)
-    for (int s = 0; s < Ub; ++s) {
+    // ---- pass 1 (every wave): z = (g - g[current letter]) / 2 with the forward masks (ppde.py:98-104), e = exp(z - mref) -> LDS
+    PPDE_STAMP(a.dbg, 10, stamp);
+    {
         const bool capped = dist >= a.thr;
-        // ---- pass 1 (only where something changed): z = (g - g[current letter]) / 2 with the forward masks (ppde.py:98-104),
-        //      e = exp(z - mref) -> LDS, the wave's partial sum of them
-        bool upd = (s == 0);                         // (the first sub-step: every wave, also one without a valid lane, posts its sum)
 #pragma unroll
-        for (int r = 0; r < GPT; ++r) upd |= R.valid[r] & ((R.l[r] == ls_prev) | (capped != capped_prev));
-        PPDE_STAMP(a.dbg, 10 + 4 * min(s, 1), stamp);
-        if (__any(upd)) {
+        for (int r = 0; r < GPT; ++r) {
+            if (!R.valid[r]) continue;
+            const float4 z = forward_logits(a, G, R.gv[r], R.l[r], R.kb[r], R.cur[r], R.wt[r], capped);
+            lds.Pv[tid + r * PPDE_BLOCK] = make_float4(expf(z.x - mref), expf(z.y - mref), expf(z.z - mref), expf(z.w - mref));
+        }
+    }
+    __syncthreads();
+    PPDE_STAMP(a.dbg, 11, stamp);
+    if (wave == 0) {
+        bool capped_prev = dist >= a.thr;
+        int ls_prev = -1;
+        // one letter's exponential under the forward masks (the scalar form of forward_logits)
+        auto letter_exp = [&](int l, int k, int cur, int wt, bool capped) {
+            const bool outside = (l < a.min_pos) | (l > a.max_pos);
+            const bool revertible = capped & (cur != wt);
+            const bool masked = outside | (capped & !(revertible & (k == wt)));
+            const float z = (G[l * 20 + k] - G[l * 20 + cur]) * 0.5f;
+            return masked ? 0.f : expf(z - mref);
+        };
+        // The lane's residues (lane + 64 r) keep their 20 exponentials in REGISTERS across the sub-steps (LDS stays the
+        // authoritative copy: the letter race and the lanes that re-evaluate a residue use it); S1 is carried along and
+        // corrected by the changed residue's difference.
+        constexpr int NRES = (GPT * PPDE_BLOCK * 4 / PPDE_A + 63) / 64;      // residues per lane: 2 / 4 / 5 for GPT = 1 / 2 / 3
+        float4 ev[NRES][5];
+        auto load_res = [&](int r) {
+            const float4* pe = lds.Pv + 5 * min(lane + 64 * r, g.L - 1);
+            ev[r][0] = lds_load4(pe); ev[r][1] = lds_load4(pe + 1); ev[r][2] = lds_load4(pe + 2); ev[r][3] = lds_load4(pe + 3); ev[r][4] = lds_load4(pe + 4);
+        };
+        auto total_mass = [&]() {                     // sum of the residue masses of e (a fixed tree per residue, then the wave)
             float sm = 0.f;
 #pragma unroll
-            for (int r = 0; r < GPT; ++r) {
-                e[r] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (!R.valid[r]) continue;
-                const float4 z = forward_logits(a, G, R.gv[r], R.l[r], R.kb[r], R.cur[r], R.wt[r], capped);
-                e[r].x = expf(z.x - mref); e[r].y = expf(z.y - mref); e[r].z = expf(z.z - mref); e[r].w = expf(z.w - mref);
-                sm += e[r].x; sm += e[r].y; sm += e[r].z; sm += e[r].w;
-                lds.Pv[tid + r * PPDE_BLOCK] = e[r];
+            for (int r = 0; r < NRES; ++r) {
+                const float4 t = add4(add4(add4(ev[r][0], ev[r][1]), add4(ev[r][2], ev[r][3])), ev[r][4]);
+                sm += lane + 64 * r < g.L ? (t.x + t.y) + (t.z + t.w) : 0.f;
             }
-            const float sw = wave_sum(sm);
-            if (lane == 0) lds.xa[wave] = sw;
-        }
-        // the next PAS_QS sub-steps' variates (the race waves finished with the previous ones before the last barrier)
-        if (s > 0 && (s % PAS_QS) == 0) fill_race_variates(a, lds, b, it, s, min(PAS_QS, Ub - s));
-        __syncthreads();
-        if (tid == 0 && s > 0) lds.St[pend_l] = (uint8_t)pend_k;   // every wave has left the previous sub-step
-        PPDE_STAMP(a.dbg, 11 + 4 * min(s, 1), stamp);
-        // ---- race waves: softmax -> clamp (ppde/utils.py:106-111) of one residue per lane, its mass, both races, partial S3
-        if (wave < NWR) {
-            float S1 = row8_sum(lane < PPDE_NW ? lds.xa[lane & (PPDE_NW - 1)] : 0.f);
-            if (!(S1 > 0.f && S1 < INFINITY)) {       // no admissible move (or a non-finite gradient): the reference raises here
-                if (tid == 0) flag_error(a.err_flag, 1);
-                S1 = 1.f;
-            }
-            const float c = 1.0f / S1;
-            const float* qs = lds.qv + (s % PAS_QS) * LQ;
-            const int l = wave * 64 + lane;
-            const bool ok = l < g.L;
-            const int la = ok ? l : g.L - 1;
-            const float4* pe = lds.Pv + 5 * la;
-            float4 p0 = lds_load4(pe), p1 = lds_load4(pe + 1), p2 = lds_load4(pe + 2), p3 = lds_load4(pe + 3), p4 = lds_load4(pe + 4);
-            const float rq = qs[la];
-            auto clamp4 = [&](float4& p) {
-                p.x = __builtin_amdgcn_fmed3f(p.x * c, PPDE_EPS, 1.0f - PPDE_EPS); p.y = __builtin_amdgcn_fmed3f(p.y * c, PPDE_EPS, 1.0f - PPDE_EPS);
-                p.z = __builtin_amdgcn_fmed3f(p.z * c, PPDE_EPS, 1.0f - PPDE_EPS); p.w = __builtin_amdgcn_fmed3f(p.w * c, PPDE_EPS, 1.0f - PPDE_EPS);
-            };
-            clamp4(p0); clamp4(p1); clamp4(p2); clamp4(p3); clamp4(p4);
-            const float4 t = add4(add4(add4(p0, p1), add4(p2, p3)), p4);
-            const float P = (t.x + t.y) + (t.z + t.w);            // residue mass, a fixed tree over its 20 letters
-            const float S3w = wave_sum(ok ? P : 0.f);
-            float vw;
-            const int wl = wave_argmax_lane(ok ? P * rq : -1.f, l, vw);      // (lanes ascend with the residue: the first wins a tie)
-            const int lw = min(wave * 64 + wl, g.L - 1);
-            // the letter inside this wave's candidate residue (lane = letter)
-            const int kl = min(lane, PPDE_A - 1);
-            const float pk = __builtin_amdgcn_fmed3f(((const float*)lds.Pv)[lw * PPDE_A + kl] * c, PPDE_EPS, 1.0f - PPDE_EPS);
-            float vk;
-            const int kw = wave_argmax_lane(lane < PPDE_A ? pk * qs[RB4 + kl] : -1.f, lane, vk);
-            const float pw = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, pk), kw));
-            if (lane == 0) {
-                *(float4*)(lds.xb + 8 * wave) = make_float4(vw, __int_as_float(lw), __int_as_float(kw), pw);
-                lds.xb[8 * wave + 4] = S3w;
-            }
-        }
-        __syncthreads();
-        // ---- every wave: the winner among the race waves' candidates (records ascend with the residue: the first maximum has
-        //      the smallest index)
-        int win;
-        {
-            const float rv = lane < NWR ? lds.xb[8 * (lane & 7)] : -1.f;
-            const float vm = row8_max(rv);
-            const int W = __builtin_amdgcn_readfirstlane(__ffsll((long long)__ballot(lane < NWR && rv == vm)) - 1) & 7;
-            const float4 rec = *(const float4*)(lds.xb + 8 * W);
-            win = min(__float_as_int(rec.y), g.L - 1) * PPDE_A + min(__float_as_int(rec.z), PPDE_A - 1);
-            if (tid == 0) {                          // for the forward log-probability, Categorical.log_prob = log(clamp(p / S3))
-                float s3 = 0.f;
-                for (int w = 0; w < NWR; ++w) s3 += lds.xb[8 * w + 4];
-                dpw[s] = rec.w; ds3[s] = s3;
-            }
-        }
-        PPDE_STAMP(a.dbg, 12 + 4 * min(s, 1), stamp);
-        const int ls = win / 20, ks = win - 20 * ls;
-        const int old = lds.St[ls];                  // (lds.St follows the path: the previous move was applied behind the first barrier)
-        const int wlt = lds.Wt[ls];
+            return wave_sum(sm);
+        };
 #pragma unroll
-        for (int r = 0; r < GPT; ++r)
-            if (R.l[r] == ls) R.cur[r] = ks;
-        dist += (int)(ks != wlt) - (int)(old != wlt);
-        pend_l = ls; pend_k = ks;
-        ls_prev = ls; capped_prev = capped;
-        if (tid == 0) {
-            rec_flat(rec_of(a, b))[s] = win;
-            if (a.tr_flat) a.tr_flat[((size_t)it * a.mu_max + s) * a.n + b] = win;
+        for (int r = 0; r < NRES; ++r) load_res(r);
+        float S1 = total_mass();
+        for (int s = 0; s < Ub; ++s) {
+            const bool capped = dist >= a.thr;
+            // (a) what the last move changed
+            if (s > 0) {
+                if (capped != capped_prev) {         // the mutation cap's mask flipped: every entry changes (rare)
+                    for (int l = lane; l < g.L; l += 64) {
+                        const int cur = lds.St[l], wt = lds.Wt[l];
+                        for (int k = 0; k < PPDE_A; ++k) E[l * PPDE_A + k] = letter_exp(l, k, cur, wt, capped);
+                    }
+#pragma unroll
+                    for (int r = 0; r < NRES; ++r) load_res(r);
+                    S1 = total_mass();
+                } else {
+                    float d = 0.f;
+                    if (lane < PPDE_A) {
+                        const float e_old = E[ls_prev * PPDE_A + lane];
+                        const float e_new = letter_exp(ls_prev, lane, lds.St[ls_prev], lds.Wt[ls_prev], capped);
+                        E[ls_prev * PPDE_A + lane] = e_new;
+                        d = e_new - e_old;
+                    }
+                    S1 += wave_sum(d);
+#pragma unroll
+                    for (int r = 0; r < NRES; ++r)
+                        if (lane + 64 * r == ls_prev) load_res(r);       // (the owner's registers; behind the stores above: one wave, in order)
+                }
+                if ((s % PAS_QS) == 0) fill_race_variates(a, lds, b, it, s, min(PAS_QS, Ub - s), lane, 64);
+            }
+            PPDE_STAMP(a.dbg, 14, stamp && s > 0);
+            float S1c = S1;
+            if (!(S1c > 0.f && S1c < INFINITY)) {     // no admissible move (or a non-finite gradient): the reference raises here
+                if (lane == 0) flag_error(a.err_flag, 1);
+                S1c = 1.f;
+            }
+            const float c = 1.0f / S1c;
+            // (c) clamp, clamped masses (a fixed tree over the 20 letters), S3, residue race
+            const float* qs = lds.qv + (s % PAS_QS) * LQ;
+            float s3 = 0.f, bv = -1.f;
+            int bl = 0;
+#pragma unroll
+            for (int r = 0; r < NRES; ++r) {
+                const int l = lane + 64 * r;
+                const float rq = qs[min(l, g.L - 1)];
+                float4 p[5];
+#pragma unroll
+                for (int i = 0; i < 5; ++i) {
+                    p[i].x = __builtin_amdgcn_fmed3f(ev[r][i].x * c, PPDE_EPS, 1.0f - PPDE_EPS); p[i].y = __builtin_amdgcn_fmed3f(ev[r][i].y * c, PPDE_EPS, 1.0f - PPDE_EPS);
+                    p[i].z = __builtin_amdgcn_fmed3f(ev[r][i].z * c, PPDE_EPS, 1.0f - PPDE_EPS); p[i].w = __builtin_amdgcn_fmed3f(ev[r][i].w * c, PPDE_EPS, 1.0f - PPDE_EPS);
+                }
+                const float4 t = add4(add4(add4(p[0], p[1]), add4(p[2], p[3])), p[4]);
+                const float P = (t.x + t.y) + (t.z + t.w);
+                if (l < g.L) {
+                    s3 += P;
+                    const float v = P * rq;
+                    if (v > bv) { bv = v; bl = l; }  // (strict >, ascending l: the first index wins a tie)
+                }
+            }
+            const float S3 = wave_sum(s3);
+            float vw;
+            const int wl = wave_argmax_lane(bv, bl, vw);
+            const int ls = min(__builtin_amdgcn_readlane(bl, wl), g.L - 1);
+            // (d) the letter inside the winning residue (lane = letter)
+            const int kl = min(lane, PPDE_A - 1);
+            const float pk = __builtin_amdgcn_fmed3f(E[ls * PPDE_A + kl] * c, PPDE_EPS, 1.0f - PPDE_EPS);
+            float vk;
+            const int ks = wave_argmax_lane(lane < PPDE_A ? pk * qs[RB4 + kl] : -1.f, lane, vk);
+            const float pw = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, pk), ks));
+            const int win = ls * PPDE_A + ks;
+            PPDE_STAMP(a.dbg, 12 + 4 * min(s, 1), stamp);
+            // (e) the move: letters in LDS, mutation count, records
+            const int old = lds.St[ls], wlt = lds.Wt[ls];
+            dist += (int)(ks != wlt) - (int)(old != wlt);
+            if (lane == 0) {
+                lds.St[ls] = (uint8_t)ks;
+                dpw[s] = pw; ds3[s] = S3;
+                rec_flat(rec_of(a, b))[s] = win;
+                if (a.tr_flat) a.tr_flat[((size_t)it * a.mu_max + s) * a.n + b] = win;
+            }
+            ls_prev = ls; capped_prev = capped;
+            PPDE_STAMP(a.dbg, 13 + 4 * min(s, 1), stamp);
         }
-        PPDE_STAMP(a.dbg, 13 + 4 * min(s, 1), stamp);
     }
+    __syncthreads();
     PPDE_STAMP(a.dbg, 18, stamp);
     // forward log-probabilities of the path: a masked entry keeps 2^-23 after the clamp (ppde/utils.py:106-111), so it CAN win
     // a race; its log-probability is log(2^-23 / S3) like any other entry's
-    if (a.mu_max > 64) __syncthreads();              // (paths longer than a wavefront: thread 0's last entries must be visible to wave 1)
     if (tid < Ub) rec_logp(rec_of(a, b), a.mu_max)[tid] = logf(clampp(dpw[tid] / ds3[tid]));
     if (tid == 0) {
         ChainRec* rc = rec_of(a, b);
@@ -980,7 +1006,7 @@ __device__ __forceinline__ void propose_body_dev(const PasArgs& a, const RowLds&
     }
 #pragma unroll
     for (int r = 0; r < GPT; ++r)
-        if (R.valid[r] && R.kb[r] == 0) store_letter(a.prop, a.propT, g, a.n_pad, b, R.l[r], (uint8_t)R.cur[r]);
+        if (R.valid[r] && R.kb[r] == 0) store_letter(a.prop, a.propT, g, a.n_pad, b, R.l[r], lds.St[R.l[r]]);
     PPDE_STAMP(a.dbg, 19, stamp);
 }
 
