@@ -608,33 +608,42 @@ int ppde_model_set_transformer(ppde_model* m, int n_layers, int dim, int heads, 
 int ppde_transformer_time_gemm(int device, int M, int N, int K, int reps, int epilogue, float* avg_us) {
     ARGCHK(avg_us && reps >= 1 && M > 0 && N > 0 && K > 0, "bad argument");
     HIPCHK(hipSetDevice(device));
-    DevTmp A, B, C, C2, bias;
-    HIPCHK(A.alloc<half_t>((size_t)M * K)); HIPCHK(B.alloc<half_t>((size_t)N * K));
-    HIPCHK(C.alloc<half_t>((size_t)M * N)); HIPCHK(C2.alloc<half_t>((size_t)M * N)); HIPCHK(bias.alloc<float>((size_t)N));
+    // PPDE_TF_TIME_ROTATE=r (diagnostic): r sets of the [M][*] operands used in rotation, so that a launch finds its A rows and
+    // second epilogue operand in HBM, as inside an evaluation, and not in the 256 MiB Infinity Cache the previous launch left them in
+    static const int rot = []() { const char* e = getenv("PPDE_TF_TIME_ROTATE"); const int v = e ? atoi(e) : 1; return v < 1 ? 1 : v > 8 ? 8 : v; }();
+    DevTmp A[8], B, C[8], C2[8], bias;
+    for (int r = 0; r < rot; ++r) {
+        HIPCHK(A[r].alloc<half_t>((size_t)M * K)); HIPCHK(C[r].alloc<half_t>((size_t)M * N)); HIPCHK(C2[r].alloc<half_t>((size_t)M * N));
+    }
+    HIPCHK(B.alloc<half_t>((size_t)N * K)); HIPCHK(bias.alloc<float>((size_t)N));
     HIPCHK(hipMemset(bias.p, 0, (size_t)N * sizeof(float)));
     hipStream_t s;
     HIPCHK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
     struct SG { hipStream_t s; ~SG() { hipStreamDestroy(s); } } sg{s};
-    hipLaunchKernelGGL(tf_fill_random, dim3((unsigned)(((size_t)M * K + 255) / 256)), dim3(256), 0, s, A.as<half_t>(), (size_t)M * K, 1u);
+    for (int r = 0; r < rot; ++r) {
+        hipLaunchKernelGGL(tf_fill_random, dim3((unsigned)(((size_t)M * K + 255) / 256)), dim3(256), 0, s, A[r].as<half_t>(), (size_t)M * K, 1u + 16u * r);
+        HIPCHK(hipMemsetAsync(C2[r].p, 0, (size_t)M * N * sizeof(half_t), s));
+    }
     hipLaunchKernelGGL(tf_fill_random, dim3((unsigned)(((size_t)N * K + 255) / 256)), dim3(256), 0, s, B.as<half_t>(), (size_t)N * K, 2u);
     HIPCHK(hipGetLastError());
     EventPair ev;
     HIPCHK(hipEventCreate(&ev.a)); HIPCHK(hipEventCreate(&ev.b));
     int rc = PPDE_OK;
-    auto one = [&]() {
+    auto one = [&](int i) {
+        const half_t* a = A[i % rot].as<half_t>();
+        half_t *c = C[i % rot].as<half_t>(), *c2 = C2[i % rot].as<half_t>();
         switch (epilogue) {
-            case TF_EPI_PLAIN: return tf_gemm<TF_EPI_PLAIN>(s, A.as<half_t>(), B.as<half_t>(), C.as<half_t>(), M, N, K);
-            case TF_EPI_BIAS: return tf_gemm<TF_EPI_BIAS>(s, A.as<half_t>(), B.as<half_t>(), C.as<half_t>(), M, N, K, bias.as<float>());
-            case TF_EPI_BIAS_RESID: return tf_gemm<TF_EPI_BIAS_RESID>(s, A.as<half_t>(), B.as<half_t>(), C.as<half_t>(), M, N, K, bias.as<float>(), C2.as<half_t>());
-            case TF_EPI_GELU_BWD: return tf_gemm<TF_EPI_GELU_BWD>(s, A.as<half_t>(), B.as<half_t>(), C.as<half_t>(), M, N, K, nullptr, C2.as<half_t>());
-            default: return tf_gemm<TF_EPI_BIAS_GELU>(s, A.as<half_t>(), B.as<half_t>(), C.as<half_t>(), M, N, K, bias.as<float>(), nullptr, C2.as<half_t>());
+            case TF_EPI_PLAIN: return tf_gemm<TF_EPI_PLAIN>(s, a, B.as<half_t>(), c, M, N, K);
+            case TF_EPI_BIAS: return tf_gemm<TF_EPI_BIAS>(s, a, B.as<half_t>(), c, M, N, K, bias.as<float>());
+            case TF_EPI_BIAS_RESID: return tf_gemm<TF_EPI_BIAS_RESID>(s, a, B.as<half_t>(), c, M, N, K, bias.as<float>(), c2);
+            case TF_EPI_GELU_BWD: return tf_gemm<TF_EPI_GELU_BWD>(s, a, B.as<half_t>(), c, M, N, K, nullptr, c2);
+            default: return tf_gemm<TF_EPI_BIAS_GELU>(s, a, B.as<half_t>(), c, M, N, K, bias.as<float>(), nullptr, c2);
         }
     };
-    HIPCHK(hipMemsetAsync(C2.p, 0, (size_t)M * N * sizeof(half_t), s));
-    for (int i = 0; i < 3 && rc == PPDE_OK; ++i) rc = one();
+    for (int i = 0; i < 3 && rc == PPDE_OK; ++i) rc = one(i);
     if (rc) return rc;
     HIPCHK(hipEventRecord(ev.a, s));
-    for (int i = 0; i < reps && rc == PPDE_OK; ++i) rc = one();
+    for (int i = 0; i < reps && rc == PPDE_OK; ++i) rc = one(i + 3);
     if (rc) return rc;
     HIPCHK(hipEventRecord(ev.b, s));
     HIPCHK(hipEventSynchronize(ev.b));

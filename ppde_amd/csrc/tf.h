@@ -307,12 +307,13 @@ __global__ __launch_bounds__(64 * NWAVE, 2) void tf_gemm_nt(TfGemmArgs g) {
 // kernel is bound by the chip's L2 -> LDS fill). Waves 2 x 2, each 80 x 80 = 5 x 5 MFMA tiles (100
 // accumulator registers; 10 fragment reads per 25 MFMAs against 8 per 16). Everything else is tf_gemm_nt: LDS-DMA staging with
 // the XOR swizzle on the source side, persistent XCD-contiguous tile walk, the second operand prefetched as whole rows,
-// the output staged through LDS. Same k order per output element: same bits.
+// the output staged through LDS. Same k order per output element: same bits. TOUCH: wave 0 pulls the A rows of k tile kt + 3
+// into L2 at step kt (see the k loop): inside an evaluation the A operand comes from HBM.
 // Requirements (the host pads / dispatches): M % 160 == 0, N % 160 == 0, K % 64 == 0.
 // ------------------------------------------------------------------------------------------------------------
 __host__ __device__ constexpr size_t tf_gemm160_lds() { return (size_t)2 * 2 * 160 * 64 * 2; }
 
-template <int EPI>
+template <int EPI, bool TOUCH = false>
 __global__ __launch_bounds__(256, 2) void tf_gemm160(TfGemmArgs g) {
     constexpr int BT = 160, BK = 64, TILE = BT * BK, PPT = 5, MT = 5, WT = 80;   // tile edge, k depth, halfs per operand tile, DMA pieces per wave, MFMA tiles per wave edge, wave tile edge
     constexpr int OCH = BT / 8, OLD = BT + 8;                    // 16-byte chunks per output row, padded row length of the staged tile
@@ -336,6 +337,7 @@ __global__ __launch_bounds__(256, 2) void tf_gemm160(TfGemmArgs g) {
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, wpx = gridDim.x >> 3;
     const int xq = tiles_total >> 3, xr = tiles_total & 7;
     const int xbeg = xcd * xq + min(xcd, xr), xcnt = xq + (xcd < xr ? 1 : 0);
+    [[maybe_unused]] uint32_t pf0 = 0, pf1 = 0;                  // (TOUCH: the touch loads' landing registers)
     for (int ti = slot; ti < xcnt; ti += wpx) {
     const int v = xbeg + ti;
     const int m0 = (v / tiles_n) * BT, n0 = (v % tiles_n) * BT;
@@ -374,12 +376,43 @@ __global__ __launch_bounds__(256, 2) void tf_gemm160(TfGemmArgs g) {
         }
     };
     stage(0, 0);
+    if constexpr (!TOUCH) {
     for (int kt = 0; kt < nk; ++kt) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // k tile kt has landed (this wave's pieces)
         __builtin_amdgcn_s_barrier();                                 // ... for every wave; buffer (kt + 1) & 1 is free
         asm volatile("" ::: "memory");
         if (kt + 1 < nk) stage((kt + 1) & 1, kt + 1);
         compute(kt & 1);
+    }
+    } else {
+    // Inside an evaluation every A operand was streamed to HBM by the previous kernel, and a row slice that comes from there
+    // arrives later than the one k step that two stage buffers give the DMA. Wave 0 therefore TOUCHES the rows of k tile kt + 3 at
+    // step kt (one dword per 128-byte row slice, a plain load whose value nobody reads): the line has two steps to reach L2 and
+    // the DMA of step kt + 2 finds it there. The column tiles of a row panel run side by side on one XCD and share the work: a
+    // workgroup touches every q-th row. The load is issued AFTER the step's DMA, so that the next step's wait (vmcnt counts in
+    // order) leaves exactly it in flight; its register is named again two steps later, behind the wait that proves it landed,
+    // which keeps the allocator from handing the register out in between. The last three steps touch the first three k tiles
+    // of the workgroup's NEXT output tile.
+    const int q = tiles_n >= 16 ? 16 : tiles_n >= 4 ? 4 : tiles_n, jq = (v % tiles_n) % q;
+    const uint32_t pfoff = (uint32_t)min(lane * q + jq, BT - 1) * (uint32_t)(K * 2);
+    const int vn = xbeg + ti + wpx;
+    const half_t* nextA = ti + wpx < xcnt ? g.A + (size_t)((vn / tiles_n) * BT) * K : baseA;
+    auto step = [&](int kt, uint32_t& ra) {
+        if (wave == 0 && kt > 0) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("; touched two steps ago, landed: %0" : : "v"(ra) : "memory");
+        if (kt + 1 < nk) stage((kt + 1) & 1, kt + 1);
+        if (wave == 0) {
+            const int x = kt + 3;
+            const half_t* src = x < nk ? baseA + (size_t)x * BK : nextA + (size_t)min(x - nk, nk - 1) * BK;
+            asm volatile("global_load_dword %0, %1, %2" : "=&v"(ra) : "v"(pfoff), "s"(src) : "memory");
+        }
+        compute(kt & 1);
+    };
+    int kt = 0;
+    for (; kt + 1 < nk; kt += 2) { step(kt, pf0); step(kt + 1, pf1); }
+    if (kt < nk) step(kt, pf0);
     }
     // ---- epilogue (as tf_gemm_nt): the fp16 tile goes through LDS and leaves as whole rows, 16 bytes per lane
     // (lane indices behind a zero the compiler cannot see through: the epilogue's address arithmetic is invariant over the
@@ -483,6 +516,10 @@ __global__ __launch_bounds__(256, 2) void tf_gemm160(TfGemmArgs g) {
     }
     flush(g.C, NT_OUT);      // (the fc1 activation too: kept in the caches for fc2 instead, an evaluation takes 30.4 ms against 30.0)
     __syncthreads();                                                  // the staged tile has been read: the next tile may overwrite it
+    }
+    if constexpr (TOUCH) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("; %0 %1" : : "v"(pf0), "v"(pf1));
     }
 }
 

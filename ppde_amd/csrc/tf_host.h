@@ -222,7 +222,12 @@ static int tf_gemm(hipStream_t s, const half_t* A, const half_t* B, half_t* C, i
     //  an evaluation it is not: 62.6 ms per step against 62.95, A/B/A/B on one box)
     if (tf_use_160() && M % 160 == 0 && N % 160 == 0) {
         const int tiles = (M / 160) * (N / 160), tiles8 = (tiles + 7) & ~7;
-        hipLaunchKernelGGL(tf_gemm160<EPI>, dim3(std::min(tiles8, 512)), dim3(256), tf_gemm160_lds(), s, g);
+        // the A rows touched ahead into L2 (tf_gemm160<EPI, true>): in situ -10 us on the q|k|v input gradient, -6 on the output
+        // projection's, -2..-5 on the forward GEMMs, +4.5 on the GELU' epilogue (which therefore keeps the plain loop);
+        // PPDE_TF_TOUCH=0 switches it off. Same bits.
+        static const bool touch = []() { const char* e = getenv("PPDE_TF_TOUCH"); return !e || atoi(e) != 0; }();
+        if (touch && EPI != TF_EPI_GELU_BWD) hipLaunchKernelGGL((tf_gemm160<EPI, true>), dim3(std::min(tiles8, 512)), dim3(256), tf_gemm160_lds(), s, g);
+        else hipLaunchKernelGGL((tf_gemm160<EPI, false>), dim3(std::min(tiles8, 512)), dim3(256), tf_gemm160_lds(), s, g);
         HIPCHK(hipGetLastError());
         return PPDE_OK;
     }

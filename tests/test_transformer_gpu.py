@@ -395,14 +395,15 @@ def test_opt_in_256_row_gemm_tiles_give_the_same_bits():
         open(script, "w").write(_BIG_TILES)
         # "0": the 128 x 128 kernel everywhere; "1": tf_gemm_big; "160": tf_gemm160 wherever the shape allows
         for tag, env in (("0", dict(PPDE_TF_BIG="0", PPDE_TF_160="0")), ("1", dict(PPDE_TF_BIG="1", PPDE_TF_160="0")),
-                         ("160", dict(PPDE_TF_BIG="0", PPDE_TF_160="1"))):
+                         ("160", dict(PPDE_TF_BIG="0", PPDE_TF_160="1", PPDE_TF_TOUCH="0")),
+                         ("160t", dict(PPDE_TF_BIG="0", PPDE_TF_160="1", PPDE_TF_TOUCH="1"))):    # ... with the A rows touched ahead into L2 (the default)
             out = os.path.join(d, f"gemm{tag}.npz")
             r = subprocess.run([sys.executable, script, REPO, out], capture_output=True, text=True, timeout=300, env=dict(os.environ, **env))
             assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
             res[tag] = dict(np.load(out))
     for k in res["0"]:
         assert np.isfinite(res["0"][k]).all(), k
-        for other in ("1", "160"):
+        for other in ("1", "160", "160t"):
             assert np.array_equal(res["0"][k], res[other][k]), (k, other)
 
 
