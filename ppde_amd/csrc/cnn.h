@@ -134,11 +134,12 @@ __host__ __device__ inline size_t cnn_bf_lds_bytes(int T, int CP, int FP, int J,
     return cnn_bf_region_bytes(T, CP, J) + bits + route + (size_t)FP * 8 + 64 + ((L + CNN_MAX_K + 15) & ~15);
 }
 
+// bf_strips_c: the form the 512-thread kernels (k_cnn, k_experts: 128 registers, four waves per SIMD hide the latencies) use.
 // One wave: for its strips ct = ct0, ct0 + ct_step, ... < ct_end:  acc[RT] = A [rows x 32 KS] (split planes in LDS) x B strip
 // (split fragments from L2: [ct][ks][term][lane] 16 bytes), then epi(i, ct, acc) with i = the wave's i-th strip. Three fragment
 // buffers in rotation over the sequence of (strip, k step) pairs: while one multiplies, the next two are in flight.
 template <int RT, typename Epi>
-__device__ __forceinline__ void bf_strips(const unsigned char* planes, const uint4* Bfrag, const int KS, const int ct0,
+__device__ __forceinline__ void bf_strips_c(const unsigned char* planes, const uint4* Bfrag, const int KS, const int ct0,
                                           const int ct_step, const int ct_end, Epi&& epi) {
     const int lane = threadIdx.x & 63, row = lane & 15, kq = lane >> 4;
     const int nstr = ct0 < ct_end ? (ct_end - ct0 + ct_step - 1) / ct_step : 0;
@@ -191,6 +192,99 @@ __device__ __forceinline__ void bf_strips(const unsigned char* planes, const uin
             if (q + 5 < Q) fill(bz, q + 5);
         }
     }
+}
+
+// bf_strips: the form of the 256-thread chunk kernels (two or three workgroups per CU, 256 registers). The same product as
+// bf_strips_c, block for block and term for term (same bits), with three differences that r04's counters asked for
+// (profiles/r04_experiments.md section 8):
+//  * the (strip, k step) position advances by one per block: the division by the run-time KS per block that bf_strips_c pays
+//    was ~40 scalar instructions in front of 18 MFMAs (SQ_INSTS_SALU: 85 per block at GFP);
+//  * PIPE: the A fragments of block q + 1 are read from LDS while block q multiplies (two register sets; NB even, so that the
+//    set in use is a compile-time choice), instead of four fragment registers refilled between the MFMAs;
+//  * PIPE: a block's MFMAs are issued term by term ACROSS the row tiles, so that consecutive MFMAs never share an accumulator
+//    (the order of the six terms within an accumulator is unchanged).
+// The B fragments are ordinary loads: hipcc waits for all of them in front of every block (vmcnt(0): its wait insertion
+// gives up on the loop's control flow), i.e. the rotation buys one block of lookahead whatever NB is; hand-counted waits on
+// inline-assembly loads (real lookahead of NB - 1 blocks) were built, were correct, and were SLOWER (section 8).
+typedef uint32_t bf_u32x4 __attribute__((ext_vector_type(4)));
+template <int RT, int NB = 4, bool PIPE = false, typename Epi>
+__device__ __forceinline__ void bf_strips(const unsigned char* planes, const uint4* Bfrag, const int KS, const int ct0,
+                                          const int ct_step, const int ct_end, Epi&& epi) {
+    static_assert(!PIPE || NB % 2 == 0, "PIPE alternates two A register sets over the unrolled rotation");
+    const int lane = threadIdx.x & 63, row = lane & 15, kq = lane >> 4;
+    const int nstr = ct0 < ct_end ? (ct_end - ct0 + ct_step - 1) / ct_step : 0;
+    const int Q = nstr * KS;
+    if (Q == 0) return;
+    const int lo0 = (kq * 16 + (row ^ kq)) << 4, lo1 = (kq * 16 + (row ^ kq ^ 4)) << 4;
+    bf_u32x4 bb[NB][3];
+    [[maybe_unused]] bf_u32x4 aa[2][RT][3];
+    f32x4 acc[RT];
+    const bf_u32x4* const bp = (const bf_u32x4*)Bfrag + (size_t)ct0 * KS * 192 + lane;
+    const int fstrip = ct_step * KS * 192;                       // elements between the wave's consecutive strips
+    auto fill = [&](bf_u32x4 (&b)[3], const int off) { b[0] = bp[off]; b[1] = bp[off + 64]; b[2] = bp[off + 128]; };
+    auto a_base = [&](int ks) { return planes + ks * (RT * 3072) + ((ks & 1) ? lo1 : lo0); };
+    auto read_a = [&](bf_u32x4 (&a)[RT][3], int ks) {
+        const unsigned char* ap = a_base(ks);
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int t = 0; t < 3; ++t) a[rt][t] = *(const bf_u32x4*)(ap + rt * 3072 + t * 1024);
+    };
+    auto mult = [&](bf_u32x4 (&b)[3], const int mks) {
+        if (mks == 0) {
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) acc[rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+        const bf16x8 b1 = __builtin_bit_cast(bf16x8, b[0]), b2 = __builtin_bit_cast(bf16x8, b[1]), b3 = __builtin_bit_cast(bf16x8, b[2]);
+        const unsigned char* ap = a_base(mks);
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+            const bf16x8 a1 = __builtin_bit_cast(bf16x8, *(const uint4*)(ap + rt * 3072));
+            const bf16x8 a2 = __builtin_bit_cast(bf16x8, *(const uint4*)(ap + rt * 3072 + 1024));
+            const bf16x8 a3 = __builtin_bit_cast(bf16x8, *(const uint4*)(ap + rt * 3072 + 2048));
+            f32x4 c = acc[rt];                                   // (small terms first)
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a3, b1, c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b3, c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2, b2, c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2, b1, c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b2, c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b1, c, 0, 0, 0);
+            acc[rt] = c;
+        }
+    };
+    auto mult_pipe = [&](bf_u32x4 (&b)[3], bf_u32x4 (&a)[RT][3], bf_u32x4 (&an)[RT][3], const bool more, const int mks) {
+        if (mks == 0) {
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) acc[rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+        if (more) read_a(an, mks + 1 == KS ? 0 : mks + 1);
+        const bf16x8 b1 = __builtin_bit_cast(bf16x8, b[0]), b2 = __builtin_bit_cast(bf16x8, b[1]), b3 = __builtin_bit_cast(bf16x8, b[2]);
+#define BF_TERM(AT, BT) _Pragma("unroll") for (int rt = 0; rt < RT; ++rt) \
+            acc[rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[rt][AT]), BT, acc[rt], 0, 0, 0);
+        BF_TERM(2, b1) BF_TERM(0, b3) BF_TERM(1, b2) BF_TERM(1, b1) BF_TERM(0, b2) BF_TERM(0, b1)     // (small terms first)
+#undef BF_TERM
+    };
+    // (strip, k step) of the next block to fill (as an element offset) and of the next block to multiply, advanced in the loop
+    // body itself (as state captured by the lambdas it went to scratch memory)
+    int foff = 0, fks = 0, mi = 0, mks = 0;
+#define BF_FILL(B) { fill(B, foff); foff += 192; if (++fks == KS) { fks = 0; foff += fstrip - KS * 192; } }
+#pragma unroll
+    for (int u = 0; u < NB; ++u)
+        if (u < Q) BF_FILL(bb[u])
+    if constexpr (PIPE) read_a(aa[0], 0);
+    for (int q = 0; q < Q; q += NB) {
+#pragma unroll
+        for (int u = 0; u < NB; ++u) {
+            if (q + u < Q) {
+                if constexpr (PIPE) mult_pipe(bb[u], aa[u & 1], aa[(u + 1) & 1], q + u + 1 < Q, mks);
+                else mult(bb[u], mks);
+                if (mks == KS - 1) { epi(mi, ct0 + mi * ct_step, acc); mks = 0; ++mi; }
+                else ++mks;
+                if (q + u + NB < Q) BF_FILL(bb[u])
+            }
+        }
+    }
+#undef BF_FILL
 }
 
 // One wave: C[rows x 16] (+)= A[rows x CP] (LDS, stride AS) * B[CP x 16] (global, leading dimension ldb, first
@@ -615,8 +709,13 @@ __device__ __forceinline__ void cnn_body_bf(const CnnArgs& a_, const int bx, con
     for (int k = 0; k < 2; ++k) wdf[k] = net.wd[min(tid + NT * k, FP - 1)];
     for (int l = tid; l < g.L + CNN_MAX_K; l += NT) sSt[l] = l < g.L ? min((int)a.idx[(size_t)b * g.Ls + g.sh + l], 19) : 0;
     for (int w = tid; w < rows * BW; w += NT) sG[w] = 0u;
-    if (halved)
-        for (int f = tid; f < FP; f += NT) { sM[f] = 0.f; sTs[f] = 0; }
+    // the second layer's bias waits in sM[f] for the strip epilogue, which replaces it by the feature's maximum (a global load
+    // inside bf_strips' epilogue would drain the fragment loads in flight); features of the other half: zero, as before
+    for (int f = tid; f < FP; f += NT) {
+        const bool mine = (f >> 4) >= ct_lo && (f >> 4) < ct_hi;
+        sM[f] = mine ? net.be[f] : 0.f;
+        if (halved) sTs[f] = 0;
+    }
     __syncthreads();
     PPDE_STAMP(a.dbg, sb + 1, stamp);
 
@@ -657,9 +756,9 @@ __device__ __forceinline__ void cnn_body_bf(const CnnArgs& a_, const int bx, con
     PPDE_STAMP(a.dbg, sb + 2, stamp);
     // ---- pre2 = h1 We^T + be (six bf16 cross-term MFMAs per block); relu and the running max over t straight from the
     //      accumulators (strict >, rows ascending: the first index wins, like torch.max)
-    bf_strips<RT>(sP, net.WeB, KS, ct_lo + wave, NT / 64, ct_hi, [&](int, int ct, const f32x4 (&acc)[RT]) {
+    auto fwd_epi = [&](int, int ct, const f32x4 (&acc)[RT]) {
         const int f = ct * 16 + (lane & 15);
-        const float bias = net.be[f];
+        const float bias = sM[f];
         float m = -INFINITY;
         int ts = 0;
 #pragma unroll
@@ -678,7 +777,8 @@ __device__ __forceinline__ void cnn_body_bf(const CnnArgs& a_, const int bx, con
             if (om > m || (om == m && ot < ts)) { m = om; ts = ot; }
         }
         if (lane < 16) { sM[f] = m; sTs[f] = ts; }
-    });
+    };
+    bf_strips_c<RT>(sP, net.WeB, KS, ct_lo + wave, NT / 64, ct_hi, fwd_epi);
     __syncthreads();
 
     PPDE_STAMP(a.dbg, sb + 3, stamp);
@@ -715,13 +815,14 @@ __device__ __forceinline__ void cnn_body_bf(const CnnArgs& a_, const int bx, con
     constexpr int NKEEP = (JP / 16 + NT / 64 - 1) / (NT / 64);     // strips per wave: 1 for five taps, 2 for eight
     static_assert(NKEEP <= 2, "at most two backward strips per wave");
     f32x4 keep[NKEEP][RT];
-    bf_strips<RT>(sP, net.WfB, KS, wave, NT / 64, JP / 16, [&](int i, int, const f32x4 (&acc)[RT]) {
+    auto bwd_epi = [&](int i, int, const f32x4 (&acc)[RT]) {
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) {
             if (NKEEP == 1 || i == 0) keep[0][rt] = acc[rt];
             else keep[NKEEP - 1][rt] = acc[rt];
         }
-    });
+    };
+    bf_strips_c<RT>(sP, net.WfB, KS, wave, NT / 64, JP / 16, bwd_epi);
     __syncthreads();
     float* sO = (float*)sP;
 #pragma unroll
@@ -789,6 +890,9 @@ __global__ __launch_bounds__(NT, 2) void k_cnn(CnnArgs a) {
 // Rows per chunk are chosen so that TWO workgroups fit a CU's LDS at GFP's width (256 padded channels): the
 // forward chunk holds [rows x channels] (64 rows: 66 KB), the backward chunk additionally [rows x 5*20] (48 rows:
 // 69 KB). With 96-row chunks a CU held one 4-wave workgroup at a time (fwd 341 us, bwd 300 us per launch at GFP).
+#ifndef CNN_CHUNK_NB
+#define CNN_CHUNK_NB 4                                // B fragment buffers of the chunk kernels' bf_strips
+#endif
 #define CNN_FCH_RT 4                                  // forward: 64 rows per chunk
 #define CNN_BCH_RT 3                                  // backward: 48-row windows
 __host__ __device__ inline int cnn_fwd_chunks(int T, int RT = CNN_FCH_RT) { return (T + RT * 16 - 1) / (RT * 16); }
@@ -799,9 +903,9 @@ __host__ __device__ inline size_t cnn_fwd_chunk_lds(int CP) { return (size_t)CNN
 // a CU (up to 128 padded channels: 48 KB), 48-row chunks beyond (GFP, 256 channels: 72 KB). Backward: the routed gradient's planes,
 // O takes their storage once every wave has read them (as cnn_body_bf).
 __host__ __device__ inline int cnn_bf_fwd_rt(int CP) { return CP <= 128 ? 4 : 3; }
-__host__ __device__ inline size_t cnn_bf_fwd_chunk_lds(int CP) {
+__host__ __device__ inline size_t cnn_bf_fwd_chunk_lds(int CP, int FP) {
     const size_t RT = cnn_bf_fwd_rt(CP);
-    return RT * 3 * (CP / 32) * 1024 + RT * 16 * ((CP + 31) / 32) * 4 + 256;
+    return RT * 3 * (CP / 32) * 1024 + RT * 16 * ((CP + 31) / 32) * 4 + 256 + (size_t)FP * 4;     // (+ letters, + the second layer's bias)
 }
 __host__ __device__ inline size_t cnn_bf_bwd_chunk_lds(int CP, int FP, int J) {
     const size_t rows = CNN_BCH_RT * 16;
@@ -893,6 +997,7 @@ __global__ __launch_bounds__(256, 2) void k_cnn_fwd_chunk(CnnChunkArgs ca) {
     uint32_t* sG = BF ? (uint32_t*)(smem_raw + (size_t)RT * 3 * (CP / 32) * 1024)
                       : (uint32_t*)(sH + (size_t)rows * AS);         // [rows][BW] gate bits of this chunk's rows
     uint8_t* sSt = (uint8_t*)(sG + (size_t)rows * BW);               // letters t0 .. t0 + rows + KT (relative index)
+    [[maybe_unused]] float* sBe = (float*)(sSt + 256);               // (BF) [FP] the second layer's bias: bf_strips' epilogue may not load from global memory
     const int t0 = c * rows;
     [[maybe_unused]] const bool stamp = blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 1;
     PPDE_STAMP(a.dbg, 50, stamp);
@@ -903,6 +1008,8 @@ __global__ __launch_bounds__(256, 2) void k_cnn_fwd_chunk(CnnChunkArgs ca) {
     }
     if constexpr (!BF)
         for (int e = tid; e < rows * 2; e += 256) sH[(e >> 1) * AS + CP + (e & 1)] = 0.f;
+    else
+        for (int f = tid; f < FP; f += 256) sBe[f] = net.be[f];
     __syncthreads();
     // sSt is relative to t0 here: shift the pointer so that cnn_build_rows can index by absolute residue
     PPDE_STAMP(a.dbg, 51, stamp);
@@ -915,7 +1022,7 @@ __global__ __launch_bounds__(256, 2) void k_cnn_fwd_chunk(CnnChunkArgs ca) {
     }
     auto strip_max = [&](int ct, const f32x4 (&acc)[RT]) {
         const int f = ct * 16 + (lane & 15);
-        const float bias = net.be[f];
+        const float bias = BF ? sBe[f] : net.be[f];
         float m = -INFINITY;
         int ts = 0;
 #pragma unroll
@@ -940,7 +1047,8 @@ __global__ __launch_bounds__(256, 2) void k_cnn_fwd_chunk(CnnChunkArgs ca) {
         }
     };
     if constexpr (BF) {
-        bf_strips<RT>(smem_raw, net.WeB, CP / 32, wave, 4, FP / 16, [&](int, int ct, const f32x4 (&acc)[RT]) { strip_max(ct, acc); });
+        // (RT = 4: a second A register set would cost UBE4B its third workgroup per CU)
+        bf_strips<RT, CNN_CHUNK_NB, (RT <= 3)>(smem_raw, net.WeB, CP / 32, wave, 4, FP / 16, [&](int, int ct, const f32x4 (&acc)[RT]) { strip_max(ct, acc); });
     } else {
         for (int ct = wave; ct < FP / 16; ct += 4) {
             f32x4 acc[RT];
@@ -1026,10 +1134,14 @@ __global__ __launch_bounds__(256, 2) void k_cnn_bwd_chunk(CnnChunkArgs ca) {
         // arrays inside the epilogue sent them to scratch memory)
         f32x4 keep0[RT], keep1[RT], keep2[RT];
         auto grab = [&](f32x4 (&kp)[RT], int ct) {
-            bf_strips<RT>(smem_raw, net.WfB, CP / 32, ct, 1 << 20, JPc / 16, [&](int, int, const f32x4 (&acc)[RT]) {
+            auto take = [&](int, int, const f32x4 (&acc)[RT]) {
 #pragma unroll
                 for (int rt = 0; rt < RT; ++rt) kp[rt] = acc[rt];
-            });
+            };
+            // (the pipelined form where two workgroups share a CU, GFP: 505 -> 501 us per step; with three, UBE4B, its
+            //  registers cost more than they buy: 104.8 -> 108.5)
+            if constexpr (SHAPE == 2) bf_strips<RT, CNN_CHUNK_NB, true>(smem_raw, net.WfB, CP / 32, ct, 1 << 20, JPc / 16, take);
+            else bf_strips_c<RT>(smem_raw, net.WfB, CP / 32, ct, 1 << 20, JPc / 16, take);
         };
         grab(keep0, wave);
         if constexpr (NKEEP > 1) grab(keep1, wave + 4);

@@ -324,7 +324,7 @@ static int launch_cnn(const ppde_model* m, const States& st, int n, const EvalTa
         ARGCHK(t.cmax && t.carg && t.cgate && t.cnn_cap >= n, "CNN chunk scratch not allocated for this batch size");
         const bool bf = cnn_bf16();
         const int frt = cnn_fwd_rt(m);
-        const size_t lds_f = bf ? cnn_bf_fwd_chunk_lds(m->CP) : cnn_fwd_chunk_lds(m->CP);
+        const size_t lds_f = bf ? cnn_bf_fwd_chunk_lds(m->CP, m->FP) : cnn_fwd_chunk_lds(m->CP);
         const size_t lds_b = bf ? cnn_bf_bwd_chunk_lds(m->CP, m->FP, m->J) : cnn_bwd_chunk_lds(m->CP, m->FP, m->J);
         ARGCHK(lds_f <= 160 * 1024 && lds_b <= 160 * 1024, "sequence too long for the chunked CNN kernels");
         CnnChunkArgs ca{a, t.cmax, t.carg, t.cgate, cnn_fwd_chunks(m->T, frt), frt * 16};
