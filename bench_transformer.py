@@ -143,7 +143,7 @@ def measure(args, rank, world, local, backend, steps, warmup, repeats, with_cpu,
     }
     if dt_other:
         out["value_reuse_grad" if not args.reuse_grad else "value_reevaluate"] = world * steps / dt_other
-    stats = rocprof_frac("transformer", "tf_gemm160<3>" if use160 else "tf_gemm_nt<3,", 2.0 * M * F * D, MFMA_F16_PEAK_TF * 1e12)   # <3 ...> = the bias + GELU epilogue (fc1)
+    stats = rocprof_frac("transformer", "tf_gemm160<3" if use160 else "tf_gemm_nt<3,", 2.0 * M * F * D, MFMA_F16_PEAK_TF * 1e12)   # <3 ...> = the bias + GELU epilogue (fc1; "<3>" in profiles before the touch-ahead variant, "<3, true>" since)
     if stats:
         stats["consistent_with_this_run"] = bool(abs(stats["avg_launch_us"] - us.value) <= 0.10 * us.value)
         out["roofline"]["committed_profile"] = stats
