@@ -122,7 +122,7 @@ int ppde_transformer_time_gemm(int device, int M, int N, int K, int reps, int ep
 
 /* Diagnostics for the parity tests: an fp16 activation of the last stateless evaluation that used the transformer
  * expert, converted to fp32. what: 0 layer input, 1 q|k|v, 2 (not kept: the backward rebuilds the attention probabilities), 3 post-attention stream,
- * 4 fc1 pre-activation (all of `layer`), 5 final stream, 6 logits, 7 d logits, 8 d embedding, 9 d tokens,
+ * 4 GELU' of the fc1 pre-activation (what the forward keeps for the backward; all of `layer`), 5 final stream, 6 logits, 7 d logits, 8 d embedding, 9 d tokens,
  * 10 / 11 attention output / d q|k|v of the layer evaluated last. The workspace holds ONE chunk of chains (PPDE_TF_WORK_GB; after an
  * evaluation in several chunks: the last one): `count` beyond the buffer's padded rows x width is PPDE_ERR_INVALID. */
 int ppde_debug_transformer_read(ppde_model* m, int what, int layer, float* out_host, int64_t count);

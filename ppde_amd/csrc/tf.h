@@ -62,6 +62,18 @@ __device__ __forceinline__ float tf_gelu_grad(float x) {     // Phi(x) + x * phi
     const float erf_z = copysignf(1.0f - tf_erfc_abs(fabsf(z), e), z);
     return __builtin_fmaf(x * 0.3989422804014327f, e, __builtin_fmaf(0.5f, erf_z, 0.5f));
 }
+// Both at once, for the forward epilogues: y = tf_gelu(x) and gp = tf_gelu_grad(x) bit for bit, from ONE erf. The forward GEMMs
+// store gp (fp16) where they used to store the pre-activation x: the backward's GELU' epilogue is then one multiplication per
+// element instead of an erf + exp of its own (~20 vector instructions per element: as much vector work per tile as the tile
+// is matrix work, r04_experiments.md section 4), for ~5 more in the forward epilogue. The factor is rounded to fp16 once more
+// than the reference's autocast would (which rounds only the product): well inside the fp16 noise of the gradient.
+__device__ __forceinline__ void tf_gelu_both(float x, float& y, float& gp) {
+    float e;
+    const float z = x * 0.70710678118654752f, hx = 0.5f * x;
+    const float erf_z = copysignf(1.0f - tf_erfc_abs(fabsf(z), e), z);
+    y = __builtin_fmaf(hx, erf_z, hx);
+    gp = __builtin_fmaf(x * 0.3989422804014327f, e, __builtin_fmaf(0.5f, erf_z, 0.5f));
+}
 
 // ------------------------------------------------------------------------------------------------------------
 // C[M,N] = A[M,K] * B[N,K]^T (+ epilogue), fp16 operands, fp32 accumulation. 128 x 128 x 64 tiles, 4 waves (2 x 2),
@@ -77,8 +89,8 @@ struct TfGemmArgs {
     const half_t* B;        // [N][K]
     half_t* C;              // [M][N]
     const float* bias;      // [N] (epilogues with a bias)
-    const half_t* R;        // [M][N] residual (BIAS_RESID) or pre-activation (GELU_BWD)
-    half_t* C2;             // [M][N] second output: the pre-activation (BIAS_GELU)
+    const half_t* R;        // [M][N] residual (BIAS_RESID) or GELU' of the pre-activation (GELU_BWD)
+    half_t* C2;             // [M][N] second output: GELU' of the pre-activation (BIAS_GELU)
     int M, N, K;
     float alpha;            // QSCALE: factor of the first `qcols` columns
     int qcols;
@@ -264,7 +276,7 @@ __global__ __launch_bounds__(64 * NWAVE, 2) void tf_gemm_nt(TfGemmArgs g) {
             } else if constexpr (EPI == TF_EPI_GELU_BWD) {
                 const f16x4 h = rpre[i][j];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) out[r] = (half_t)((float)(half_t)v[r] * tf_gelu_grad((float)h[r]));
+                for (int r = 0; r < 4; ++r) out[r] = (half_t)((float)(half_t)v[r] * (float)h[r]);        // (h: GELU' of the pre-activation, as the forward stored it)
             } else {
                 const float4 b4 = *(const float4*)(g.bias + n);
                 const float bb[4] = {b4.x, b4.y, b4.z, b4.w};
@@ -281,14 +293,18 @@ __global__ __launch_bounds__(64 * NWAVE, 2) void tf_gemm_nt(TfGemmArgs g) {
                     for (int r = 0; r < 4; ++r) out[r] = (half_t)((float)out[r] + (float)res[r]);
                 } else if constexpr (EPI == TF_EPI_BIAS_GELU) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) second[i][j][r] = (half_t)tf_gelu((float)out[r]);
+                    for (int r = 0; r < 4; ++r) {                     // (out: the fp16 pre-activation; what is stored is GELU' of it)
+                        float y, gp;
+                        tf_gelu_both((float)out[r], y, gp);
+                        second[i][j][r] = (half_t)y; out[r] = (half_t)gp;
+                    }
                 }
             }
             *(f16x4*)(sOut + ml * OLD + nl) = out;
         }
     }
     if constexpr (EPI == TF_EPI_BIAS_GELU) {
-        flush(g.C2, NT_OUT);                                          // the pre-activation (read again only by the backward)
+        flush(g.C2, NT_OUT);                                          // GELU' of the pre-activation (read again only by the backward)
         __syncthreads();
 #pragma unroll
         for (int i = 0; i < MT; ++i)
@@ -417,7 +433,7 @@ __global__ __launch_bounds__(256, 2) void tf_gemm160(TfGemmArgs g) {
     // ---- epilogue (as tf_gemm_nt): the fp16 tile goes through LDS and leaves as whole rows, 16 bytes per lane
     // (lane indices behind a zero the compiler cannot see through: the epilogue's address arithmetic is invariant over the
     //  persistent tile loop and would otherwise be hoisted above the k loop, where it costs spills next to 100 accumulators)
-    const int oz = (EPI == TF_EPI_BIAS_RESID || EPI == TF_EPI_GELU_BWD) ? opaque_zero() : 0;   // (the others do not spill without it)
+    const int oz = (EPI == TF_EPI_BIAS_RESID || EPI == TF_EPI_GELU_BWD || EPI == TF_EPI_BIAS_GELU) ? opaque_zero() : 0;   // (the others do not spill without it)
     const int tide = tid + oz, lanee = lane + oz, fre = fr + oz, fge = fg + oz;
     half_t* sOut = (half_t*)tf_smem;
     static_assert((size_t)BT * OLD * 2 <= tf_gemm160_lds(), "the output tile is staged in the operand buffers");
@@ -483,7 +499,7 @@ __global__ __launch_bounds__(256, 2) void tf_gemm160(TfGemmArgs g) {
             } else if constexpr (EPI == TF_EPI_GELU_BWD) {
                 const f16x4 h = rpre[i][j];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) out[r] = (half_t)((float)(half_t)vv[r] * tf_gelu_grad((float)h[r]));
+                for (int r = 0; r < 4; ++r) out[r] = (half_t)((float)(half_t)vv[r] * (float)h[r]);      // (h: GELU' of the pre-activation, as the forward stored it)
             } else {
                 const float4 b4 = *(const float4*)(g.bias + n);
                 const float bb[4] = {b4.x, b4.y, b4.z, b4.w};
@@ -500,7 +516,11 @@ __global__ __launch_bounds__(256, 2) void tf_gemm160(TfGemmArgs g) {
                     for (int r = 0; r < 4; ++r) out[r] = (half_t)((float)out[r] + (float)res[r]);
                 } else if constexpr (EPI == TF_EPI_BIAS_GELU) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) second[i][j][r] = (half_t)tf_gelu((float)out[r]);
+                    for (int r = 0; r < 4; ++r) {                     // (out: the fp16 pre-activation; what is stored is GELU' of it)
+                        float y, gp;
+                        tf_gelu_both((float)out[r], y, gp);
+                        second[i][j][r] = (half_t)y; out[r] = (half_t)gp;
+                    }
                 }
             }
             *(f16x4*)(sOut + ml * OLD + nl) = out;
@@ -714,7 +734,11 @@ __global__ __launch_bounds__(512, 1) void tf_gemm_big(TfGemmArgs g) {
                     } else if constexpr (EPI == TF_EPI_BIAS_GELU) {
                         half_t a4[4];
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) a4[r] = (half_t)tf_gelu((float)o[r]);
+                        for (int r = 0; r < 4; ++r) {
+                            float y, gp;
+                            tf_gelu_both((float)o[r], y, gp);
+                            a4[r] = (half_t)y; o[r] = (half_t)gp;
+                        }
                         acc[i][j][2] = pack2(a4[0], a4[1]); acc[i][j][3] = pack2(a4[2], a4[3]);
                     }
                 }
@@ -782,7 +806,7 @@ __global__ __launch_bounds__(512, 1) void tf_gemm_big(TfGemmArgs g) {
                 f16x4 o;
                 if constexpr (EPI == TF_EPI_GELU_BWD) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) o[r] = (half_t)((float)(half_t)v[r] * tf_gelu_grad((float)rv[r]));
+                    for (int r = 0; r < 4; ++r) o[r] = (half_t)((float)(half_t)v[r] * (float)rv[r]);
                 } else {
                     const float4 b4 = *(const float4*)(sBias + nl);
                     const float bb[4] = {b4.x, b4.y, b4.z, b4.w};

@@ -23,7 +23,7 @@ struct TfModel {
 };
 
 struct TfLayerAct {
-    half_t *xin = nullptr, *qkv = nullptr, *xmid = nullptr, *hpre = nullptr;
+    half_t *xin = nullptr, *qkv = nullptr, *xmid = nullptr, *hpre = nullptr;     // (hpre: GELU' of the fc1 pre-activation)
     float2* stat = nullptr;          // softmax row statistics [n][H][L]
     float *mean1 = nullptr, *rstd1 = nullptr, *mean2 = nullptr, *rstd2 = nullptr;
 };
@@ -205,13 +205,18 @@ static int tf_gemm(hipStream_t s, const half_t* A, const half_t* B, half_t* C, i
     // PPDE_TF_BIG=1 uses it wherever the shape allows, =256 / =128 only with that column tile. Same bits either way.
     static const int big = []() { const char* e = getenv("PPDE_TF_BIG"); return e ? atoi(e) : 0; }();
     if (big && M % 256 == 0 && K % 128 == 0 && N >= 256) {
-        const bool wide = N % 256 == 0 && big != 128, narrow = N % 128 == 0 && big != 256;
+        // (the GELU epilogue has two results per element since it stores GELU' for the backward: next to the 128 accumulators of
+        //  a 256-wide tile that spills, so this epilogue takes the 128-wide tile)
+        constexpr bool can_wide = EPI != TF_EPI_BIAS_GELU;
+        const bool wide = can_wide && N % 256 == 0 && big != 128, narrow = N % 128 == 0 && (big != 256 || !can_wide);
         if (wide || narrow) {
             const int TN = wide ? 256 : 128;
             const int tiles = (M >> 8) * (N / TN), tiles8 = (tiles + 7) & ~7;
             const dim3 grid(std::min(tiles8, 256));
-            if (wide) hipLaunchKernelGGL((tf_gemm_big<EPI, 256>), grid, dim3(512), tf_gemm_big_lds<256>(), s, g);
-            else hipLaunchKernelGGL((tf_gemm_big<EPI, 128>), grid, dim3(512), tf_gemm_big_lds<128>(), s, g);
+            if constexpr (can_wide) {
+                if (wide) hipLaunchKernelGGL((tf_gemm_big<EPI, 256>), grid, dim3(512), tf_gemm_big_lds<256>(), s, g);
+            }
+            if (!wide) hipLaunchKernelGGL((tf_gemm_big<EPI, 128>), grid, dim3(512), tf_gemm_big_lds<128>(), s, g);
             HIPCHK(hipGetLastError());
             return PPDE_OK;
         }
@@ -225,8 +230,8 @@ static int tf_gemm(hipStream_t s, const half_t* A, const half_t* B, half_t* C, i
         // the A rows touched ahead into L2 (tf_gemm160<EPI, true>): in situ -10 us on the q|k|v input gradient, -6 on the output
         // projection's, -2..-5 on the forward GEMMs, +4.5 on the GELU' epilogue (which therefore keeps the plain loop);
         // PPDE_TF_TOUCH=0 switches it off. Same bits.
-        static const bool touch = []() { const char* e = getenv("PPDE_TF_TOUCH"); return !e || atoi(e) != 0; }();
-        if (touch && EPI != TF_EPI_GELU_BWD) hipLaunchKernelGGL((tf_gemm160<EPI, true>), dim3(std::min(tiles8, 512)), dim3(256), tf_gemm160_lds(), s, g);
+        static const int touch = []() { const char* e = getenv("PPDE_TF_TOUCH"); return e ? atoi(e) : 1; }();
+        if (touch >= 2 || (touch && EPI != TF_EPI_GELU_BWD)) hipLaunchKernelGGL((tf_gemm160<EPI, true>), dim3(std::min(tiles8, 512)), dim3(256), tf_gemm160_lds(), s, g);
         else hipLaunchKernelGGL((tf_gemm160<EPI, false>), dim3(std::min(tiles8, 512)), dim3(256), tf_gemm160_lds(), s, g);
         HIPCHK(hipGetLastError());
         return PPDE_OK;
@@ -287,7 +292,7 @@ static int tf_ln(hipStream_t s, bool bwd, const half_t* x, half_t* y, const floa
 }
 __global__ void tf_gelu_bwd_ew(const half_t* __restrict__ da, const half_t* __restrict__ y, half_t* __restrict__ dy, size_t count) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < count) dy[i] = (half_t)((float)da[i] * tf_gelu_grad((float)y[i]));
+    if (i < count) dy[i] = (half_t)((float)da[i] * (float)y[i]);        // (y: GELU' of the head's pre-activation, as the forward GEMM stored it)
 }
 // pseudo-random fp16 operands for the GEMM timing hook (zero operands would flatter the clock)
 __global__ void tf_fill_random(half_t* p, size_t count, uint32_t seed) {
