@@ -927,16 +927,16 @@ struct CnnChunkArgs {
 };
 
 // h1 rows [t0, t0 + rows) of one chain into LDS and / or their ReLU gate bits
-template <int KT, bool WANT_H, bool WANT_BITS, bool BF = false>
+template <int KT, bool WANT_H, bool WANT_BITS, bool BF = false, int NTB = 256>
 __device__ __forceinline__ void cnn_build_rows(const CnnNet& net, const uint8_t* sSt, int t0, int rows, int T, int CP, int AS,
                                                float* sH, uint32_t* sG, int BW) {
     const int tid = threadIdx.x;
-    const int G4 = CP / 4, RPR = 256 / G4 > 0 ? 256 / G4 : 1;
-    for (int g4 = tid % (G4 < 256 ? G4 : 256); g4 < G4; g4 += 256) {
+    const int G4 = CP / 4, RPR = NTB / G4 > 0 ? NTB / G4 : 1;
+    for (int g4 = tid % (G4 < NTB ? G4 : NTB); g4 < G4; g4 += NTB) {
         const int tr = tid / G4;
-        if (G4 < 256 && tr >= RPR) continue;
+        if (G4 < NTB && tr >= RPR) continue;
         const float4 bias4 = *(const float4*)(net.bc + 4 * g4);
-        for (int r0 = (G4 < 256 ? tr : 0); r0 < rows; r0 += 2 * RPR) {
+        for (int r0 = (G4 < NTB ? tr : 0); r0 < rows; r0 += 2 * RPR) {
             float4 wv[2][KT];
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
@@ -980,8 +980,8 @@ template <int SHAPE> struct CnnChunkShape {
     static constexpr int J = 100, JP = 112;
 };
 // BF: h1 as split bf16 planes and the contraction on the bf16 matrix pipe (bf_strips); RTV = row tiles per chunk
-template <int KT, int SHAPE = 0, int RTV = CNN_FCH_RT, bool BF = false>      // (SHAPE != 0 is NOT used by the host for this kernel: measured slower, see launch_cnn)
-__global__ __launch_bounds__(256, 2) void k_cnn_fwd_chunk(CnnChunkArgs ca) {
+template <int KT, int SHAPE = 0, int RTV = CNN_FCH_RT, bool BF = false, int NT = 256>      // (SHAPE != 0 is NOT used by the host for this kernel: measured slower, see launch_cnn)
+__global__ __launch_bounds__(NT, 2) void k_cnn_fwd_chunk(CnnChunkArgs ca) {
     warm_kernargs<sizeof(CnnChunkArgs)>();
     extern __shared__ unsigned char smem_raw[];
     const CnnArgs& a = ca.a;
@@ -1001,24 +1001,24 @@ __global__ __launch_bounds__(256, 2) void k_cnn_fwd_chunk(CnnChunkArgs ca) {
     const int t0 = c * rows;
     [[maybe_unused]] const bool stamp = blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 1;
     PPDE_STAMP(a.dbg, 50, stamp);
-    for (int w = tid; w < rows * BW; w += 256) sG[w] = 0u;
-    for (int l = tid; l < rows + CNN_MAX_K; l += 256) {
+    for (int w = tid; w < rows * BW; w += NT) sG[w] = 0u;
+    for (int l = tid; l < rows + CNN_MAX_K; l += NT) {
         const int res = t0 + l;
         sSt[l] = res < g.L ? min((int)a.idx[(size_t)b * g.Ls + g.sh + res], 19) : 0;
     }
     if constexpr (!BF)
-        for (int e = tid; e < rows * 2; e += 256) sH[(e >> 1) * AS + CP + (e & 1)] = 0.f;
+        for (int e = tid; e < rows * 2; e += NT) sH[(e >> 1) * AS + CP + (e & 1)] = 0.f;
     else
-        for (int f = tid; f < FP; f += 256) sBe[f] = net.be[f];
+        for (int f = tid; f < FP; f += NT) sBe[f] = net.be[f];
     __syncthreads();
     // sSt is relative to t0 here: shift the pointer so that cnn_build_rows can index by absolute residue
     PPDE_STAMP(a.dbg, 51, stamp);
-    cnn_build_rows<KT, true, true, BF>(net, sSt - t0, t0, rows, T, CP, AS, sH, sG, BW);
+    cnn_build_rows<KT, true, true, BF, NT>(net, sSt - t0, t0, rows, T, CP, AS, sH, sG, BW);
     __syncthreads();
     PPDE_STAMP(a.dbg, 52, stamp);
     if (a.want_grad) {                                               // the backward windows read the gate instead of recomputing it
         uint32_t* gout = ca.cgate + ((((size_t)ni * a.n + b) * ca.NCH) + c) * rows * BW;
-        for (int w = tid; w < rows * BW; w += 256) gout[w] = sG[w];
+        for (int w = tid; w < rows * BW; w += NT) gout[w] = sG[w];
     }
     auto strip_max = [&](int ct, const f32x4 (&acc)[RT]) {
         const int f = ct * 16 + (lane & 15);
@@ -1048,9 +1048,9 @@ __global__ __launch_bounds__(256, 2) void k_cnn_fwd_chunk(CnnChunkArgs ca) {
     };
     if constexpr (BF) {
         // (RT = 4: a second A register set would cost UBE4B its third workgroup per CU)
-        bf_strips<RT, CNN_CHUNK_NB, (RT <= 3)>(smem_raw, net.WeB, CP / 32, wave, 4, FP / 16, [&](int, int ct, const f32x4 (&acc)[RT]) { strip_max(ct, acc); });
+        bf_strips<RT, CNN_CHUNK_NB, (RT <= 3 && NT == 256)>(smem_raw, net.WeB, CP / 32, wave, NT / 64, FP / 16, [&](int, int ct, const f32x4 (&acc)[RT]) { strip_max(ct, acc); });
     } else {
-        for (int ct = wave; ct < FP / 16; ct += 4) {
+        for (int ct = wave; ct < FP / 16; ct += NT / 64) {
             f32x4 acc[RT];
 #pragma unroll
             for (int rt = 0; rt < RT; ++rt) acc[rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -1061,8 +1061,8 @@ __global__ __launch_bounds__(256, 2) void k_cnn_fwd_chunk(CnnChunkArgs ca) {
     PPDE_STAMP(a.dbg, 53, stamp);
 }
 
-template <int KT, int SHAPE = 0, bool BF = false>
-__global__ __launch_bounds__(256, 2) void k_cnn_bwd_chunk(CnnChunkArgs ca) {
+template <int KT, int SHAPE = 0, bool BF = false, int NT = 256>
+__global__ __launch_bounds__(NT, 2) void k_cnn_bwd_chunk(CnnChunkArgs ca) {
     warm_kernargs<sizeof(CnnChunkArgs)>();
     extern __shared__ unsigned char smem_raw[];
     const CnnArgs& a = ca.a;
@@ -1094,7 +1094,8 @@ __global__ __launch_bounds__(256, 2) void k_cnn_bwd_chunk(CnnChunkArgs ca) {
     PPDE_STAMP(a.dbg, 40, stamp);
     // ---- merge the forward chunks: first index on ties (chunks ascending, strict >)
     float part = 0.f;
-    for (int f = tid; f < FP; f += 256) {
+    // (256 threads whatever NT is: the partition of the features over threads is the summation order of the fitness)
+    for (int f = tid; f < FP && tid < 256; f += 256) {
         const size_t base = (((size_t)ni * a.n + b) * ca.NCH) * FP + f;
         float m = -INFINITY;
         int ts = 0;
@@ -1107,16 +1108,23 @@ __global__ __launch_bounds__(256, 2) void k_cnn_bwd_chunk(CnnChunkArgs ca) {
         sM[f] = (f < F && m > 0.f) ? a.scale * wdf : 0.f;
         sTs[f] = ts;
     }
-    const float tot = block_sum<4>(part, red, phase);
+    float tot;
+    {   // the four-wave tree of the 256-thread form (waves 4.. of a 512-thread workgroup hold zeros and only join the barrier)
+        const float wsum = wave_sum(part);
+        if (lane == 0 && wave < 4) red[wave] = wsum;
+        __syncthreads();
+        ++phase;
+        tot = tree_sum<4>(red);
+    }
     if (c == 0 && tid == 0) a.fitC[((size_t)slot * a.n_parts + ni) * a.n + b] = tot + net.bd;
     if (!a.want_grad) return;
 
-    for (int w = tid; w < rows * ((FP + 31) / 32); w += 256) ((uint32_t*)sD)[w] = 0u;   // route bitmap (in sD's storage)
+    for (int w = tid; w < rows * ((FP + 31) / 32); w += NT) ((uint32_t*)sD)[w] = 0u;   // route bitmap (in sD's storage)
     PPDE_STAMP(a.dbg, 41, stamp);
     // ---- ReLU gate bits of the window's rows, as the forward chunks left them (rows outside [0, T): zero)
     {
         const uint32_t* gin = ca.cgate + ((size_t)ni * a.n + b) * ca.NCH * ca.frows * BW;
-        for (int w = tid; w < rows * BW; w += 256) {
+        for (int w = tid; w < rows * BW; w += NT) {
             const int t = r0 + w / BW;
             sG[w] = (t >= 0 && t < T) ? gin[(size_t)t * BW + (w % BW)] : 0u;
         }
@@ -1124,11 +1132,11 @@ __global__ __launch_bounds__(256, 2) void k_cnn_bwd_chunk(CnnChunkArgs ca) {
     __syncthreads();
     PPDE_STAMP(a.dbg, 42, stamp);
     // ---- route the features whose arg-max row lies in the window, gate (cnn_route_rows)
-    cnn_route_rows<256, BF>(net, rows, r0, CP, AS, FP, BW, sD, (uint32_t*)sD, sG, sM, sTs, sStart, sList, sCnt);
+    cnn_route_rows<NT, BF>(net, rows, r0, CP, AS, FP, BW, sD, (uint32_t*)sD, sG, sM, sTs, sStart, sList, sCnt);
     PPDE_STAMP(a.dbg, 43, stamp);
     // ---- O = dpre1 x Wf on the matrix cores
     if constexpr (BF) {
-        constexpr int JPc = (KT * 20 + 15) & ~15, NKEEP = (JPc / 16 + 3) / 4;       // strips per wave (J = KT * 20)
+        constexpr int NW = NT / 64, JPc = (KT * 20 + 15) & ~15, NKEEP = (JPc / 16 + NW - 1) / NW;       // strips per wave (J = KT * 20)
         static_assert(NKEEP <= 3, "at most three backward strips per wave");
         // one bf_strips call per strip slot of the wave, each into its own accumulator array (a run-time choice between the
         // arrays inside the epilogue sent them to scratch memory)
@@ -1140,12 +1148,12 @@ __global__ __launch_bounds__(256, 2) void k_cnn_bwd_chunk(CnnChunkArgs ca) {
             };
             // (the pipelined form where two workgroups share a CU, GFP: 505 -> 501 us per step; with three, UBE4B, its
             //  registers cost more than they buy: 104.8 -> 108.5)
-            if constexpr (SHAPE == 2) bf_strips<RT, CNN_CHUNK_NB, true>(smem_raw, net.WfB, CP / 32, ct, 1 << 20, JPc / 16, take);
+            if constexpr (SHAPE == 2 && NT == 256) bf_strips<RT, CNN_CHUNK_NB, true>(smem_raw, net.WfB, CP / 32, ct, 1 << 20, JPc / 16, take);
             else bf_strips_c<RT>(smem_raw, net.WfB, CP / 32, ct, 1 << 20, JPc / 16, take);
         };
         grab(keep0, wave);
-        if constexpr (NKEEP > 1) grab(keep1, wave + 4);
-        if constexpr (NKEEP > 2) grab(keep2, wave + 8);
+        if constexpr (NKEEP > 1) grab(keep1, wave + NW);
+        if constexpr (NKEEP > 2) grab(keep2, wave + 2 * NW);
         __syncthreads();                                              // every wave is done reading the planes: O takes their storage
         auto put = [&](const f32x4 (&kp)[RT], int ct) {
             const int j = ct * 16 + (lane & 15);
@@ -1158,10 +1166,10 @@ __global__ __launch_bounds__(256, 2) void k_cnn_bwd_chunk(CnnChunkArgs ca) {
             }
         };
         put(keep0, wave);
-        if constexpr (NKEEP > 1) put(keep1, wave + 4);
-        if constexpr (NKEEP > 2) put(keep2, wave + 8);
+        if constexpr (NKEEP > 1) put(keep1, wave + NW);
+        if constexpr (NKEEP > 2) put(keep2, wave + 2 * NW);
     } else
-    for (int ct = wave; ct < JP / 16; ct += 4) {
+    for (int ct = wave; ct < JP / 16; ct += NT / 64) {
         f32x4 acc[RT];
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) acc[rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -1180,7 +1188,7 @@ __global__ __launch_bounds__(256, 2) void k_cnn_bwd_chunk(CnnChunkArgs ca) {
     // ---- transposed convolution for this chunk's own output positions
     float* out = a.gradC + (((size_t)slot * a.n_parts + ni) * a.n + b) * g.N;
     const int p1 = min(p0 + PO, g.L);
-    for (int e = p0 * 20 + tid; e < p1 * 20; e += 256) {
+    for (int e = p0 * 20 + tid; e < p1 * 20; e += NT) {
         const int p = e / 20, cc = e - 20 * p;
         float ov[KT];
 #pragma unroll

@@ -337,6 +337,21 @@ static int launch_cnn(const ppde_model* m, const States& st, int n, const EvalTa
                           : (m->T == 233 && m->CP == 256 && m->F == 474 && m->FP == 480) ? 2 : 0;
         if (bf) {
             // split-precision chunks (bf16 matrix pipe): forward chunks of 64 rows (<= 128 channels) or 48 rows
+            // Networks of more than 128 channels (GFP: two chunk workgroups per CU by LDS) run the chunk kernels with 512 threads:
+            // four waves per SIMD hide what a block's instruction stream costs better than the second A register set of the
+            // 256-thread form (GFP + CNN 505 -> 446 us per step, A/B on one box); up to 128 channels three 256-thread workgroups
+            // share a CU and 512 threads lose (UBE4B 104.2 -> 106.6). PPDE_CNN_CHUNK_512=0 keeps 256 threads everywhere. Same bits.
+            static const bool allow512 = []() { const char* e = getenv("PPDE_CNN_CHUNK_512"); return !e || atoi(e) != 0; }();
+            const bool wide = allow512 && m->CP > 128;
+            if (wide) {
+                if (m->KT == 5) hipLaunchKernelGGL((k_cnn_fwd_chunk<5, 0, 3, true, 512>), gf, dim3(512), lds_f, s, ca);
+                else hipLaunchKernelGGL((k_cnn_fwd_chunk<CNN_MAX_K, 0, 3, true, 512>), gf, dim3(512), lds_f, s, ca);
+                if (shape == 2) hipLaunchKernelGGL((k_cnn_bwd_chunk<5, 2, true, 512>), gb, dim3(512), lds_b, s, ca);
+                else if (m->KT == 5) hipLaunchKernelGGL((k_cnn_bwd_chunk<5, 0, true, 512>), gb, dim3(512), lds_b, s, ca);
+                else hipLaunchKernelGGL((k_cnn_bwd_chunk<CNN_MAX_K, 0, true, 512>), gb, dim3(512), lds_b, s, ca);
+                HIPCHK(hipGetLastError());
+                return PPDE_OK;
+            }
             if (m->KT == 5 && frt == 4) hipLaunchKernelGGL((k_cnn_fwd_chunk<5, 0, 4, true>), gf, dim3(256), lds_f, s, ca);
             else if (m->KT == 5) hipLaunchKernelGGL((k_cnn_fwd_chunk<5, 0, 3, true>), gf, dim3(256), lds_f, s, ca);
             else if (frt == 4) hipLaunchKernelGGL((k_cnn_fwd_chunk<CNN_MAX_K, 0, 4, true>), gf, dim3(256), lds_f, s, ca);

@@ -210,7 +210,8 @@ np.savez(sys.argv[2], **out)
 
 def test_cnn_launch_forms_give_the_same_bits():
     """The supervised expert's kernels in their pinned (PPDE_CNN_SPEC, default) and general instantiations, fused with the Potts
-    tiles in one launch (default) or launched separately (PPDE_FUSE_EXPERTS=0): same arithmetic, so energies, fitness and
+    tiles in one launch (default) or launched separately (PPDE_FUSE_EXPERTS=0), the long proteins' chunk kernels with 512 (default
+    above 128 channels) or 256 threads (PPDE_CNN_CHUNK_512=0): same arithmetic, so energies, fitness and
     gradients must be bit-identical at the PABP (single launch), UBE4B and GFP (chunked) shapes."""
     import os
     import subprocess
@@ -221,12 +222,13 @@ def test_cnn_launch_forms_give_the_same_bits():
     with tempfile.TemporaryDirectory() as d:
         script = os.path.join(d, "cnn_knobs.py")
         open(script, "w").write(_CNN_KNOBS)
-        for tag, env in (("default", {}), ("general", {"PPDE_CNN_SPEC": "0"}), ("unfused", {"PPDE_FUSE_EXPERTS": "0"})):
+        for tag, env in (("default", {}), ("general", {"PPDE_CNN_SPEC": "0"}), ("unfused", {"PPDE_FUSE_EXPERTS": "0"}),
+                         ("chunks256", {"PPDE_CNN_CHUNK_512": "0"})):    # GFP's chunk kernels with 256 threads (default above 128 channels: 512)
             out = os.path.join(d, tag + ".npz")
             r = subprocess.run([sys.executable, script, REPO, out], capture_output=True, text=True, timeout=400, env=dict(os.environ, **env))
             assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
             res[tag] = dict(np.load(out))
     assert len(res["default"]) == 3 * 3 * 2
-    for tag in ("general", "unfused"):
+    for tag in ("general", "unfused", "chunks256"):
         for k in res["default"]:
             assert np.isfinite(res["default"][k]).all() and np.array_equal(res["default"][k], res[tag][k]), (tag, k)
