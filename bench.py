@@ -15,7 +15,8 @@ chains a GPU holds. Workload = BASELINE.json configs[1]: PABP_YEAST Potts produc
 A=20, 128 chains per GPU (weak scaling: every rank runs its own 128 independent chains, no data-path
 collective; the only collective is the final population gather, outside the timed region like the reference's
 own post-processing, and timed separately as `population_gather_ms`). `--protein GFP --gpus 8` is BASELINE
-configs[3] (1024 chains over 8 GPUs). Inputs are synthetic (seeded couplings, all chains start at the wild
+configs[3] (1024 chains over 8 GPUs) with the Potts expert alone; `--protein GFP --workload potts+cnn --gpus 8` is that config as
+the reference would run it (its energy evaluates the supervised CNN whatever lamda is; --lamda defaults to the README's 15). Inputs are synthetic (seeded couplings, all chains start at the wild
 type) and resident in HBM before the timed region. Rank 0 prints ONE JSON line.
 
 Timing: W warm-up steps, then `--repeats` blocks of EXACTLY K steps, each block bracketed by barrier +
@@ -56,6 +57,9 @@ def parse():
     p.add_argument("--reuse-grad", type=int, default=0,
                    help="0 (default): evaluate energy+gradient twice per step exactly as the reference does; "
                         "1: carry the current state's gradient over (bit-identical results, half the expert calls)")
+    p.add_argument("--lamda", type=float, default=None,
+                   help="energy_lamda of the potts+cnn workload (default: the reference README's value for the protein's Potts expert, "
+                        "README.md:65-72: PABP 5, UBE4B 0.5, GFP 15)")
     p.add_argument("--nmut", type=int, default=0)
     p.add_argument("--pas", type=int, default=2, help="ppde_pas_length (reference default 2)")
     p.add_argument("--streams", type=int, default=1, help="sub-populations run on separate HIP streams")
@@ -85,9 +89,14 @@ def launch_ranks(args):
     return subprocess.run(cmd, env=env).returncode
 
 
+README_LAMDA = {"PABP": 5.0, "UBE4B": 0.5, "GFP": 15.0}      # reference README.md:65-72, Potts expert
+
+
 def resolve_defaults(args):
     """Per-workload defaults of the arguments left unset (None), so that every value can also be asked for explicitly."""
     tf = args.workload == "transformer"
+    if getattr(args, "lamda", None) is None:
+        args.lamda = README_LAMDA[args.protein]
     if args.steps is None:
         args.steps = 20 if tf else 2000
     if args.warmup is None:
@@ -195,7 +204,7 @@ def also_poe(args, device, rank, protein="PABP", lamda=5.0, steps=200, warm=40, 
             out["value_reuse_grad"] = steps / dt
         del ch
     if not args.no_cpu_baseline and protein == "PABP":
-        a2 = argparse.Namespace(**{**vars(args), "cpu_seconds": 8.0})
+        a2 = argparse.Namespace(**{**vars(args), "cpu_seconds": 8.0, "lamda": lamda})
         out["cpu_baseline"] = cpu_baseline(a2, wt, J, h, i0, Lp, cnn, n)
     return out
 
@@ -210,7 +219,7 @@ def committed_profile(tag, kernel, work, peak, live_us):
     return st
 
 
-def torch_rng_value(args, m, wt, i0, Lp, n, which, overlap=False, T=(50, 350)):
+def torch_rng_value(args, m, wt, i0, Lp, n, which, T=(50, 350)):
     """The same workload as a drop-in user runs it (swap the imports, keep the command line): PPDE_PAS.run with
     its default ppde_rng='torch' -- U, q, u drawn on the host with torch's CPU generator in the reference's order
     (ppde.py:67, :109, :138) and uploaded, the trajectory the reference's seed gives. steps/s from the difference of a long and
@@ -220,8 +229,7 @@ def torch_rng_value(args, m, wt, i0, Lp, n, which, overlap=False, T=(50, 350)):
     import torch
     from ppde_amd.encoding import idx_to_onehot
     from ppde_amd.sampler import PPDE_PAS
-    a = argparse.Namespace(ppde_pas_length=args.pas, nmut_threshold=args.nmut, paper_results=False, ppde_rng="torch", seed=1,
-                           ppde_overlap_noise=overlap)
+    a = argparse.Namespace(ppde_pas_length=args.pas, nmut_threshold=args.nmut, paper_results=False, ppde_rng="torch", seed=1)
     energy = type("Energy", (), {"model": m, "which": which})()
     x0 = torch.from_numpy(idx_to_onehot(np.tile(wt, (n, 1)))).float().to(m.device)
 
@@ -259,7 +267,7 @@ def cpu_baseline(args, wt, J, h, i0, Lp, cnn, n):
     import ppde_oracle as orc
     cores = min(os.cpu_count() or 1, 16)      # a 1-GPU box's CPU share; torch's intra-op pool beyond that only adds overhead
     torch.set_num_threads(cores)
-    lam = 5.0 if cnn is not None else 0.0
+    lam = float(getattr(args, "lamda", 5.0)) if cnn is not None else 0.0
     en = orc.EnergyOracle(orc.PottsOracle(J, h, i0, torch.as_tensor(wt.astype(np.int64))),
                           orc.CnnOracle(cnn) if cnn is not None else None, lam)
     L = wt.shape[0]
@@ -320,7 +328,7 @@ def main():
 
     from ppde_amd.sampler import Chains
     from ppde_amd.parallel import all_gather_rows
-    m, wt, J, h, i0, Lp, cnn = build_model(args.workload, device, args.protein)
+    m, wt, J, h, i0, Lp, cnn = build_model(args.workload, device, args.protein, args.lamda)
     n, L = args.chains, wt.shape[0]
     which = 3 if args.workload == "potts+cnn" else 1
     IN_SITU = 200
@@ -428,7 +436,7 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": pname + " Potts product of experts" + (" + supervised CNN (lamda=5)" if cnn else "")
+            "config": {"workload": pname + " Potts product of experts" + (f" + supervised CNN (lamda={args.lamda:g})" if cnn else "")
                                    + f", L={L}, L'={Lp}, A=20, {n} chains/GPU, pas_length={args.pas}, nmut_threshold={args.nmut}, "
                                      "device Philox RNG, all chains start at WT",
                        "chains_per_gpu": n, "total_chains": n * world, "parallelism": f"chains sharded x{world}, no per-step collective",
@@ -459,7 +467,6 @@ def main():
         # BASELINE configs[2] and configs[4] under the same clock: a few short median-of-3 blocks each (N = 1 default workload only)
         if world == 1 and not dist_on and args.workload == "potts" and args.protein == "PABP" and n == 128 and not args.no_also:
             out["value_torch_rng"] = torch_rng_value(args, m, wt, i0, Lp, n, which)
-            out["value_torch_rng_overlapped_upload"] = torch_rng_value(args, m, wt, i0, Lp, n, which, overlap=True)
             t0 = time.perf_counter()
             from ppde_amd.noise import draw_chunk
             draw_chunk(40, n, L * 20, args.pas)
@@ -467,9 +474,7 @@ def main():
             out["value_torch_rng_note"] = ("steps/s of the same workload through PPDE_PAS.run with its default ppde_rng='torch' (what a drop-in user "
                                            "runs: host-drawn U, q, u in the reference's order, replaying the reference's trajectory; gradient reuse). "
                                            "torch_rng_host_draw_ceiling = iterations/s at which this box's host cores draw that noise alone "
-                                           "(torch's CPU exponential_, n * L*20 * max_u variates per iteration): the mode's ceiling. "
-                                           "value_torch_rng_overlapped_upload = with args.ppde_overlap_noise (next chunk drawn and uploaded while "
-                                           "the previous one runs; opt-in)")
+                                           "(torch's CPU exponential_, n * L*20 * max_u variates per iteration): the mode's ceiling")
             del m
             also = {"config3": also_poe(args, device, rank)}
             if out.get("cpu_baseline") and also["config3"].get("cpu_baseline"):

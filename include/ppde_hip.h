@@ -208,12 +208,6 @@ int ppde_chains_run(ppde_chains* c, int steps, const int32_t* U_dev, const float
 /* Block until enqueued work is done; reports PPDE_ERR_NUMERIC if a proposal row degenerated. */
 int ppde_chains_sync(ppde_chains* c);
 
-/* Markers for callers that pipeline rng_mode 0 (the noise of chunk i+1 is drawn and uploaded while chunk i runs; the reference
- * draws its noise inside the loop, ppde.py:67,109,138): ppde_chains_mark records marker `slot` (0 or 1) behind everything
- * enqueued so far, ppde_chains_wait_mark blocks until that point has been reached (at once if the marker was never
- * recorded) -- i.e. until the kernels that read a noise buffer are done and it may be overwritten. */
-int ppde_chains_mark(ppde_chains* c, int slot);
-int ppde_chains_wait_mark(ppde_chains* c, int slot);
 int ppde_chains_steps_done(ppde_chains* c);
 
 /* Current population (after the mutation-cap reset) and what the reference logs every log_every
@@ -252,10 +246,12 @@ int ppde_chains_time_potts_kernel(ppde_chains* c, int reps, float* avg_us);
  * pair on the chains' stream; average microseconds per evaluation. */
 int ppde_chains_time_experts(ppde_chains* c, int reps, float* avg_us);
 
-/* The same kernel timed IN SITU: runs `iters` real iterations (eagerly, on the chains' stream) with a HIP event
- * pair around every Potts energy+gradient launch and returns the mean event-to-event time in microseconds and
- * the number of launches timed. The iterations count towards steps_done. rng_mode 1 only. */
-int ppde_chains_time_potts_in_situ(ppde_chains* c, int iters, float* avg_us, int* launches);
+/* The same kernel timed IN SITU: runs `iters` real iterations of a Potts-only energy (which = 1; eagerly, on the chains'
+ * stream) with a stop event bound to every kernel's dispatch; avg_us = mean time from the predecessor kernel's end to the
+ * Potts launch's end in microseconds, launches = how many were timed, avg_dispatch_us (may be NULL) = mean of the Potts
+ * dispatches' own start -> end stamps (0 if the runtime does not report them). The iterations count towards steps_done.
+ * rng_mode 1 only. */
+int ppde_chains_time_potts_in_situ(ppde_chains* c, int iters, float* avg_us, int* launches, float* avg_dispatch_us);
 
 #ifdef __cplusplus
 }

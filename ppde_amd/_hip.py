@@ -60,8 +60,6 @@ SIGNATURES = {
     "ppde_chains_run": (_i, [_p, _i, _p, _p, _p, _p]),
     "ppde_chains_sync": (_i, [_p]),
     "ppde_chains_steps_done": (_i, [_p]),
-    "ppde_chains_mark": (_i, [_p, _i]),
-    "ppde_chains_wait_mark": (_i, [_p, _i]),
     "ppde_chains_peek": (_i, [_p, _p, _p, _p, _p, _p]),
     "ppde_chains_collect": (_i, [_p, _p, _p, _p, _p, _p, _p, _p]),
     "ppde_chains_trace": (_i, [_p, _p, _p, _p, _p]),
@@ -69,7 +67,7 @@ SIGNATURES = {
     "ppde_chains_philox_dump": (_i, [_p, _i, _i, _p, _p, _p]),
     "ppde_chains_time_potts_kernel": (_i, [_p, _i, C.POINTER(_f)]),
     "ppde_chains_time_experts": (_i, [_p, _i, C.POINTER(_f)]),
-    "ppde_chains_time_potts_in_situ": (_i, [_p, _i, C.POINTER(_f), C.POINTER(_i)]),
+    "ppde_chains_time_potts_in_situ": (_i, [_p, _i, C.POINTER(_f), C.POINTER(_i), C.POINTER(_f)]),
 }
 
 _lib = None

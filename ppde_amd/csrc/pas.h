@@ -338,7 +338,10 @@ __device__ __forceinline__ float row_commit(const RowLds& lds, const Geom& g, co
     if (tid < g.L) { lds.St[tid] = q.st; lds.Wt[tid] = q.wt; }
     if constexpr (SPREAD) {
         const float wmx = wave_max(mx), wmn = -wave_max(-mn);
-        if ((tid & 63) == 0) { lds.xa[tid >> 6] = wmx; lds.xa[PPDE_NW + (tid >> 6)] = wmn; }
+        // through exchange B, not A: the reverse path that follows in the accept kernels writes exchange A (its row sums)
+        // with no barrier in between, while a slower wave may still be reading these extrema; its first write to B sits behind
+        // its own first barrier
+        if ((tid & 63) == 0) { lds.xb[tid >> 6] = wmx; lds.xb[PPDE_NW + (tid >> 6)] = wmn; }
     }
     __syncthreads();
 #pragma unroll
@@ -348,8 +351,8 @@ __device__ __forceinline__ float row_commit(const RowLds& lds, const Geom& g, co
     }
     if constexpr (SPREAD) {
         const int lane = tid & 63;
-        const float a = lane < PPDE_NW ? lds.xa[lane & (PPDE_NW - 1)] : -INFINITY;
-        const float b = lane < PPDE_NW ? -lds.xa[PPDE_NW + (lane & (PPDE_NW - 1))] : -INFINITY;
+        const float a = lane < PPDE_NW ? lds.xb[lane & (PPDE_NW - 1)] : -INFINITY;
+        const float b = lane < PPDE_NW ? -lds.xb[PPDE_NW + (lane & (PPDE_NW - 1))] : -INFINITY;
         const float spread = row8_max(a) + row8_max(b);            // max - min (NaN / inf rows end in the S1 check of the sub-steps)
         return fminf(fmaxf(spread * 0.5f, 0.f), 64.f);
     }
@@ -928,10 +931,16 @@ __device__ __forceinline__ void propose_body_dev(const PasArgs& a, const RowLds&
                         E[ls_prev * PPDE_A + lane] = e_new;
                         d = e_new - e_old;
                     }
-                    S1 += wave_sum(d);
+                    const float dsum = wave_sum(d);
+                    S1 += dsum;
 #pragma unroll
                     for (int r = 0; r < NRES; ++r)
                         if (lane + 64 * r == ls_prev) load_res(r);       // (the owner's registers; behind the stores above: one wave, in order)
+                    // The correction cancels when the residue just moved held (nearly) all the mass -- one logit far above the
+                    // rest: S1 ~ 1 against a remainder of L * 20 * exp(-mref) that can lie below ulp(1). Then the carried sum is
+                    // worth nothing and the total is summed afresh from the registers (the reference takes a logsumexp per
+                    // sub-step, utils.py:106-111; k_accept's reverse sums are exact). Uniform, rare; also catches S1 <= 0.
+                    if (!(fabsf(dsum) <= 16.f * S1)) S1 = total_mass();
                 }
                 if ((s % PAS_QS) == 0) fill_race_variates(a, lds, b, it, s, min(PAS_QS, Ub - s), lane, 64);
             }

@@ -187,9 +187,10 @@ struct EventPool {
     std::vector<hipEvent_t> ev;
     std::vector<char> is_potts;
     size_t used = 0;
+    bool exhausted = false;      // a launch went out untimed: the intervals are no longer predecessor -> successor
     ~EventPool() { for (hipEvent_t e : ev) if (e) hipEventDestroy(e); }
     hipEvent_t next(bool potts) {
-        if (used >= ev.size()) return nullptr;
+        if (used >= ev.size()) { exhausted = true; return nullptr; }
         is_potts[used] = potts ? 1 : 0;
         return ev[used++];
     }
@@ -1017,8 +1018,6 @@ struct ppde_chains {
     // graph replay: segments of different lengths, longest first, captured once by ppde_chains_init
     struct GraphSeg { hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr; int len = 0; };
     std::vector<GraphSeg> graphs;
-    hipEvent_t marks[2] = {nullptr, nullptr};    // ppde_chains_mark / ppde_chains_wait_mark
-    bool mark_set[2] = {false, false};
     int n_captures = 0, n_captures_in_run = 0;   // graphs captured in all / inside ppde_chains_run (must stay 0)
     long long n_replayed_steps = 0, n_eager_steps = 0;
     std::vector<void*> allocs;
@@ -1309,7 +1308,6 @@ int ppde_chains_destroy(ppde_chains* c) {
     if (c->h_err) hipHostFree(c->h_err);
     for (hipStream_t st : c->streams) if (st) hipStreamDestroy(st);
     for (hipEvent_t ev : c->events) if (ev) hipEventDestroy(ev);
-    for (hipEvent_t ev : c->marks) if (ev) hipEventDestroy(ev);
     delete c;
     return PPDE_OK;
 }
@@ -1447,23 +1445,6 @@ int ppde_chains_sync(ppde_chains* c) {
 
 int ppde_chains_steps_done(ppde_chains* c) { return c ? c->steps_done : PPDE_ERR_INVALID; }
 
-int ppde_chains_mark(ppde_chains* c, int slot) {
-    ARGCHK(c && (slot == 0 || slot == 1), "marker slot must be 0 or 1");
-    HIPCHK(hipSetDevice(c->device));
-    if (!c->marks[slot]) HIPCHK(hipEventCreateWithFlags(&c->marks[slot], hipEventDisableTiming));
-    HIPCHK(hipEventRecord(c->marks[slot], c->stream));
-    c->mark_set[slot] = true;
-    return PPDE_OK;
-}
-
-int ppde_chains_wait_mark(ppde_chains* c, int slot) {
-    ARGCHK(c && (slot == 0 || slot == 1), "marker slot must be 0 or 1");
-    if (!c->mark_set[slot]) return PPDE_OK;
-    HIPCHK(hipSetDevice(c->device));
-    HIPCHK(hipEventSynchronize(c->marks[slot]));
-    return PPDE_OK;
-}
-
 int ppde_chains_peek(ppde_chains* c, uint8_t* idx, float* energy, float* fitness, uint8_t* accepted, int32_t* dist) {
     ARGCHK(c && c->initialised, "chains not initialised");
     int rc = ppde_chains_sync(c);
@@ -1555,9 +1536,11 @@ int ppde_debug_read_wg_stamps(ppde_chains* c, unsigned long long* out, int words
 }
 #endif
 
-int ppde_chains_time_potts_in_situ(ppde_chains* c, int iters, float* avg_us, int* launches) {
+int ppde_chains_time_potts_in_situ(ppde_chains* c, int iters, float* avg_us, int* launches, float* avg_dispatch_us) {
     ARGCHK(c && c->initialised && avg_us && launches && iters >= 1, "bad argument");
-    ARGCHK(c->cfg.which & 1, "no Potts expert in this energy");
+    // only launch_potts and launch_chain_kernel bind events: with another expert in the energy the event in front of a Potts
+    // launch would not be its immediate predecessor's
+    ARGCHK((c->cfg.which & 7) == 1, "in-situ timing is defined for the Potts-only energy (which = 1)");
     ARGCHK(c->cfg.rng_mode == 1, "in-situ timing needs the device RNG");
     ARGCHK(c->steps_done + iters <= c->T, "run would exceed max_steps");
     ARGCHK(c->streams.size() == 1, "in-situ timing takes consecutive dispatches of ONE stream");
@@ -1573,17 +1556,23 @@ int ppde_chains_time_potts_in_situ(ppde_chains* c, int iters, float* avg_us, int
         c->steps_done += iters;
         rc = ppde_chains_sync(c);
     }
-    double tot = 0.0;
-    int cnt = 0;
-    if (rc == PPDE_OK)
-        for (size_t i = 1; i < pool.used; ++i) {                             // predecessor's end -> this Potts launch's end
-            float ms = 0.f;
-            if (pool.is_potts[i] && hipEventElapsedTime(&ms, pool.ev[i - 1], pool.ev[i]) == hipSuccess) { tot += ms; ++cnt; }
-        }
     if (rc) return rc;
+    ARGCHK(!pool.exhausted, "event pool exhausted: a launch went out untimed");
+    double tot = 0.0, tot_d = 0.0;
+    int cnt = 0, cnt_d = 0;
+    for (size_t i = 1; i < pool.used; ++i) {                             // predecessor's end -> this Potts launch's end
+        float ms = 0.f;
+        if (!pool.is_potts[i]) continue;
+        if (hipEventElapsedTime(&ms, pool.ev[i - 1], pool.ev[i]) == hipSuccess) { tot += ms; ++cnt; }
+        // the dispatch's own interval: an event bound to a kernel against itself yields that command's start -> end as the
+        // command processor stamped them (the pair rocprofv3's kernel trace reads)
+        if (hipEventElapsedTime(&ms, pool.ev[i], pool.ev[i]) == hipSuccess) { tot_d += ms; ++cnt_d; }
+    }
+    (void)hipGetLastError();
     ARGCHK(cnt > 0, "no Potts launch was timed");
     *avg_us = (float)(tot * 1000.0 / cnt);
     *launches = cnt;
+    if (avg_dispatch_us) *avg_dispatch_us = cnt_d ? (float)(tot_d * 1000.0 / cnt_d) : 0.f;
     return PPDE_OK;
 }
 

@@ -345,7 +345,15 @@ class _HipEnergy(torch.nn.Module):
         return self
 
     def _eval(self, x, which, want_grad):
-        return self.model.energy_grad(self.model.onehot_to_idx(x), which, want_grad)
+        """(e [n], fit, grad). The reference's ensemble ends in `.squeeze()` (nets.py:442), so ONE chain's fitness is a 0-dim
+        tensor there -- and with it the energy of ProteinSupervised, which IS the fitness (energy.py:154-161); the Potts /
+        transformer term keeps its [1] (energy.py:99-100). Same shapes here."""
+        e, fit, g = self.model.energy_grad(self.model.onehot_to_idx(x), which, want_grad)
+        if fit.numel() == 1:
+            fit = fit.reshape(())
+            if which == WHICH_SUPERVISED:
+                e = e.reshape(())
+        return e, fit, g
 
     def get_energy(self, x):
         """ppde/energy.py:97-101. On a plain tensor: (e, fit), no graph. On a tensor that is part of an autograd graph (the

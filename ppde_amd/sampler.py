@@ -4,7 +4,8 @@
 argparse namespace (reads ppde_pas_length, nmut_threshold, paper_results) and
     run(initial_population, num_steps, energy_function, min_pos, max_pos, oracle, log_every=50)
 returns (best_x Tensor[n,L,20], best_energy np[n], best_fitness np[n], energy_history np[T+1,n],
-fitness_history np[T+1,n], random_traj list of T+1 np[L,20]).
+fitness_history np[T+1,n], random_traj list of T+1 np[L,20]); with ONE chain fitness_history is (T+1,) as in the reference
+(ppde.py:178-183, nets.py:442; fixture run_toy24_n1.npz).
 
 Extra, optional attributes on `args` (absent in the reference, defaults keep its behaviour):
     ppde_rng            'torch' (default): path lengths / race variates / accept uniforms are drawn with torch's
@@ -14,11 +15,6 @@ Extra, optional attributes on `args` (absent in the reference, defaults keep its
     ppde_reuse_grad     True (default): energy/gradient of the current state are carried over from the previous
                         iteration instead of being recomputed (bit-identical results).
     ppde_use_graph      True (default): replay iterations from a captured hipGraph in philox mode.
-    ppde_overlap_noise  False (default): in 'torch' mode draw, upload, run and wait chunk by chunk. True: the noise of the next
-                        chunk of iterations is drawn and uploaded from pinned memory while the previous chunk runs on the GPU
-                        (same generator, same draw order: same trajectory). Measured slower at 128 chains (profiles/
-                        r04_experiments.md): an iteration's GPU work is ~20 us against ~13 ms of torch's CPU exponential_, so
-                        there is nothing to hide and the pinned staging copy costs more than it saves.
     ppde_streams        1 (default). >1: philox mode cuts the chains into this many sub-populations whose iterations run on
                         separate HIP streams and overlap on the GPU (independent chains: results unchanged).
     ppde_cpu_alias      False (default): state histories hold the pre-reset state (reference on cuda);
@@ -27,6 +23,8 @@ Extra, optional attributes on `args` (absent in the reference, defaults keep its
                         and gathered at the end (one RCCL all_gather); every rank returns the full result.
 """
 import ctypes as C
+import sys
+import time
 
 import numpy as np
 import torch
@@ -92,18 +90,6 @@ class Chains:
     def sync(self):
         _hip.check(self.lib.ppde_chains_sync(self.handle))
 
-    def run_enqueue(self, steps, U_dev, q_dev, u_dev, max_u):
-        """Enqueue `steps` iterations on caller-supplied noise ALREADY on the device and return at once: the caller keeps the
-        buffers alive and untouched until a marker recorded behind this call has been reached (mark / wait_mark)."""
-        mu = np.ascontiguousarray(np.asarray(max_u, dtype=np.int32))
-        _hip.check(self.lib.ppde_chains_run(self.handle, int(steps), _hip.ptr(U_dev), _hip.ptr(q_dev), _hip.ptr(u_dev), _hip.ptr(mu)))
-
-    def mark(self, slot):
-        _hip.check(self.lib.ppde_chains_mark(self.handle, int(slot)))
-
-    def wait_mark(self, slot):
-        _hip.check(self.lib.ppde_chains_wait_mark(self.handle, int(slot)))
-
     @property
     def steps_done(self):
         return self.lib.ppde_chains_steps_done(self.handle)
@@ -152,10 +138,11 @@ class Chains:
         return q[:, :L + 20].contiguous(), u, U
 
     def time_potts_in_situ(self, iters=200):
-        """Mean duration (us) of the Potts kernel launches inside `iters` real iterations, and how many were timed."""
-        v, k = C.c_float(), C.c_int()
-        _hip.check(self.lib.ppde_chains_time_potts_in_situ(self.handle, int(iters), C.byref(v), C.byref(k)))
-        return v.value, k.value
+        """Potts kernel launches inside `iters` real iterations (Potts-only energy): (mean us from the predecessor kernel's end
+        to the launch's end, launches timed, mean us of the dispatches' own start -> end stamps or None)."""
+        v, k, d = C.c_float(), C.c_int(), C.c_float()
+        _hip.check(self.lib.ppde_chains_time_potts_in_situ(self.handle, int(iters), C.byref(v), C.byref(k), C.byref(d)))
+        return v.value, k.value, (d.value if d.value > 0 else None)
 
     def time_experts(self, reps=100):
         """Mean duration (us) of one evaluation of all experts of the energy (current states -> proposal slot)."""
@@ -169,39 +156,9 @@ class Chains:
         return v.value
 
 
-class NoisePipe:
-    """Replay mode (`ppde_rng='torch'`) without serialising host and device: the reference draws U, q, u inside its loop with
-    torch's CPU generator (ppde.py:67, :109, :138); here chunk i + 1 is drawn (same generator, same order: noise.draw_chunk)
-    and uploaded from pinned memory on a copy stream while the kernels of chunk i run. Two host and two device buffer sets;
-    a set is rewritten only after the marker behind the kernels that read it has been reached. What remains in series is
-    torch's own `exponential_` (the ceiling of this mode: ~n * L*20 * E[max_u] variates per iteration on the host cores)."""
-
-    def __init__(self, chains, k_max, n, N, mu_max):
-        dev = chains.model.device
-        self.chains, self.k_max, self.i = chains, int(k_max), 0
-        mk = lambda shape, dt: (torch.empty(shape, dtype=dt).pin_memory(), torch.empty(shape, dtype=dt, device=dev))
-        self.U = [mk((k_max, n), torch.int32) for _ in range(2)]
-        self.q = [mk((k_max * mu_max, n, N), torch.float32) for _ in range(2)]
-        self.u = [mk((k_max, n), torch.float32) for _ in range(2)]
-        self.copy_stream = torch.cuda.Stream(dev)
-
-    def push(self, k, noise):
-        """Upload the noise of k iterations (noise.draw_chunk's tuple) and enqueue them."""
-        U, q, u, mus = noise
-        slot = self.i & 1
-        self.i += 1
-        self.chains.wait_mark(slot)                      # the kernels that read this set two chunks ago are done
-        rows = int(q.shape[0])
-        (hU, dU), (hq, dq), (hu, du) = self.U[slot], self.q[slot], self.u[slot]
-        hU[:k].copy_(U); hq[:rows].copy_(q); hu[:k].copy_(u)
-        with torch.cuda.stream(self.copy_stream):
-            dU[:k].copy_(hU[:k], non_blocking=True); dq[:rows].copy_(hq[:rows], non_blocking=True); du[:k].copy_(hu[:k], non_blocking=True)
-        self.copy_stream.synchronize()                   # (the previous chunk's kernels keep running meanwhile)
-        self.chains.run_enqueue(k, dU, dq, du, mus)
-        self.chains.mark(slot)
-
-
 class PPDE_PAS(BaseSampler):
+    _hinted = False
+
     def __init__(self, args):
         super().__init__()
         self.ppde_temp = 2  # locally balanced g(t) = sqrt(t)  (ppde.py:11)
@@ -220,9 +177,9 @@ class PPDE_PAS(BaseSampler):
         self.cpu_alias = getattr(args, "ppde_cpu_alias", False)
         self.shard = getattr(args, "ppde_shard", False)
         self.trace = getattr(args, "ppde_trace", False)
-        self.noise_bytes = getattr(args, "ppde_noise_bytes", 48 << 20)   # host->device noise is uploaded in chunks of about this size
-        self.overlap = getattr(args, "ppde_overlap_noise", False)   # True: pipeline the noise upload (NoisePipe)
+        self.noise_bytes = getattr(args, "ppde_noise_bytes", 96 << 20)   # host->device noise is uploaded in chunks of about this size
         self.last_chains = None
+        self.timings = {}       # seconds of the last run(): setup (chains + hipGraph capture), iterations, log path, collect
 
     def approximate_energy_change(self, score_change):
         return score_change / self.ppde_temp
@@ -246,6 +203,13 @@ class PPDE_PAS(BaseSampler):
         seed = (self.seed if self.seed is not None else torch.initial_seed()) & (2 ** 63 - 1)
         if comm:        # one recorded chain and one Philox key for the whole job, whatever each rank's host RNG state is
             random_idx, seed = agree_from_rank0([random_idx, seed])
+        if self.rng == "torch" and not PPDE_PAS._hinted:
+            PPDE_PAS._hinted = True
+            print("[ppde_amd] ppde_rng='torch' replays the reference's random stream: every iteration waits for torch's CPU exponential_ "
+                  "(~100 iterations/s at 128 chains). --ppde_rng philox draws on the device: hundreds of times faster, same law, "
+                  "another trajectory.", file=sys.stderr, flush=True)
+        t_begin = time.perf_counter()
+        t_log = 0.0
         chains = Chains(model, n, num_steps, self.ppde_pas_length, self.nmut_threshold, self.paper_results, min_pos,
                         max_pos, energy_function.which, 0 if self.rng == "torch" else 1, self.reuse_grad, self.cpu_alias,
                         self.trace, random_idx - lo if lo <= random_idx < hi else -1, self.use_graph, seed, lo,
@@ -258,7 +222,8 @@ class PPDE_PAS(BaseSampler):
 
         def log(i, first=False):
             pk = chains.peek()
-            x_now = torch.from_numpy(idx_to_onehot(gathered(pk["idx"]))).float().to(model.device)
+            # (the one-hot form the oracle takes is expanded on the device: n x L bytes cross PCIe instead of n x L x 20 floats)
+            x_now = model.idx_to_onehot(torch.from_numpy(np.ascontiguousarray(gathered(pk["idx"]))))
             gt = oracle(x_now).detach().cpu().numpy()
             fq = np.quantile(gathered(pk["fitness"]), [0.5, 0.9])
             gq = np.quantile(gt, [0.5, 0.9])
@@ -275,10 +240,14 @@ class PPDE_PAS(BaseSampler):
                 print(f'   # dist = {float(gathered(pk["dist"]).astype(np.float32).mean())}')
                 print('', flush=True)
 
+        chains.sync()
+        t_setup = time.perf_counter() - t_begin
+        t0 = time.perf_counter()
         log(0, first=True)
+        t_run0 = time.perf_counter()
+        t_log0 = t_run0 - t0
         N = L * 20
         done = 0
-        pipe = None
         while done < num_steps:
             # next iteration index i with i > 0 and (i+1) % log_every == 0  ->  stop after i+1 steps
             stop = min(num_steps, ((done // log_every) + 1) * log_every) if log_every > 0 else num_steps
@@ -286,23 +255,22 @@ class PPDE_PAS(BaseSampler):
                 if self.rng == "torch":
                     per_it = self.ppde_pas_length * 2 * n * N * 4 + 1
                     kmax = max(1, int(self.noise_bytes // per_it))
-                    if self.overlap and pipe is None:
-                        pipe = NoisePipe(chains, kmax, n, N, 2 * self.ppde_pas_length - 1)
                     while done < stop:
                         k = min(kmax, stop - done)
-                        noise = draw_chunk(k, n_global, N, self.ppde_pas_length, rows=(lo, hi))
-                        if pipe is not None:
-                            pipe.push(k, noise)              # returns once the chunk is enqueued; the next draw overlaps it
-                        else:
-                            chains.run(k, noise)
+                        chains.run(k, draw_chunk(k, n_global, N, self.ppde_pas_length, rows=(lo, hi)))
                         done += k
-                    chains.sync()                            # once per log_every block
                 else:
                     chains.run(stop - done)
                     done = stop
             i = done - 1
             if log_every > 0 and i > 0 and (i + 1) % log_every == 0:
+                chains.sync()
+                t0 = time.perf_counter()
                 log(i)
+                t_log += time.perf_counter() - t0
+        chains.sync()
+        t_run = time.perf_counter() - t_run0 - t_log
+        t0 = time.perf_counter()
         res = chains.collect()
         dev = initial_population.device
         best_idx = gathered(res["best_idx"])
@@ -316,4 +284,14 @@ class PPDE_PAS(BaseSampler):
         else:
             rtraj = res["random_traj"]
         random_traj = [idx_to_onehot(rtraj[t]).astype(np.float32) for t in range(rtraj.shape[0])]
-        return (best_x, gathered(res["best_energy"]), gathered(res["best_fitness"]), e_hist, f_hist, random_traj)
+        best_e, best_f = gathered(res["best_energy"]), gathered(res["best_fitness"])
+        if n_global == 1:
+            # the reference's single-chain shapes (ppde.py:178-183; the ensemble's `.squeeze()`, nets.py:442, makes one chain's
+            # fitness a scalar): fitness_history (T+1,) next to energy_history (T+1, 1); with ProteinSupervised the energy IS
+            # that scalar, so energy_history is (T+1,) too and best_energy / best_fitness are 0-dim
+            f_hist = f_hist.reshape(-1)
+            if (energy_function.which & 7) == 2:
+                e_hist, best_e, best_f = e_hist.reshape(-1), best_e.reshape(()), best_f.reshape(())
+        self.timings = {"setup_s": t_setup, "iterations_s": t_run, "log_s": t_log0 + t_log, "log_calls": 1 + (num_steps // log_every if log_every > 0 else 0),
+                        "collect_s": time.perf_counter() - t0, "graph": chains.graph_stats()}
+        return (best_x, best_e, best_f, e_hist, f_hist, random_traj)

@@ -9,7 +9,8 @@ exist here: `--sampler PPDE` with `--unsupervised_expert potts | transformer | t
 transformer-L | potts+transformer` (the ESM-2 checkpoint must be in <hub_dir>/checkpoints/) and `--energy_function supervised`; the baseline samplers and
 the MSA-Transformer scoring are out of scope.
 
-Extra flags: --ppde_rng {torch,philox}, --ppde_seed, --ppde_reuse_grad {0,1}, --ppde_shard (with torchrun), --ppde_full_grad.
+Extra flags: --ppde_rng {torch,philox}, --ppde_seed, --ppde_reuse_grad {0,1}, --ppde_shard (with torchrun), --ppde_full_grad,
+--ppde_timing.
 """
 import argparse
 import datetime
@@ -17,6 +18,7 @@ import json
 import os
 import random
 import sys
+import time
 from pathlib import Path
 
 import numpy as np
@@ -39,6 +41,7 @@ def get_sampler(args):
 
 
 def main(args):
+    t_start = time.perf_counter()
     np.random.seed(args.seed)
     random.seed(args.seed)
     torch.manual_seed(args.seed)
@@ -79,10 +82,12 @@ def main(args):
         print(f"WT protein energy: {energy_func.get_energy(initial_population)[0].mean():.3f}")
 
     sampler = get_sampler(args)
+    t_loaded = time.perf_counter()
     best_samples, best_energy, best_fitness, energy_history, fitness_history, random_traj = \
         sampler.run(initial_population, args.n_iters, energy_func, oracle.potts.index_list[0],
                     oracle.potts.index_list[-1], oracle, args.log_every)
 
+    t_sampled = time.perf_counter()
     best_oracle = oracle(best_samples).detach().cpu().numpy()
     potts_score = proteins_potts_score(best_samples, dataset).cpu().numpy()
 
@@ -105,6 +110,10 @@ def main(args):
     if not args.disable_MSA_transformer_scoring:
         print("MSA-Transformer scoring is not part of this build (needs the ESM-MSA-1b weights); skipped")
     print("done")
+    if getattr(args, "ppde_timing", False):     # wall-clock split of this command (bench.py's also.paper_protocol reads this line)
+        t_end = time.perf_counter()
+        print("[ppde timing] " + json.dumps({"total_s": t_end - t_start, "load_s": t_loaded - t_start, "sampler_s": t_sampled - t_loaded,
+                                             "score_and_save_s": t_end - t_sampled, **getattr(sampler, "timings", {})}), flush=True)
     if args.ppde_shard and torch.distributed.is_initialized():
         torch.distributed.barrier()
     return results_path
@@ -153,6 +162,7 @@ def build_parser():
     pp.add_argument("--ppde_seed", type=int, default=None)
     pp.add_argument("--ppde_reuse_grad", type=int, default=1)
     pp.add_argument("--ppde_shard", action="store_true", help="split the chains over the ranks of a torchrun launch")
+    pp.add_argument("--ppde_timing", action="store_true", help="print one '[ppde timing] {json}' line with the wall-clock split of the run")
     pp.add_argument("--ppde_full_grad", action="store_true",
                     help="transformer experts only: let lamda * d fit/dx into the proposal gradient (the reference leaves it out)")
     return parser

@@ -417,6 +417,15 @@ def run_case(root, protein, lamda, n, T, seed, pas, nmut, paper, out, store_q, u
     print("wrote", out, f"({os.path.getsize(out) / 1e3:.0f} kB)")
 
 
+def single_chain_case(root):
+    """The reference's single-chain contract (ppde.py:178-183 special-cases n_chains == 1; nets.py:442 squeezes the ensemble
+    output to a scalar): fitness_history comes back 1-D (T+1,), energy_history stays (T+1, 1), best_x [1, L, 20]."""
+    out = os.path.join(HERE, "run_toy24_n1.npz")
+    run_case(root, "TOY24", 5.0, 1, 20, 120, 2, 3, False, out, store_q=True)
+    fx = np.load(out)
+    assert fx["fitness_history"].shape == (21,) and fx["energy_history"].shape == (21, 1) and fx["best_fitness"].shape == (1,)
+
+
 def script_case(root, protein, n_chains, n_iters, seed, out):
     """The reference's own command line (BASELINE.json configs[0]): scripts/directed_evolution.py end to end."""
     import glob
@@ -461,7 +470,15 @@ def main():
             real_case(protein, lam, 6, seed, os.path.join(HERE, f"real_{protein.split('_')[0].lower()}.npz"))
         return
     if only and "realcnn" in only:
-        real_cnn_weights("PABP_YEAST_Fields2013", os.path.join(HERE, "real_pabp_cnn.npz"))
+        # the values of the shipped checkpoints of all three proteins (PABP 0.34, UBE4B 0.4, GFP 1.6 MB): UBE4B and GFP take the
+        # chunked HIP kernels, and they are the supervised expert of BASELINE configs 5 and 4
+        for protein in ("PABP_YEAST_Fields2013", "UBE4B_MOUSE_Klevit2013-nscor_log2_ratio", "GFP_AEQVI_Sarkisyan2016"):
+            real_cnn_weights(protein, os.path.join(HERE, f"real_{protein.split('_')[0].lower()}_cnn.npz"))
+        return
+    if only and "single" in only:
+        with tempfile.TemporaryDirectory() as root:
+            synthetic.write_weights_dir(root, "TOY24", potts_seed=7)
+            single_chain_case(root)
         return
     if only and "tf" in only:
         with tempfile.TemporaryDirectory() as root:
@@ -498,6 +515,7 @@ def main():
                                            ("c", 3, 2, True, 0.0), ("d", 2, 3, False, 0.0)]:
             run_case(root, "TOY24", lam, 8, 20, 100 + ord(tag), pas, nmut, paper,
                      os.path.join(HERE, f"run_toy24_{tag}.npz"), store_q=True)
+        single_chain_case(root)
         # PABP-size trajectories: noise is re-drawn from the seed by the test (q_sum guards the stream)
         k = 0
         for paper in (False, True):

@@ -143,12 +143,20 @@ def smallest_argmax_gap(cnn, rows):
     return best
 
 
-def real_pabp_cnn_states():
-    """The shipped (TRAINED) PABP supervised-CNN weights as frozen in tests/golden/real_pabp_cnn.npz: a list of three state
-    dicts with the reference's parameter names, and the SHA-256 of the files they were read from."""
-    fx = load("real_pabp_cnn.npz")
+REAL_PROTEINS = {"pabp": "PABP_YEAST_Fields2013", "ube4b": "UBE4B_MOUSE_Klevit2013-nscor_log2_ratio", "gfp": "GFP_AEQVI_Sarkisyan2016"}
+
+
+def real_cnn_states(tag):
+    """The shipped (TRAINED) supervised-CNN weights of one protein (tag: pabp / ube4b / gfp) as frozen in
+    tests/golden/real_<tag>_cnn.npz: a list of three state dicts with the reference's parameter names, and the SHA-256 of
+    the files they were read from (real_<tag>.npz holds what the REFERENCE computed from those files)."""
+    fx = load(f"real_{tag}_cnn.npz")
     names = ("encoder.weight", "encoder.bias", "embedding.0.weight", "embedding.0.bias", "decoder.weight", "decoder.bias")
     return [{k: fx[f"net{i}.{k}"] for k in names} for i in range(3)], [str(x) for x in fx["file_sha"]]
+
+
+def real_pabp_cnn_states():
+    return real_cnn_states("pabp")
 
 
 def exact_pas_kernel(energy, wt_idx, positions, pas_length, min_pos, max_pos, nmut_threshold=0):

@@ -31,7 +31,7 @@ Ptrs many(int count, size_t n) { Ptrs r; for (int i = 0; i < count; ++i) r.store
 int sequence(int L, int Lp, int win, bool with_tf, bool verbose, int tf_dim = 128, int tf_heads = 4) {
     int status = PPDE_OK;
     ppde_model* m = nullptr;
-    ppde_chains *c0 = nullptr, *c1 = nullptr, *c2 = nullptr;
+    ppde_chains *c0 = nullptr, *c1 = nullptr, *c2 = nullptr, *c3 = nullptr;
     const int n = 6, T = 30, N = L * 20;
     std::vector<uint8_t> wt(L);
     for (auto& v : wt) v = rng() % 20;
@@ -91,12 +91,7 @@ int sequence(int L, int Lp, int win, bool with_tf, bool verbose, int tf_dim = 12
         std::vector<int32_t> U((size_t)steps * n, 2), mu(steps, 3);
         for (int t = 0; t < steps; ++t) U[(size_t)t * n] = 3;
         std::vector<float> q((size_t)steps * 3 * n * N, 1.0f), u((size_t)steps * n, 0.5f);
-        TRY(ppde_chains_wait_mark(c0, 1));            // never recorded: returns at once
         TRY(ppde_chains_run(c0, steps, U.data(), q.data(), u.data(), mu.data()));
-        TRY(ppde_chains_mark(c0, 0));
-        TRY(ppde_chains_mark(c0, 0));                 // (re-recording reuses the event)
-        TRY(ppde_chains_wait_mark(c0, 0));
-        if (ppde_chains_mark(c0, 2) == PPDE_OK) { fprintf(stderr, "marker slot 2 accepted\n"); status = 97; goto done; }
         TRY(ppde_chains_sync(c0));
         std::vector<int32_t> flat((size_t)steps * 3 * n), Ut((size_t)steps * n), dist(n);
         std::vector<uint8_t> acc((size_t)steps * n), pidx((size_t)n * L), pacc(n);
@@ -126,7 +121,7 @@ int sequence(int L, int Lp, int win, bool with_tf, bool verbose, int tf_dim = 12
         float us = 0.f; int launches = 0;
         TRY(ppde_chains_time_potts_kernel(c, 3, &us));
         TRY(ppde_chains_time_experts(c, 2, &us));
-        if (cfg.which == 3 && streams == 1) TRY(ppde_chains_time_potts_in_situ(c, 2, &us, &launches));
+        if (ppde_chains_time_potts_in_situ(c, 2, &us, &launches, nullptr) == PPDE_OK) { fprintf(stderr, "in-situ timing accepted an energy with a CNN\n"); status = 97; goto done; }
         std::vector<float> qd((size_t)n * N), ud(n);
         std::vector<int32_t> Ud(n);
         TRY(ppde_chains_philox_dump(c, 0, 0, qd.data(), ud.data(), Ud.data()));
@@ -136,7 +131,19 @@ int sequence(int L, int Lp, int win, bool with_tf, bool verbose, int tf_dim = 12
         std::vector<int32_t> bs(n);
         TRY(ppde_chains_collect(c, bi.data(), be.data(), bf.data(), bs.data(), eh.data(), fh.data(), nullptr));
     }
+    {
+        // Potts-only energy: the in-situ timing hook (events bound to every dispatch of real iterations)
+        ppde_chain_config cfg{};
+        cfg.n_chains = n; cfg.max_steps = T; cfg.pas_length = 2; cfg.min_pos = win; cfg.max_pos = win + Lp - 1;
+        cfg.which = 1; cfg.rng_mode = 1; cfg.random_chain = -1; cfg.use_graph = 0; cfg.n_streams = 1; cfg.seed = 5;
+        TRY(ppde_chains_create(&c3, m, &cfg));
+        TRY(ppde_chains_init(c3, idx.data()));
+        float us = 0.f, usd = 0.f; int launches = 0;
+        TRY(ppde_chains_time_potts_in_situ(c3, 2, &us, &launches, &usd));
+        TRY(ppde_chains_time_potts_in_situ(c3, 1, &us, &launches, nullptr));
+    }
 done:
+    if (c3) ppde_chains_destroy(c3);
     if (c0) ppde_chains_destroy(c0);
     if (c1) ppde_chains_destroy(c1);
     if (c2) ppde_chains_destroy(c2);

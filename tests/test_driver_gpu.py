@@ -57,11 +57,10 @@ def test_driver_reproduces_reference_cli_run():
         assert np.abs(ld("pred_fitness_scores.npy") - fx["pred_fitness"]).max() <= 1e-5
         assert np.abs(ld("oracle_fitness_scores.npy") - fx["oracle_fitness"]).max() <= 2e-5
         assert np.abs(ld("potts_scores.npy") - fx["potts_scores"]).max() <= 3e-5
-        # the same command with the noise upload pipelined (args.ppde_overlap_noise: next chunk drawn and uploaded while the previous
-        # one runs; chunks of two iterations here, so both buffer sets and their markers turn over many times): the same bits
+        # the same command with the noise uploaded in chunks of two iterations (args.ppde_noise_bytes): the same bits
         args2 = drv.build_parser().parse_args(argv)
-        args2.ppde_reuse_grad, args2.ppde_overlap_noise, args2.ppde_noise_bytes = True, True, 2 * (2 * 2 * 16 * 1920 * 4 + 1)
-        args2.run_signature = "overlap"                                            # (its own results directory)
+        args2.ppde_reuse_grad, args2.ppde_noise_bytes = True, 2 * (2 * 2 * 16 * 1920 * 4 + 1)
+        args2.run_signature = "chunks"                                             # (its own results directory)
         with contextlib.redirect_stdout(io.StringIO()):
             out2 = drv.main(args2)
         for f in ("population.npy", "energy_history.npy", "fitness_history.npy", "energy_scores.npy"):
@@ -118,3 +117,50 @@ def test_sharded_driver_two_ranks_equals_single_process():
         d2 = glob.glob(os.path.join(res2, "TOY24", "*"))[0]
         for f in ("population.npy", "energy_history.npy", "fitness_history.npy", "energy_scores.npy", "pred_fitness_scores.npy"):
             assert np.array_equal(np.load(os.path.join(d1, f)), np.load(os.path.join(d2, f))), f
+
+
+def test_single_chain_contract_of_the_reference():
+    """One chain: the reference special-cases n_chains == 1 (ppde.py:178-183) and its ensemble squeezes a single prediction to
+    a scalar (nets.py:442), so `run` returns fitness_history (T+1,) next to energy_history (T+1, 1), best_x [1, L, 20],
+    best_energy (1,), best_fitness (1,), and get_energy's fit is 0-dim. Fixture run_toy24_n1.npz: the reference itself with one
+    chain (same seed -> same trajectory here in replay mode); with ProteinSupervised the energy is that scalar too."""
+    import argparse
+    import torch
+    from ppde_amd.energy import ProteinProductOfExperts, ProteinSupervised
+    from ppde_amd.nets import AugmentedLinearRegression
+    from ppde_amd.sampler import PPDE_PAS
+    fx = load("run_toy24_n1.npz")
+    T, seed = int(fx["T"]), int(fx["seed"])
+    with tempfile.TemporaryDirectory() as root:
+        synthetic.write_weights_dir(root, "TOY24", potts_seed=7)
+        args = argparse.Namespace(energy_lamda=float(fx["lamda"]), unsupervised_expert="potts", protein_weights=root, protein="TOY24",
+                                  n_chains=1, device="cuda:0", ppde_pas_length=int(fx["pas"]), nmut_threshold=int(fx["nmut"]),
+                                  paper_results=bool(fx["paper"]), ppde_rng="torch")
+        en, sup = ProteinProductOfExperts(args), ProteinSupervised(args)
+        alr = AugmentedLinearRegression(os.path.join(root, "TOY24"))
+        x0 = en.wt_onehot.repeat(1, 1, 1)
+        e, fit = en.get_energy(x0)
+        assert e.shape == (1,) and fit.shape == ()
+        e, fit, g = en.get_energy_and_grads(x0)
+        assert e.shape == (1,) and fit.shape == () and g.shape == x0.shape
+        assert en.get_supervised_expert(x0).shape == () and en.get_unsupervised_expert(x0).shape == (1,)
+        e, fit = sup.get_energy(x0)
+        assert e.shape == () and fit.shape == () and float(e) == float(fit)
+        np.random.seed(seed)
+        torch.manual_seed(seed)
+        with contextlib.redirect_stdout(io.StringIO()):
+            best_x, best_e, best_f, e_hist, f_hist, rtraj = PPDE_PAS(args).run(x0, T, en, int(fx["min_pos"]), int(fx["max_pos"]), alr, log_every=10)
+        assert tuple(best_x.shape) == (1, 24, 20) and best_x.device == x0.device and best_x.dtype == torch.float32
+        assert best_e.shape == (1,) and best_f.shape == (1,) and e_hist.shape == (T + 1, 1) and f_hist.shape == (T + 1,)
+        assert all(a.dtype == np.float32 for a in (best_e, best_f, e_hist, f_hist))
+        assert len(rtraj) == T + 1 and rtraj[0].shape == (24, 20)
+        assert np.array_equal(best_x.argmax(-1).cpu().numpy(), fx["best_idx"])
+        assert np.abs(e_hist - fx["energy_history"]).max() <= 2e-5 and np.abs(f_hist - fx["fitness_history"]).max() <= 5e-6
+        assert np.abs(best_e - fx["best_energy"]).max() <= 2e-5 and np.abs(best_f - fx["best_fitness"]).max() <= 5e-6
+        assert np.array_equal(np.stack([r.argmax(-1) for r in rtraj]), fx["random_traj"])
+        # ProteinSupervised, one chain: the reference's energy_history is (T+1,) and the best values are 0-dim (probed)
+        np.random.seed(seed)
+        torch.manual_seed(seed)
+        with contextlib.redirect_stdout(io.StringIO()):
+            r = PPDE_PAS(args).run(x0, 5, sup, int(fx["min_pos"]), int(fx["max_pos"]), alr, log_every=10)
+        assert tuple(r[0].shape) == (1, 24, 20) and r[1].shape == () and r[2].shape == () and r[3].shape == (6,) and r[4].shape == (6,)

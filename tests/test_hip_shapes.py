@@ -8,6 +8,7 @@ pytestmark = pytest.mark.gpu
 
 import ppde_oracle as orc
 from helpers import smallest_argmax_gap, oracle_energy
+from test_hip_parity import e_tol, observed
 from ppde_amd import synthetic
 from ppde_amd.encoding import seqs_to_idx
 
@@ -46,15 +47,20 @@ def test_energy_grad_shapes(L, Lp, i0, with_cnn):
     which = 3 if with_cnn else 1
     e, f, g = m.energy_grad(torch.as_tensor(idx).cuda(), which)
     eo, fo, go = en.energy_grad(torch.as_tensor(idx.astype(np.int64)))
-    scale = abs(float(en.potts.wt_H)) + 1.0
-    assert np.abs(e.cpu().numpy() - eo.numpy()).max() <= 2e-6 * 8 * (scale + np.abs(eo.numpy()).max()) + 1e-5 * lam
-    assert np.abs(f.cpu().numpy() - fo.numpy()).max() <= 5e-6
+    # SURVEY 8(c)'s tolerances (the oracle is pinned to the reference at the same ones): energies 5e-6 * max(1, |e|) plus the
+    # fitness term's 4e-6 * lamda * max(1, |fit|), fitness 5e-6, gradients 2e-6 * max(1, lamda) relative to the largest entry
+    tag = f"shape_L{L}_Lp{Lp}_i{i0}_{'cnn' if with_cnn else 'potts'}"
+    eo_, fo_, go_ = eo.numpy(), fo.numpy(), go.numpy()
+    assert observed(tag + ":e", np.abs(e.cpu().numpy() - eo_), e_tol(eo_) + 4e-6 * lam * np.maximum(1.0, np.abs(fo_))) <= 1.0
+    assert observed(tag + ":fit", np.abs(f.cpu().numpy() - fo_), 5e-6 * np.maximum(1.0, np.abs(fo_))) <= 1.0
     # the max over t picks a row: where two rows tie to within matmul rounding the routed gradient is implementation-defined
     # (numerics contract); a chain may differ only if the fp64 evaluation shows such a tie in it (the 300-residue
     # case holds one: network 1, feature 413, rows 200 / 168, relative gap 4.5e-7)
-    dg = np.abs(g.cpu().numpy() - go.numpy()).reshape(idx.shape[0], -1).max(1)
-    for b in np.nonzero(dg > 2e-5 * max(1.0, lam))[0]:
-        assert with_cnn and smallest_argmax_gap(cnn, idx[b:b + 1]) < 5e-6, (b, dg[b])
+    gtol = 2e-6 * max(1.0, lam) * max(1.0, float(np.abs(go_).max()))
+    dg = np.abs(g.cpu().numpy() - go_).reshape(idx.shape[0], -1).max(1)
+    tied = [b for b in np.nonzero(dg > gtol)[0] if with_cnn and smallest_argmax_gap(cnn, idx[b:b + 1]) < 5e-6]
+    keep = np.setdiff1d(np.arange(idx.shape[0]), tied)
+    assert observed(tag + ":grad", dg[keep], gtol) <= 1.0, (dg, gtol)
 
 
 @pytest.mark.parametrize("L,K", [(50, 3), (150, 3), (278, 3), (120, 7)])
@@ -66,8 +72,8 @@ def test_cnn_other_kernel_size(L, K):
     idx = np.random.default_rng(0).integers(0, 20, (6, L)).astype(np.uint8)
     e, f, g = m.energy_grad(torch.as_tensor(idx).cuda(), 2)
     fo, go = en.cnn.fit_grad(torch.as_tensor(idx.astype(np.int64)))
-    assert np.abs(f.cpu().numpy() - fo.numpy()).max() <= 5e-6
-    assert np.abs(g.cpu().numpy() - go.numpy()).max() <= 5e-6
+    assert observed(f"cnn_L{L}_K{K}:fit", np.abs(f.cpu().numpy() - fo.numpy()), 5e-6 * np.maximum(1.0, np.abs(fo.numpy()))) <= 1.0
+    assert observed(f"cnn_L{L}_K{K}:grad", np.abs(g.cpu().numpy() - go.numpy()).max(), 2e-6 * max(1.0, float(go.abs().max()))) <= 1.0
 
 
 @pytest.mark.parametrize("L,Lp,i0,n,with_cnn", [(237, 237, 0, 24, False), (237, 237, 0, 6, True), (104, 76, 23, 20, True),

@@ -223,6 +223,17 @@ def test_bench_launches_its_own_ranks(monkeypatch):
     assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
     assert cmd[-6:] == ["--gpus", "4", "--steps", "20", "--warmup", "5"] and cmd[-7].endswith("bench.py")
     assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    # BASELINE configs[3] as the reference would run it: GFP, Potts + supervised CNN, 8 ranks; --lamda defaults to the README's 15
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--protein", "GFP", "--workload", "potts+cnn", "--gpus", "8"])
+    with pytest.raises(SystemExit) as ex:
+        bench.main()
+    assert ex.value.code == 0 and "--nproc-per-node=8" in seen["cmd"]
+    assert seen["cmd"][-6:] == ["--protein", "GFP", "--workload", "potts+cnn", "--gpus", "8"]
+    for protein, lam in (("PABP", 5.0), ("UBE4B", 0.5), ("GFP", 15.0)):
+        monkeypatch.setattr(sys, "argv", ["bench.py", "--protein", protein, "--workload", "potts+cnn"])
+        assert bench.resolve_defaults(bench.parse()).lamda == lam
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--protein", "GFP", "--workload", "potts+cnn", "--lamda", "2.5"])
+    assert bench.resolve_defaults(bench.parse()).lamda == 2.5
     monkeypatch.undo()                                               # (bench.subprocess IS this module's subprocess)
     # as a rank: WORLD_SIZE must equal --gpus
     r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2"], capture_output=True, text=True,
