@@ -27,6 +27,7 @@ struct CnnNet {
     const float* Wf;     // [CP][JP]      conv weights as [channel] x [kappa*20 + c] (B operand of the backward)
     const uint4* WeB;    // [FP/16][CP/32][3][64]  We as MFMA B fragments of its exact three-term bf16 split (split-precision path)
     const uint4* WfB;    // [JP/16][CP/32][3][64]  Wf likewise
+    const uint4* WcA;    // [CP/16][KT][3][64]     conv table as MFMA A fragments of its split: one k step of 32 (20 letters) per tap
     float bd;
 };
 
@@ -131,13 +132,88 @@ __host__ __device__ inline size_t cnn_bf_lds_bytes(int T, int CP, int FP, int J,
     const size_t rows = cnn_rows(T);
     const size_t bits = rows * ((CP + 31) / 32) * 4;        // ReLU gate of h1
     const size_t route = (rows + 4 + (size_t)FP) * 4;       // row offsets and the row-sorted list of routed features
-    return cnn_bf_region_bytes(T, CP, J) + bits + route + (size_t)FP * 8 + 64 + ((L + CNN_MAX_K + 15) & ~15);
+    const size_t upto_x = cnn_bf_region_bytes(T, CP, J) + bits + route + (size_t)FP * 8 + 64 + ((L + CNN_MAX_K + 15) & ~15);
+    return ((upto_x + 15) & ~(size_t)15) + (size_t)(rows + CNN_MAX_K) * 64;   // + the one-hot fragments per position (cnn_conv_x_bytes)
 }
 
 // bf_strips_c: the form the 512-thread kernels (k_cnn, k_experts: 128 registers, four waves per SIMD hide the latencies) use.
 // One wave: for its strips ct = ct0, ct0 + ct_step, ... < ct_end:  acc[RT] = A [rows x 32 KS] (split planes in LDS) x B strip
 // (split fragments from L2: [ct][ks][term][lane] 16 bytes), then epi(i, ct, acc) with i = the wave's i-th strip. Three fragment
 // buffers in rotation over the sequence of (strip, k step) pairs: while one multiplies, the next two are in flight.
+#ifndef CNN_A_PREFETCH
+#define CNN_A_PREFETCH 1             // 0: the r04 form (a row tile's A fragments read right in front of its MFMAs), for A/B builds
+#endif
+#if CNN_A_PREFETCH
+template <int RT, typename Epi>
+__device__ __forceinline__ void bf_strips_c(const unsigned char* planes, const uint4* Bfrag, const int KS, const int ct0,
+                                          const int ct_step, const int ct_end, Epi&& epi) {
+    const int lane = threadIdx.x & 63, row = lane & 15, kq = lane >> 4;
+    const int nstr = ct0 < ct_end ? (ct_end - ct0 + ct_step - 1) / ct_step : 0;
+    const int Q = nstr * KS;
+    if (Q == 0) return;
+    const uint4* bp = Bfrag + lane;
+    const int lo0 = (kq * 16 + (row ^ kq)) << 4, lo1 = (kq * 16 + (row ^ kq ^ 4)) << 4;
+    uint4 bx[3], by[3], bz[3];
+    f32x4 acc[RT];
+    // The A fragments of row tile rt + 1 (at a block's last row tile: of the NEXT block's first) are read from LDS while row tile
+    // rt multiplies: two register sets in alternation. Up to r04 a row tile's three reads were issued right in front of its six
+    // MFMAs and waited for there -- 8-10 exposed LDS round trips per block of 36 MFMAs (r05_experiments.md).
+    uint4 aa[2][3];
+    auto a_base = [&](int ks) { return planes + ks * (RT * 3072) + ((ks & 1) ? lo1 : lo0); };
+    auto read_a = [&](uint4 (&a)[3], const unsigned char* ap, int rt) {
+        a[0] = *(const uint4*)(ap + rt * 3072); a[1] = *(const uint4*)(ap + rt * 3072 + 1024); a[2] = *(const uint4*)(ap + rt * 3072 + 2048);
+    };
+    auto fill = [&](uint4 (&b)[3], int q) {
+        q = min(q, Q - 1);
+        const int i = q / KS, ks = q - i * KS;
+        const size_t at = ((size_t)(ct0 + i * ct_step) * KS + ks) * 192;
+        b[0] = bp[at]; b[1] = bp[at + 64]; b[2] = bp[at + 128];
+    };
+    auto mult = [&](const uint4 (&b)[3], const int q) {
+        const int i = q / KS, ks = q - i * KS;
+        if (ks == 0) {
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) acc[rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+        const bf16x8 b1 = __builtin_bit_cast(bf16x8, b[0]), b2 = __builtin_bit_cast(bf16x8, b[1]), b3 = __builtin_bit_cast(bf16x8, b[2]);
+        const unsigned char* ap = a_base(ks);
+        const unsigned char* ap_next = a_base(ks + 1 == KS ? 0 : ks + 1);
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+            if (rt + 1 < RT) read_a(aa[(rt + 1) & 1], ap, rt + 1);
+            else if (q + 1 < Q) read_a(aa[(rt + 1) & 1], ap_next, 0);
+            const bf16x8 a1 = __builtin_bit_cast(bf16x8, aa[rt & 1][0]), a2 = __builtin_bit_cast(bf16x8, aa[rt & 1][1]),
+                         a3 = __builtin_bit_cast(bf16x8, aa[rt & 1][2]);
+            f32x4 c = acc[rt];                                   // (small terms first)
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a3, b1, c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b3, c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2, b2, c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2, b1, c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b2, c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b1, c, 0, 0, 0);
+            acc[rt] = c;
+        }
+        if constexpr (RT & 1) {                                  // (odd tile count: the next block's first set sits in aa[1])
+            aa[0][0] = aa[1][0]; aa[0][1] = aa[1][1]; aa[0][2] = aa[1][2];
+        }
+        if (ks == KS - 1) epi(i, ct0 + i * ct_step, acc);
+    };
+    fill(bx, 0); fill(by, 1); fill(bz, 2);
+    read_a(aa[0], a_base(0), 0);
+    for (int q = 0; q < Q; q += 3) {
+        mult(bx, q);
+        if (q + 3 < Q) fill(bx, q + 3);
+        if (q + 1 < Q) {
+            mult(by, q + 1);
+            if (q + 4 < Q) fill(by, q + 4);
+        }
+        if (q + 2 < Q) {
+            mult(bz, q + 2);
+            if (q + 5 < Q) fill(bz, q + 5);
+        }
+    }
+}
+#else
 template <int RT, typename Epi>
 __device__ __forceinline__ void bf_strips_c(const unsigned char* planes, const uint4* Bfrag, const int KS, const int ct0,
                                           const int ct_step, const int ct_end, Epi&& epi) {
@@ -193,6 +269,7 @@ __device__ __forceinline__ void bf_strips_c(const unsigned char* planes, const u
         }
     }
 }
+#endif
 
 // bf_strips: the form of the 256-thread chunk kernels (two or three workgroups per CU, 256 registers). The same product as
 // bf_strips_c, block for block and term for term (same bits), with three differences that r04's counters asked for
@@ -343,10 +420,20 @@ __device__ __forceinline__ void mfma_strip(f32x4 (&acc)[RT], const float* A, int
 //       coming straight from L2 with a dozen loads in flight per thread, and applies the gate.
 // sM[f] = coefficient (0: not routed), sTs[f] = absolute arg-max row. sB (rows x ceil(FP/32) words) must be ZERO on
 // entry and may alias sD (it is dead before sD is written); rows <= 128. Ends with a barrier.
+// CNN_ROUTE_TAIL: 1 (default) = list entries of a row beyond the first four are fetched one by one; n > 1 = in batches of n with
+// all loads of a batch in flight before the first use (same sums, same order, same bits). Batches were built because rows collect
+// 7-9 routed features with seeded weights and 20-40 with the trained networks, and measured SLOWER, with either kind of weights
+// (k_experts 28.5 / 28.7 / 29.3 us for 1 / 4 / 8, A/B on one box: profiles/r05_experiments.md): the phase is bound by the
+// instructions it issues, not by that chain of L2 latencies.
+#ifndef CNN_ROUTE_TAIL
+#define CNN_ROUTE_TAIL 1
+#endif
+
 template <int NT, bool BF = false>
 __device__ __forceinline__ void cnn_route_rows(const CnnNet& net, const int rows, const int r0, const int CP, const int AS,
                                                const int FP, const int BW, float* sD, uint32_t* sB, const uint32_t* sG,
-                                               const float* sM, const int* sTs, int* sStart, int* sList, int* sTot) {
+                                               const float* sM, const int* sTs, int* sStart, int* sList, int* sTot,
+                                               [[maybe_unused]] unsigned long long* dbg = nullptr, [[maybe_unused]] const bool stamp = false) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int BWF = (FP + 31) / 32;
     for (int f = tid; f < FP; f += NT) {
@@ -354,6 +441,7 @@ __device__ __forceinline__ void cnn_route_rows(const CnnNet& net, const int rows
         if (sM[f] != 0.f && t >= 0 && t < rows) atomicOr(&sB[t * BWF + (f >> 5)], 1u << (f & 31));
     }
     __syncthreads();
+    PPDE_STAMP(dbg, 60, stamp);
     // row counts and offsets: an exclusive scan inside each group of 64 rows (waves 0 and 1), then the second
     // group is shifted by the first group's total
     if (tid < 128) {
@@ -373,6 +461,7 @@ __device__ __forceinline__ void cnn_route_rows(const CnnNet& net, const int rows
     __syncthreads();
     if (tid >= 64 && tid <= rows) sStart[tid] += sTot[0];
     __syncthreads();
+    PPDE_STAMP(dbg, 61, stamp);
     for (int f = tid; f < FP; f += NT) {
         const int t = sTs[f] - r0, w = f >> 5;
         if (sM[f] == 0.f || t < 0 || t >= rows) continue;
@@ -381,6 +470,7 @@ __device__ __forceinline__ void cnn_route_rows(const CnnNet& net, const int rows
         sList[sStart[t] + r] = f;
     }
     __syncthreads();
+    PPDE_STAMP(dbg, 62, stamp);
     {
         // work item = (row, 4 channels); three items per round, the first four list entries of each fetched
         // unconditionally (clamped index, zero coefficient past the row's end): 12 independent L2 loads in flight
@@ -415,12 +505,29 @@ __device__ __forceinline__ void cnn_route_rows(const CnnNet& net, const int rows
                     acc.x += c[j][q] * v[j][q].x; acc.y += c[j][q] * v[j][q].y;
                     acc.z += c[j][q] * v[j][q].z; acc.w += c[j][q] * v[j][q].w;
                 }
+#if CNN_ROUTE_TAIL == 1
                 for (int q = 4; q < kk[j]; ++q) {                    // rows with more than four routed features
                     const int f = sList[rs[j] + q];
                     const float cq = sM[f];
                     const float4 w = We4[(size_t)f * G4 + c4[j]];
                     acc.x += cq * w.x; acc.y += cq * w.y; acc.z += cq * w.z; acc.w += cq * w.w;
                 }
+#else
+                for (int q0 = 4; q0 < kk[j]; q0 += CNN_ROUTE_TAIL) {  // rows with more than four routed features: batches, in order
+                    float4 w[CNN_ROUTE_TAIL];
+                    float cq[CNN_ROUTE_TAIL];
+#pragma unroll
+                    for (int u = 0; u < CNN_ROUTE_TAIL; ++u) {
+                        const int f = min((unsigned)sList[min(rs[j] + q0 + u, last)], (unsigned)(FP - 1));
+                        w[u] = We4[(size_t)f * G4 + c4[j]];
+                        cq[u] = q0 + u < kk[j] ? sM[f] : 0.f;
+                    }
+#pragma unroll
+                    for (int u = 0; u < CNN_ROUTE_TAIL; ++u) {
+                        acc.x += cq[u] * w[u].x; acc.y += cq[u] * w[u].y; acc.z += cq[u] * w[u].z; acc.w += cq[u] * w[u].w;
+                    }
+                }
+#endif
                 const uint32_t nib = (sG[t[j] * BW + (c4[j] >> 3)] >> (4 * (c4[j] & 7))) & 0xFu;   // gate by relu'(pre1)
                 acc.x = (nib & 1u) ? acc.x : 0.f; acc.y = (nib & 2u) ? acc.y : 0.f;
                 acc.z = (nib & 4u) ? acc.z : 0.f; acc.w = (nib & 8u) ? acc.w : 0.f;
@@ -435,6 +542,7 @@ __device__ __forceinline__ void cnn_route_rows(const CnnNet& net, const int rows
             }
         }
     }
+    PPDE_STAMP(dbg, 63, stamp);
     __syncthreads();
 }
 
@@ -656,6 +764,74 @@ __device__ __forceinline__ void cnn_body(const CnnArgs& a_, const int bx, const 
     PPDE_WG_STAMP(a.dbg, wg_lin, 3);
 }
 
+// The convolution of a ONE-HOT input on the matrix pipe (split-precision kernels, five taps).
+//   pre1[t][o] = bc[o] + sum_kappa Wc[o][a_{t+kappa}][kappa]  =  bc[o] + sum_k A[o][k] X[k][t],   k = 32 kappa + letter,
+// A = the convolution table (three exact bf16 terms, MFMA A fragments prepared at upload: net.WcA), X[k][t] = [a_{t+kappa} == letter]
+// -- exact in bf16, so each term is ONE v_mfma_f32_16x16x32_bf16 with no cross terms: 15 per 16 channels x 16 rows, every product
+// 1 * w exact, accumulated in fp32 from the bias in the order tap 0..4, terms small to large. A wave owns a 16-channel tile (or, with
+// fewer tiles than waves, a range of its row tiles): the tile's 15 table fragments (15 KB) are loaded ONCE, before the letters have
+// even landed, and stay in registers while the wave walks its row tiles: ~100 KB per network and workgroup from L2 against 184 KB
+// of 16-byte gathers, and 90 matrix instructions per tile against ~100 vector instructions per (row, 4 channels) piece. The
+// one-hot operand depends on the POSITION only (X fragment of row t, tap kappa = the letter at t + kappa): it is written to LDS once
+// per position and 8-letter group next to the staged letters (sX[p][kq], 16 bytes with at most one bf16 1.0), so a fragment is
+// one ds_read_b128 at an immediate offset. In this orientation a lane's accumulator is (row t, 4 consecutive channels): the piece
+// bf_store4 splits into the three planes, with bias, ReLU and gate bits as in the gather form.
+#ifndef CNN_CONV_MFMA
+#define CNN_CONV_MFMA 1
+#endif
+__host__ __device__ inline size_t cnn_conv_x_bytes(int T) { return (size_t)(cnn_rows(T) + CNN_MAX_K) * 64; }
+// the lane's share of the one-hot fragments of position p: letters 8 kq .. 8 kq + 7
+__device__ __forceinline__ uint4 conv_x_fragment(int letter, int kq) {
+    const unsigned d = (unsigned)(letter - 8 * kq);
+    const uint32_t one = 0x3F80u << (16 * (d & 1u));                // bf16 1.0 in the half the letter selects
+    const unsigned sel = d < 8u ? (d >> 1) : 4u;
+    return make_uint4(sel == 0u ? one : 0u, sel == 1u ? one : 0u, sel == 2u ? one : 0u, sel == 3u ? one : 0u);
+}
+// which (tile, row tiles [rt_lo, rt_hi)) a wave starts with; further tiles follow in steps of NW (only when NTILE > NW)
+struct ConvUnit { int tile, rt_lo, rt_hi; };
+__device__ __forceinline__ ConvUnit conv_unit(int wave, int NW, int NTILE, int RT) {
+    if (NTILE >= NW) return ConvUnit{wave, 0, RT};
+    const int q = NW / NTILE, r = NW - q * NTILE;                    // tiles 0 .. r-1 are shared by q + 1 waves, the others by q
+    int tile, sub, nsub;
+    if (wave < r * (q + 1)) { tile = wave / (q + 1); sub = wave - tile * (q + 1); nsub = q + 1; }
+    else { const int w2 = wave - r * (q + 1); tile = r + w2 / q; sub = w2 - (w2 / q) * q; nsub = q; }
+    return ConvUnit{tile, sub * RT / nsub, (sub + 1) * RT / nsub};
+}
+template <int KT>
+__device__ __forceinline__ void conv_load_a(uint4 (&af)[KT][3], const CnnNet& net, int tile) {
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int kp = 0; kp < KT; ++kp)
+#pragma unroll
+        for (int tm = 0; tm < 3; ++tm) af[kp][tm] = net.WcA[(((size_t)tile * KT + kp) * 3 + tm) * 64 + lane];
+}
+template <int RT, int KT>
+__device__ __forceinline__ void conv_tile_rows(const uint4 (&af)[KT][3], const CnnNet& net, const uint4* sX, unsigned char* sP, uint32_t* sG,
+                                               const int tile, const int rt_lo, const int rt_hi, const int T, const int BW) {
+    const int lane = threadIdx.x & 63, n = lane & 15, kq = lane >> 4;
+    const int g4 = tile * 4 + kq;                                    // the lane's 4 channels: 4 g4 .. 4 g4 + 3
+    const float4 bias4 = *(const float4*)(net.bc + 4 * g4);
+    for (int rt = rt_lo; rt < rt_hi; ++rt) {
+        const int t = rt * 16 + n;
+        const uint4* xp = sX + (size_t)t * 4 + kq;                   // fragment of tap kp: position t + kp
+        f32x4 acc = {bias4.x, bias4.y, bias4.z, bias4.w};
+#pragma unroll
+        for (int kp = 0; kp < KT; ++kp) {
+            const bf16x8 xb = __builtin_bit_cast(bf16x8, xp[4 * kp]);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af[kp][2]), xb, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af[kp][1]), xb, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af[kp][0]), xb, acc, 0, 0, 0);
+        }
+        const bool live = t < T;
+        float4 x;
+        x.x = live ? fmaxf(acc[0], 0.f) : 0.f; x.y = live ? fmaxf(acc[1], 0.f) : 0.f;
+        x.z = live ? fmaxf(acc[2], 0.f) : 0.f; x.w = live ? fmaxf(acc[3], 0.f) : 0.f;
+        const uint32_t nib = (x.x > 0.f ? 1u : 0u) | (x.y > 0.f ? 2u : 0u) | (x.z > 0.f ? 4u : 0u) | (x.w > 0.f ? 8u : 0u);
+        bf_store4(sP, RT, t, g4, x);
+        if (nib) atomicOr(&sG[t * BW + (g4 >> 3)], nib << (4 * (g4 & 7)));
+    }
+}
+
 // The same workgroup with both dense contractions on the bf16 matrix pipe (split-precision, see bf_strips): h1 and the routed
 // gradient live in LDS as three-plane bf16 images in MFMA fragment order (one region: h1 planes, then the route bitmap, then the
 // routed gradient's planes, then O); a wave owns whole column strips (all row tiles: every B fragment is fetched once per
@@ -695,8 +871,11 @@ __device__ __forceinline__ void cnn_body_bf(const CnnArgs& a_, const int bx, con
     int* sTs = (int*)(sM + FP);
     float* red = (float*)(sTs + FP);
     uint8_t* sSt = (uint8_t*)(red + 16);
+    // one-hot MFMA fragments per position (five-tap convolution on the matrix pipe): [rows + CNN_MAX_K][4] x 16 bytes
+    uint4* sX = (uint4*)(smem_raw + (((size_t)((unsigned char*)sSt - smem_raw) + ((g.L + CNN_MAX_K + 15) & ~15) + 15) & ~(size_t)15));
     int phase = 0;
     const int slot = a.slot;
+    constexpr bool CONV_MFMA = KT == 5 && CNN_CONV_MFMA;
 
     [[maybe_unused]] const bool first_wg = bx == 0 && ni == 0;
     [[maybe_unused]] const bool stamp = first_wg || (bx == n_bx - 1 && ni == n_ni - 1);
@@ -708,6 +887,18 @@ __device__ __forceinline__ void cnn_body_bf(const CnnArgs& a_, const int bx, con
 #pragma unroll
     for (int k = 0; k < 2; ++k) wdf[k] = net.wd[min(tid + NT * k, FP - 1)];
     for (int l = tid; l < g.L + CNN_MAX_K; l += NT) sSt[l] = l < g.L ? min((int)a.idx[(size_t)b * g.Ls + g.sh + l], 19) : 0;
+    // the convolution's operands: the wave's table fragments (independent of the state: in flight while the letters land) and the
+    // one-hot fragment of every position p < rows + KT - 1 (positions past the sequence: letter 0, their rows are dead)
+    [[maybe_unused]] uint4 af[KT][3];
+    [[maybe_unused]] const ConvUnit cu = conv_unit(wave, NT / 64, CP / 16, RT);
+    if constexpr (CONV_MFMA) {
+        if (cu.tile < CP / 16) conv_load_a<KT>(af, net, cu.tile);
+        for (int i = tid; i < (rows + KT - 1) * 4; i += NT) {
+            const int p = i >> 2;
+            const int letter = p < g.L ? min((int)a.idx[(size_t)b * g.Ls + g.sh + p], 19) : 0;
+            sX[i] = conv_x_fragment(letter, i & 3);
+        }
+    }
     for (int w = tid; w < rows * BW; w += NT) sG[w] = 0u;
     // the second layer's bias waits in sM[f] for the strip epilogue, which replaces it by the feature's maximum (a global load
     // inside bf_strips' epilogue would drain the fragment loads in flight); features of the other half: zero, as before
@@ -719,8 +910,15 @@ __device__ __forceinline__ void cnn_body_bf(const CnnArgs& a_, const int bx, con
     __syncthreads();
     PPDE_STAMP(a.dbg, sb + 1, stamp);
 
-    // ---- h1 = relu(conv) as in cnn_body; every (row, 4 channels) piece is split and stored into the three planes
-    {
+    // ---- h1 = relu(conv). Five taps: on the matrix pipe (conv_onehot_mfma below); other tap counts: the table gather of cnn_body.
+    //      Either way every (row, 4 channels) piece is split and stored into the three planes.
+    if constexpr (CONV_MFMA) {
+        if (cu.tile < CP / 16) conv_tile_rows<RT, KT>(af, net, sX, sP, sG, cu.tile, cu.rt_lo, cu.rt_hi, T, BW);
+        for (int tile = cu.tile + NT / 64; tile < CP / 16; tile += NT / 64) {      // (more tiles than waves: each a whole tile)
+            conv_load_a<KT>(af, net, tile);
+            conv_tile_rows<RT, KT>(af, net, sX, sP, sG, tile, 0, RT, T, BW);
+        }
+    } else {
         const int G4 = CP / 4;
         const int RPR = NT / G4;
         const int g4 = tid % G4, tr = tid / G4;
@@ -807,7 +1005,7 @@ __device__ __forceinline__ void cnn_body_bf(const CnnArgs& a_, const int bx, con
     if (!a_shape.want_grad) return;
 
     // ---- route + gate (cnn_route_rows) -> the routed gradient's split planes
-    cnn_route_rows<NT, true>(net, rows, 0, CP, 0, FP, BW, (float*)sP, sB, sG, sM, sTs, sStart, sList, (int*)(red + 12));
+    cnn_route_rows<NT, true>(net, rows, 0, CP, 0, FP, BW, (float*)sP, sB, sG, sM, sTs, sStart, sList, (int*)(red + 12), a.dbg, first_wg);
     PPDE_STAMP(a.dbg, sb + 5, stamp);
     PPDE_STAMP(a.dbg, sb + 7, stamp);
     PPDE_WG_STAMP(a.dbg, wg_lin, 2);
@@ -871,7 +1069,8 @@ __device__ __forceinline__ void cnn_body_bf(const CnnArgs& a_, const int bx, con
 
 // BF: the split-precision body (bf16 matrix pipe) instead of the exact-fp32 MFMA one
 template <int RT, int KT, int NT = CNN_NT, bool BF = false>
-__global__ __launch_bounds__(NT, 2) void k_cnn(CnnArgs a) {
+// (two 512-thread workgroups share a CU up to six row tiles: four waves per SIMD, i.e. at most 128 registers)
+__global__ __launch_bounds__(NT, (RT <= 6 && NT == 512 && KT == 5) ? 4 : 2) void k_cnn(CnnArgs a) {
     warm_kernargs<sizeof(CnnArgs)>();
     extern __shared__ unsigned char smem_raw[];
     if constexpr (BF) cnn_body_bf<RT, KT, NT>(a, blockIdx.x, blockIdx.y, gridDim.x, gridDim.y, smem_raw);
@@ -1085,7 +1284,7 @@ __global__ __launch_bounds__(NT, 2) void k_cnn_bwd_chunk(CnnChunkArgs ca) {
     float* red = (float*)(sList + FP);                                // 16 floats + 1 int
     int* sCnt = (int*)(red + 16);
     int* sStart = sCnt + 4;                                           // [rows + 1] list offsets of the window's rows (+ 3 pad)
-    int phase = 0;
+    [[maybe_unused]] int phase = 0;
     const int PO = cnn_bwd_out_per_chunk(KT);
     const int p0 = c * PO, r0 = p0 - (KT - 1);                        // window rows r0 .. r0 + rows
     const int slot = a.slot;

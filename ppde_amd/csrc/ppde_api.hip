@@ -420,18 +420,47 @@ struct ExpertsArgs {
 };
 // PABP: the CNN's shape pinned to the PABP_YEAST networks' (L = 96: 96 channels, 192 features, 5 taps, three networks in four
 // output rows, gradients wanted), so that every trip count of cnn_body is a compile-time constant (as pin_config in pas.h)
+// Block order of the fused launch. 1 (default): the two HALF units of every chain first, the whole units second -- a CU's first
+// workgroup is the older one and wins the issue arbitration (priority, then age: MI355X_MICROARCH.md), so the unit with less work
+// finishes early and the whole unit has the CU to itself for its remainder (k_experts 28.7 -> 28.1 us, A/B on one box; with the
+// whole units first the half unit crawls beside them and finishes last). 0: units in part order; 2 / 3: the Potts tiles in front
+// (measured slower). Outputs do not depend on it. PPDE_EXPERTS_PRIO: s_setprio experiments, none kept (r05_experiments.md).
+#ifndef PPDE_EXPERTS_ORDER
+#define PPDE_EXPERTS_ORDER 1
+#endif
+#ifndef PPDE_EXPERTS_PRIO
+#define PPDE_EXPERTS_PRIO 0
+#endif
 template <int RT, int NG, bool PABP = false, bool BF = false>
-__global__ __launch_bounds__(CNN_NT, 2) void k_experts(ExpertsArgs a) {
+__global__ __launch_bounds__(CNN_NT, RT <= 6 ? 4 : 2) void k_experts(ExpertsArgs a) {
     warm_kernargs<sizeof(ExpertsArgs)>();
 
     extern __shared__ float4 smem_experts[];
-    const int w = blockIdx.x, n_cnn = a.cnn_bx * a.cnn_ni;
+    const int n_cnn = a.cnn_bx * a.cnn_ni;
+#if PPDE_EXPERTS_ORDER >= 2                      // (tuning builds: the Potts tiles first in block order)
+    const int w = (int)blockIdx.x < a.potts_items ? n_cnn + (int)blockIdx.x : (int)blockIdx.x - a.potts_items;
+#else
+    const int w = blockIdx.x;
+#endif
     if (w < n_cnn) {
-        const int ni = w / a.cnn_bx;
-        if constexpr (BF) cnn_body_bf<RT, 5, CNN_NT, PABP>(a.c, w - ni * a.cnn_bx, ni, a.cnn_bx, a.cnn_ni, (unsigned char*)smem_experts);
-        else cnn_body<RT, 5, CNN_NT, PABP>(a.c, w - ni * a.cnn_bx, ni, a.cnn_bx, a.cnn_ni, (unsigned char*)smem_experts);
+        const int nw = w / a.cnn_bx;
+#if PPDE_EXPERTS_ORDER == 1 || PPDE_EXPERTS_ORDER == 3   // (tuning builds: the half units first in block order)
+        const int ni = a.cnn_ni == 4 ? ((nw + 2) & 3) : nw;
+#else
+        const int ni = nw;
+#endif
+#if PPDE_EXPERTS_PRIO == 1                       // (tuning builds: the workgroups dispatched second get the higher issue priority)
+        if (2 * w >= n_cnn) __builtin_amdgcn_s_setprio(1);
+#elif PPDE_EXPERTS_PRIO == 2
+        if (2 * w < n_cnn) __builtin_amdgcn_s_setprio(1);
+#endif
+        if constexpr (BF) cnn_body_bf<RT, 5, CNN_NT, PABP>(a.c, w - nw * a.cnn_bx, ni, a.cnn_bx, a.cnn_ni, (unsigned char*)smem_experts);
+        else cnn_body<RT, 5, CNN_NT, PABP>(a.c, w - nw * a.cnn_bx, ni, a.cnn_bx, a.cnn_ni, (unsigned char*)smem_experts);
     } else {
         if (threadIdx.x >= 256) return;          // a Potts tile is the work of four waves (the barrier counts live waves only)
+#if PPDE_EXPERTS_PRIO == 3
+        __builtin_amdgcn_s_setprio(2);
+#endif
         const int v = xcd_contiguous(w - n_cnn, a.potts_items);
         potts_body<NG, false, 2, PABP ? 5 : 0>(a.p, v / a.potts_nby, v % a.potts_nby, smem_experts);
     }
@@ -862,6 +891,28 @@ int ppde_model_set_cnn(ppde_model* m, int n_nets, int C, int K, int F, const flo
         };
         if ((rc = frags(WeT, FP, FP, &nt.WeB))) return rc;
         if ((rc = frags(Wf, JP, JP, &nt.WfB))) return rc;
+        {
+            // the convolution table as MFMA A fragments of its three-term bf16 split (cnn.h conv_onehot_mfma: the convolution of a
+            // one-hot input as [channels x (tap, letter)] x [(tap, letter) x rows], one k step of 32 per tap, letters 20..31 zero):
+            // [channel tile of 16][tap][term][lane] x 8 bf16, lane = (channel ct * 16 + (l & 15), letters 8 (l >> 4) + j)
+            const int NT16 = CP / 16;
+            std::vector<uint16_t> fr((size_t)NT16 * KT * 3 * 64 * 8, 0);
+            for (int ct = 0; ct < NT16; ++ct)
+                for (int kp = 0; kp < K; ++kp)
+                    for (int l = 0; l < 64; ++l)
+                        for (int j = 0; j < 8; ++j) {
+                            const int o = ct * 16 + (l & 15), c = 8 * (l >> 4) + j;
+                            if (o >= C || c >= 20) continue;
+                            uint16_t t3[3];
+                            bf16_split3_host(conv_w[k][((size_t)o * 20 + c) * K + kp], t3);
+                            for (int t = 0; t < 3; ++t) fr[((((size_t)ct * KT + kp) * 3 + t) * 64 + l) * 8 + j] = t3[t];
+                        }
+            uint16_t* d = nullptr;
+            HIPCHK(dalloc(&d, fr.size()));
+            HIPCHK(hipMemcpy(d, fr.data(), fr.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+            m->cnn_allocs.push_back(d);
+            nt.WcA = (const uint4*)d;
+        }
         nt.bd = dec_b[k][0];
     }
     free_scratch(m);

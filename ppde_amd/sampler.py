@@ -283,7 +283,7 @@ class PPDE_PAS(BaseSampler):
             rtraj = broadcast_from(rt, owner).numpy()
         else:
             rtraj = res["random_traj"]
-        random_traj = [idx_to_onehot(rtraj[t]).astype(np.float32) for t in range(rtraj.shape[0])]
+        random_traj = list(idx_to_onehot(rtraj, dtype=np.float32))     # T + 1 arrays [L, 20] (views of one expansion)
         best_e, best_f = gathered(res["best_energy"]), gathered(res["best_fitness"])
         if n_global == 1:
             # the reference's single-chain shapes (ppde.py:178-183; the ensemble's `.squeeze()`, nets.py:442, makes one chain's
