@@ -1037,31 +1037,21 @@ __device__ __forceinline__ void cnn_body_bf(const CnnArgs& a_, const int bx, con
     }
     __syncthreads();
     PPDE_STAMP(a.dbg, sb + 8, stamp);
-    // ---- transposed convolution: dx[p][c] = sum_kappa O[p - kappa][kappa*20 + c]   (as cnn_body)
+    // ---- transposed convolution: dx[p][c] = sum_kappa O[p - kappa][kappa*20 + c], taps in ascending order (the sums of cnn_body,
+    //      bit for bit); one item = (position, four letters): KT 16-byte LDS reads and one 16-byte store
     float* out = a.gradC + (((size_t)slot * a_shape.n_parts + part) * a.n + b) * g.N;
-    for (int e0 = tid; e0 < g.N; e0 += 2 * NT) {
-        float x[2][KT];
-        int pp[2];
+    for (int it = tid; it < g.L * 5; it += NT) {
+        const int p = it / 5, c4 = it - 5 * p;
+        float4 x[KT];
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int e = min(e0 + NT * u, g.N - 1);
-            const int p = e / 20, c = e - 20 * p;
-            pp[u] = p;
+        for (int kp = 0; kp < KT; ++kp) x[kp] = *(const float4*)(sO + min(max(p - kp, 0), T - 1) * OS + kp * 20 + 4 * c4);
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-            for (int kp = 0; kp < KT; ++kp) x[u][kp] = sO[min(max(p - kp, 0), T - 1) * OS + kp * 20 + c];
+        for (int kp = 0; kp < KT; ++kp) {
+            const bool ok = p - kp >= 0 && p - kp < T;
+            v.x += ok ? x[kp].x : 0.f; v.y += ok ? x[kp].y : 0.f; v.z += ok ? x[kp].z : 0.f; v.w += ok ? x[kp].w : 0.f;
         }
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-#pragma unroll
-            for (int kp = 0; kp < KT; ++kp) use_here(x[u][kp]);
-        }
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            float v = 0.f;
-#pragma unroll
-            for (int kp = 0; kp < KT; ++kp) v += (pp[u] - kp >= 0 && pp[u] - kp < T) ? x[u][kp] : 0.f;
-            if (e0 + NT * u < g.N) out[e0 + NT * u] = v;
-        }
+        *(float4*)(out + (size_t)p * 20 + 4 * c4) = v;
     }
     PPDE_STAMP(a.dbg, sb + 9, stamp);
     PPDE_WG_STAMP(a.dbg, wg_lin, 3);
