@@ -297,7 +297,9 @@ __device__ __forceinline__ void bf_strips(const unsigned char* planes, const uin
     [[maybe_unused]] bf_u32x4 aa[2][RT][3];
     f32x4 acc[RT];
     const bf_u32x4* const bp = (const bf_u32x4*)Bfrag + (size_t)ct0 * KS * 192 + lane;
-    const int fstrip = ct_step * KS * 192;                       // elements between the wave's consecutive strips
+    // elements between the wave's consecutive strips; a caller that wants ONE strip passes a huge step: nstr is 1 then and the
+    // stride is never applied, so it is left at zero instead of overflowing an int (ct_step * KS * 192)
+    const int fstrip = nstr > 1 ? ct_step * KS * 192 : 0;
     auto fill = [&](bf_u32x4 (&b)[3], const int off) { b[0] = bp[off]; b[1] = bp[off + 64]; b[2] = bp[off + 128]; };
     auto a_base = [&](int ks) { return planes + ks * (RT * 3072) + ((ks & 1) ? lo1 : lo0); };
     auto read_a = [&](bf_u32x4 (&a)[RT][3], int ks) {

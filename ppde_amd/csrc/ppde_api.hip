@@ -830,6 +830,8 @@ int ppde_model_set_cnn(ppde_model* m, int n_nets, int C, int K, int F, const flo
     m->CP = CP;
     const int FP = (F + 15) & ~15, JP = (m->J + 15) & ~15;
     m->FP = FP; m->JP = JP;
+    // what the split-precision kernels take for granted: whole k steps of 32 channels, whole strips of 16 columns
+    ARGCHK(CP % 32 == 0 && FP % 16 == 0 && JP % 16 == 0, "padded CNN shape is not a whole number of MFMA blocks");
     auto up = [&](const std::vector<float>& v, const float** out) -> int {
         float* d = nullptr;
         HIPCHK(dalloc(&d, v.size()));

@@ -225,9 +225,8 @@ class PPDE_PAS(BaseSampler):
             # (the one-hot form the oracle takes is expanded on the device: n x L bytes cross PCIe instead of n x L x 20 floats)
             x_now = model.idx_to_onehot(torch.from_numpy(np.ascontiguousarray(gathered(pk["idx"]))))
             gt = oracle(x_now).detach().cpu().numpy()
-            fq = np.quantile(gathered(pk["fitness"]), [0.5, 0.9])
-            gq = np.quantile(gt, [0.5, 0.9])
-            eq = np.quantile(gathered(pk["energy"]), [0.5, 0.9])
+            # (one call for the three rows: np.quantile's fixed cost is ~60 us, a seventh of a log line)
+            fq, gq, eq = np.quantile(np.stack([gathered(pk["fitness"]), gt, gathered(pk["energy"])]), [0.5, 0.9], axis=1).T
             print(f'[Iteration {i}] energy: 50% {eq[0]:.3f}, 90% {eq[1]:.3f}', flush=not first)
             if first:
                 print(f'[Iteration {i}] pred fit 50% {fq[0]:.3f}, 90% {fq[1]:.3f}')
