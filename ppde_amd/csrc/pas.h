@@ -891,8 +891,7 @@ __device__ __forceinline__ void propose_body_dev(const PasArgs& a, const RowLds&
             return masked ? 0.f : expf(z - mref);
         };
         // The lane's residues (lane + 64 r) keep their 20 exponentials in REGISTERS across the sub-steps (LDS stays the
-        // authoritative copy: the letter race and the lanes that re-evaluate a residue use it); S1 is carried along and
-        // corrected by the changed residue's difference.
+        // authoritative copy: the letter race and the lanes that re-evaluate a residue use it); S1 is their total.
         constexpr int NRES = (GPT * PPDE_BLOCK * 4 / PPDE_A + 63) / 64;      // residues per lane: 2 / 4 / 5 for GPT = 1 / 2 / 3
         float4 ev[NRES][5];
         auto load_res = [&](int r) {
@@ -922,26 +921,18 @@ __device__ __forceinline__ void propose_body_dev(const PasArgs& a, const RowLds&
                     }
 #pragma unroll
                     for (int r = 0; r < NRES; ++r) load_res(r);
-                    S1 = total_mass();
                 } else {
-                    float d = 0.f;
-                    if (lane < PPDE_A) {
-                        const float e_old = E[ls_prev * PPDE_A + lane];
-                        const float e_new = letter_exp(ls_prev, lane, lds.St[ls_prev], lds.Wt[ls_prev], capped);
-                        E[ls_prev * PPDE_A + lane] = e_new;
-                        d = e_new - e_old;
-                    }
-                    const float dsum = wave_sum(d);
-                    S1 += dsum;
+                    if (lane < PPDE_A)
+                        E[ls_prev * PPDE_A + lane] = letter_exp(ls_prev, lane, lds.St[ls_prev], lds.Wt[ls_prev], capped);
 #pragma unroll
                     for (int r = 0; r < NRES; ++r)
                         if (lane + 64 * r == ls_prev) load_res(r);       // (the owner's registers; behind the stores above: one wave, in order)
-                    // The correction cancels when the residue just moved held (nearly) all the mass -- one logit far above the
-                    // rest: S1 ~ 1 against a remainder of L * 20 * exp(-mref) that can lie below ulp(1). Then the carried sum is
-                    // worth nothing and the total is summed afresh from the registers (the reference takes a logsumexp per
-                    // sub-step, utils.py:106-111; k_accept's reverse sums are exact). Uniform, rare; also catches S1 <= 0.
-                    if (!(fabsf(dsum) <= 16.f * S1)) S1 = total_mass();
+                    // The total is summed afresh from the registers every sub-step (a fixed tree per residue, then the wave). Carrying
+                    // it as S1 += sum(e_new - e_old), as up to r04, cancels when the residue just moved held (nearly) all the mass --
+                    // one logit far above the rest: S1 ~ 1 against a remainder of L * 20 * exp(-mref) that can lie below ulp(1) --
+                    // while the reference takes a logsumexp per sub-step (utils.py:106-111) and k_accept's reverse sums are exact.
                 }
+                S1 = total_mass();
                 if ((s % PAS_QS) == 0) fill_race_variates(a, lds, b, it, s, min(PAS_QS, Ub - s), lane, 64);
             }
             PPDE_STAMP(a.dbg, 14, stamp && s > 0);
