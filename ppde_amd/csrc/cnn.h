@@ -133,7 +133,7 @@ __host__ __device__ inline size_t cnn_bf_lds_bytes(int T, int CP, int FP, int J,
     const size_t bits = rows * ((CP + 31) / 32) * 4;        // ReLU gate of h1
     const size_t route = (rows + 4 + (size_t)FP) * 4;       // row offsets and the row-sorted list of routed features
     const size_t upto_x = cnn_bf_region_bytes(T, CP, J) + bits + route + (size_t)FP * 8 + 64 + ((L + CNN_MAX_K + 15) & ~15);
-    return ((upto_x + 15) & ~(size_t)15) + (size_t)(rows + CNN_MAX_K) * 64;   // + the one-hot fragments per position (cnn_conv_x_bytes)
+    return ((upto_x + 15) & ~(size_t)15) + (size_t)(rows + CNN_MAX_K) * 64 + 128;   // + the one-hot fragments per position (cnn_conv_x_bytes) + the route's row order
 }
 
 // bf_strips_c: the form the 512-thread kernels (k_cnn, k_experts: 128 registers, four waves per SIMD hide the latencies) use.
@@ -431,13 +431,23 @@ __device__ __forceinline__ void mfma_strip(f32x4 (&acc)[RT], const float* A, int
 #define CNN_ROUTE_TAIL 1
 #endif
 
-template <int NT, bool BF = false>
+// GROUPED (the single-launch split-precision kernels; sRows = `rows` bytes of LDS, sTot four ints): the row sums run over the rows
+// that RECEIVED a feature only (a quarter to a third of the rows receive none: their pieces are zeros and are written as such),
+// and one work item is a row and three consecutive 4-channel pieces, so that the row's extent, its first four list entries and
+// their coefficients are fetched once for three pieces (the same 12 L2 loads in flight per item as the ungrouped form has per
+// thread and round). A piece's sum still runs over its row's entries in list order: the same bits (CNN_ROUTE_GROUPED=0: A/B builds).
+#ifndef CNN_ROUTE_GROUPED
+#define CNN_ROUTE_GROUPED 1
+#endif
+template <int NT, bool BF = false, bool GROUPED = false>
 __device__ __forceinline__ void cnn_route_rows(const CnnNet& net, const int rows, const int r0, const int CP, const int AS,
                                                const int FP, const int BW, float* sD, uint32_t* sB, const uint32_t* sG,
                                                const float* sM, const int* sTs, int* sStart, int* sList, int* sTot,
-                                               [[maybe_unused]] unsigned long long* dbg = nullptr, [[maybe_unused]] const bool stamp = false) {
+                                               [[maybe_unused]] unsigned long long* dbg = nullptr, [[maybe_unused]] const bool stamp = false,
+                                               [[maybe_unused]] uint8_t* sRows = nullptr) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int BWF = (FP + 31) / 32;
+    [[maybe_unused]] int row_cnt = 0, ne_rank = 0;                   // GROUPED: this thread's row (tid < rows) across the barrier
     for (int f = tid; f < FP; f += NT) {
         const int t = sTs[f] - r0;
         if (sM[f] != 0.f && t >= 0 && t < rows) atomicOr(&sB[t * BWF + (f >> 5)], 1u << (f & 31));
@@ -459,9 +469,23 @@ __device__ __forceinline__ void cnn_route_rows(const CnnNet& net, const int rows
         if (tid < rows) sStart[tid] = incl - my_cnt;
         if (tid == rows - 1) sStart[rows] = (rows == 64) ? 0 : incl;   // (row index `rows` belongs to the next group iff rows == 64)
         if (lane == 63) sTot[wave] = incl;
+        if constexpr (GROUPED) {                                       // rank of this row among the wave's non-empty rows
+            const unsigned long long nz = __ballot(my_cnt > 0);         // (threads past `rows` hold my_cnt = 0)
+            row_cnt = my_cnt;
+            ne_rank = __builtin_popcountll(nz & ((1ull << lane) - 1ull));
+            if (lane == 0) sTot[2 + wave] = __builtin_popcountll(nz);
+        }
     }
     __syncthreads();
     if (tid >= 64 && tid <= rows) sStart[tid] += sTot[0];
+    if constexpr (GROUPED) {
+        // sRows: the non-empty rows in ascending order, then the empty ones
+        if (tid < rows) {
+            const int ne0 = sTot[2], ne_all = ne0 + sTot[3];
+            const int before = (wave == 1 ? ne0 : 0) + ne_rank;          // non-empty rows in front of this one
+            sRows[row_cnt > 0 ? before : ne_all + (tid - before)] = (uint8_t)tid;
+        }
+    }
     __syncthreads();
     PPDE_STAMP(dbg, 61, stamp);
     for (int f = tid; f < FP; f += NT) {
@@ -473,7 +497,77 @@ __device__ __forceinline__ void cnn_route_rows(const CnnNet& net, const int rows
     }
     __syncthreads();
     PPDE_STAMP(dbg, 62, stamp);
-    {
+    if constexpr (GROUPED) {
+        const int G4 = CP / 4, TR = (G4 + 2) / 3;                      // pieces per row, items per row
+        const int n_ne = sTot[2] + sTot[3];
+        const int last = max(sStart[rows] - 1, 0);
+        const float4* We4 = (const float4*)net.We;                   // [FP][G4]
+        auto put = [&](int t, int c4, float4 acc) {
+            if constexpr (BF) bf_store4((unsigned char*)sD, rows / 16, t, c4, acc);   // split planes (AS unused)
+            else {
+                float* dp = sD + t * AS + 4 * c4;                    // AS = 2 mod 4: rows are only 8-byte aligned
+                *(float2*)dp = make_float2(acc.x, acc.y);
+                *(float2*)(dp + 2) = make_float2(acc.z, acc.w);
+            }
+        };
+        for (int u = tid; u < n_ne * TR; u += NT) {
+            const int r = u / TR, k = u - r * TR;
+            const int t = sRows[r];
+            const int rs = sStart[t], kk = sStart[t + 1] - rs;
+            int f[4], c4c[3];
+            float cq[4];
+            float4 v[3][4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) f[q] = min((unsigned)sList[min(rs + q, last)], (unsigned)(FP - 1));
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float cm = sM[f[q]];
+                use_here(cm);                                        // (an unconditional read: hipcc predicates `q < kk ? sM[f] : 0`,
+                cq[q] = q < kk ? cm : 0.f;                           //  which puts a wait in front of every entry)
+            }
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                c4c[j] = min(3 * k + j, G4 - 1);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v[j][q] = We4[(size_t)f[q] * G4 + c4c[j]];
+            }
+            float4 acc[3];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                acc[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    acc[j].x += cq[q] * v[j][q].x; acc[j].y += cq[q] * v[j][q].y;
+                    acc[j].z += cq[q] * v[j][q].z; acc[j].w += cq[q] * v[j][q].w;
+                }
+            }
+            for (int q = 4; q < kk; ++q) {                           // rows with more than four routed features
+                const int fq = sList[rs + q];
+                const float cf = sM[fq];
+                float4 w[3];
+#pragma unroll
+                for (int j = 0; j < 3; ++j) w[j] = We4[(size_t)fq * G4 + c4c[j]];
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    acc[j].x += cf * w[j].x; acc[j].y += cf * w[j].y; acc[j].z += cf * w[j].z; acc[j].w += cf * w[j].w;
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const int c4 = 3 * k + j;
+                if (c4 >= G4) continue;
+                const uint32_t nib = (sG[t * BW + (c4 >> 3)] >> (4 * (c4 & 7))) & 0xFu;   // gate by relu'(pre1)
+                float4 a4 = acc[j];
+                a4.x = (nib & 1u) ? a4.x : 0.f; a4.y = (nib & 2u) ? a4.y : 0.f;
+                a4.z = (nib & 4u) ? a4.z : 0.f; a4.w = (nib & 8u) ? a4.w : 0.f;
+                put(t, c4, a4);
+            }
+        }
+        for (int i = tid; i < (rows - n_ne) * G4; i += NT) {          // rows without a routed feature: zero pieces
+            const int r = i / G4, c4 = i - r * G4;
+            put(sRows[n_ne + r], c4, make_float4(0.f, 0.f, 0.f, 0.f));
+        }
+    } else {
         // work item = (row, 4 channels); three items per round, the first four list entries of each fetched
         // unconditionally (clamped index, zero coefficient past the row's end): 12 independent L2 loads in flight
         const int G4 = CP / 4, items = rows * G4;
@@ -1007,7 +1101,8 @@ __device__ __forceinline__ void cnn_body_bf(const CnnArgs& a_, const int bx, con
     if (!a_shape.want_grad) return;
 
     // ---- route + gate (cnn_route_rows) -> the routed gradient's split planes
-    cnn_route_rows<NT, true>(net, rows, 0, CP, 0, FP, BW, (float*)sP, sB, sG, sM, sTs, sStart, sList, (int*)(red + 12), a.dbg, first_wg);
+    cnn_route_rows<NT, true, CNN_ROUTE_GROUPED != 0>(net, rows, 0, CP, 0, FP, BW, (float*)sP, sB, sG, sM, sTs, sStart, sList, (int*)(red + 12), a.dbg, first_wg,
+                                                      (uint8_t*)(sX + (size_t)(rows + CNN_MAX_K) * 4));
     PPDE_STAMP(a.dbg, sb + 5, stamp);
     PPDE_STAMP(a.dbg, sb + 7, stamp);
     PPDE_WG_STAMP(a.dbg, wg_lin, 2);
