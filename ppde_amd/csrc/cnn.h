@@ -133,7 +133,7 @@ __host__ __device__ inline size_t cnn_bf_lds_bytes(int T, int CP, int FP, int J,
     const size_t bits = rows * ((CP + 31) / 32) * 4;        // ReLU gate of h1
     const size_t route = (rows + 4 + (size_t)FP) * 4;       // row offsets and the row-sorted list of routed features
     const size_t upto_x = cnn_bf_region_bytes(T, CP, J) + bits + route + (size_t)FP * 8 + 64 + ((L + CNN_MAX_K + 15) & ~15);
-    return ((upto_x + 15) & ~(size_t)15) + (size_t)(rows + CNN_MAX_K) * 64 + 128;   // + the one-hot fragments per position (cnn_conv_x_bytes) + the route's row order
+    return ((upto_x + 15) & ~(size_t)15) + (size_t)(rows + CNN_MAX_K) * 64 + 256;   // + the one-hot fragments per position (cnn_conv_x_bytes) + the route's row order and its inverse
 }
 
 // bf_strips_c: the form the 512-thread kernels (k_cnn, k_experts: 128 registers, four waves per SIMD hide the latencies) use.
@@ -144,9 +144,13 @@ __host__ __device__ inline size_t cnn_bf_lds_bytes(int T, int CP, int FP, int J,
 #define CNN_A_PREFETCH 1             // 0: the r04 form (a row tile's A fragments read right in front of its MFMAs), for A/B builds
 #endif
 #if CNN_A_PREFETCH
-template <int RT, typename Epi>
+// RTC <= RT: only the first RTC row tiles hold data and are multiplied (the backward's compacted rows). A compile-time count: with
+// a run-time one the general instantiations of the single-launch kernels produced zeros for every row tile from the third on
+// (any run-time value, reproducibly; the shape-pinned instantiation did not; r05_experiments.md) -- bf_strips_rows dispatches.
+template <int RT, int RTC = RT, typename Epi>
 __device__ __forceinline__ void bf_strips_c(const unsigned char* planes, const uint4* Bfrag, const int KS, const int ct0,
                                           const int ct_step, const int ct_end, Epi&& epi) {
+    static_assert(RTC >= 1 && RTC <= RT, "row tiles to multiply");
     const int lane = threadIdx.x & 63, row = lane & 15, kq = lane >> 4;
     const int nstr = ct0 < ct_end ? (ct_end - ct0 + ct_step - 1) / ct_step : 0;
     const int Q = nstr * KS;
@@ -179,8 +183,8 @@ __device__ __forceinline__ void bf_strips_c(const unsigned char* planes, const u
         const unsigned char* ap = a_base(ks);
         const unsigned char* ap_next = a_base(ks + 1 == KS ? 0 : ks + 1);
 #pragma unroll
-        for (int rt = 0; rt < RT; ++rt) {
-            if (rt + 1 < RT) read_a(aa[(rt + 1) & 1], ap, rt + 1);
+        for (int rt = 0; rt < RTC; ++rt) {
+            if (rt + 1 < RTC) read_a(aa[(rt + 1) & 1], ap, rt + 1);
             else if (q + 1 < Q) read_a(aa[(rt + 1) & 1], ap_next, 0);
             const bf16x8 a1 = __builtin_bit_cast(bf16x8, aa[rt & 1][0]), a2 = __builtin_bit_cast(bf16x8, aa[rt & 1][1]),
                          a3 = __builtin_bit_cast(bf16x8, aa[rt & 1][2]);
@@ -193,7 +197,7 @@ __device__ __forceinline__ void bf_strips_c(const unsigned char* planes, const u
             c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b1, c, 0, 0, 0);
             acc[rt] = c;
         }
-        if constexpr (RT & 1) {                                  // (odd tile count: the next block's first set sits in aa[1])
+        if constexpr (RTC & 1) {                                 // (odd tile count: the next block's first set sits in aa[1])
             aa[0][0] = aa[1][0]; aa[0][1] = aa[1][1]; aa[0][2] = aa[1][2];
         }
         if (ks == KS - 1) epi(i, ct0 + i * ct_step, acc);
@@ -214,7 +218,7 @@ __device__ __forceinline__ void bf_strips_c(const unsigned char* planes, const u
     }
 }
 #else
-template <int RT, typename Epi>
+template <int RT, int RTC = RT, typename Epi>
 __device__ __forceinline__ void bf_strips_c(const unsigned char* planes, const uint4* Bfrag, const int KS, const int ct0,
                                           const int ct_step, const int ct_end, Epi&& epi) {
     const int lane = threadIdx.x & 63, row = lane & 15, kq = lane >> 4;
@@ -270,6 +274,16 @@ __device__ __forceinline__ void bf_strips_c(const unsigned char* planes, const u
     }
 }
 #endif
+// bf_strips_c for the first rtc (run-time, 0..RT) row tiles: one instantiation per count
+template <int RT, int R = 1, typename Epi>
+__device__ __forceinline__ void bf_strips_rows(const unsigned char* planes, const uint4* Bfrag, const int KS, const int ct0,
+                                               const int ct_step, const int ct_end, Epi&& epi, const int rtc) {
+    if constexpr (R >= RT) bf_strips_c<RT, RT>(planes, Bfrag, KS, ct0, ct_step, ct_end, epi);
+    else {
+        if (rtc <= R) bf_strips_c<RT, R>(planes, Bfrag, KS, ct0, ct_step, ct_end, epi);
+        else bf_strips_rows<RT, R + 1>(planes, Bfrag, KS, ct0, ct_step, ct_end, epi, rtc);
+    }
+}
 
 // bf_strips: the form of the 256-thread chunk kernels (two or three workgroups per CU, 256 registers). The same product as
 // bf_strips_c, block for block and term for term (same bits), with three differences that r04's counters asked for
@@ -437,17 +451,21 @@ __device__ __forceinline__ void mfma_strip(f32x4 (&acc)[RT], const float* A, int
 // their coefficients are fetched once for three pieces (the same 12 L2 loads in flight per item as the ungrouped form has per
 // thread and round). A piece's sum still runs over its row's entries in list order: the same bits (CNN_ROUTE_GROUPED=0: A/B builds).
 #ifndef CNN_ROUTE_GROUPED
-#define CNN_ROUTE_GROUPED 1
+#define CNN_ROUTE_GROUPED 2          // 0: ungrouped row sums; 1: grouped; 2: grouped + the backward over the compacted non-empty rows
 #endif
-template <int NT, bool BF = false, bool GROUPED = false>
-__device__ __forceinline__ void cnn_route_rows(const CnnNet& net, const int rows, const int r0, const int CP, const int AS,
+template <int NT, bool BF = false, int GROUPED = 0>
+__device__ __forceinline__ int cnn_route_rows(const CnnNet& net, const int rows, const int r0, const int CP, const int AS,
                                                const int FP, const int BW, float* sD, uint32_t* sB, const uint32_t* sG,
                                                const float* sM, const int* sTs, int* sStart, int* sList, int* sTot,
                                                [[maybe_unused]] unsigned long long* dbg = nullptr, [[maybe_unused]] const bool stamp = false,
                                                [[maybe_unused]] uint8_t* sRows = nullptr) {
+    // GROUPED = 2: the routed gradient is written by COMPACTED row index (the r-th non-empty row in image row r, zeros up to the
+    // next multiple of 16; sRows[rows + t] = r, or 255 for a row without a feature): the caller's backward contraction then runs
+    // over ceil(n_ne / 16) row tiles instead of all of them, and its transposed convolution maps rows back.
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int BWF = (FP + 31) / 32;
     [[maybe_unused]] int row_cnt = 0, ne_rank = 0;                   // GROUPED: this thread's row (tid < rows) across the barrier
+    int n_rows_routed = rows;
     for (int f = tid; f < FP; f += NT) {
         const int t = sTs[f] - r0;
         if (sM[f] != 0.f && t >= 0 && t < rows) atomicOr(&sB[t * BWF + (f >> 5)], 1u << (f & 31));
@@ -484,6 +502,7 @@ __device__ __forceinline__ void cnn_route_rows(const CnnNet& net, const int rows
             const int ne0 = sTot[2], ne_all = ne0 + sTot[3];
             const int before = (wave == 1 ? ne0 : 0) + ne_rank;          // non-empty rows in front of this one
             sRows[row_cnt > 0 ? before : ne_all + (tid - before)] = (uint8_t)tid;
+            if constexpr (GROUPED == 2) sRows[rows + tid] = row_cnt > 0 ? (uint8_t)before : (uint8_t)255;
         }
     }
     __syncthreads();
@@ -500,6 +519,7 @@ __device__ __forceinline__ void cnn_route_rows(const CnnNet& net, const int rows
     if constexpr (GROUPED) {
         const int G4 = CP / 4, TR = (G4 + 2) / 3;                      // pieces per row, items per row
         const int n_ne = sTot[2] + sTot[3];
+        n_rows_routed = n_ne;
         const int last = max(sStart[rows] - 1, 0);
         const float4* We4 = (const float4*)net.We;                   // [FP][G4]
         auto put = [&](int t, int c4, float4 acc) {
@@ -560,12 +580,20 @@ __device__ __forceinline__ void cnn_route_rows(const CnnNet& net, const int rows
                 float4 a4 = acc[j];
                 a4.x = (nib & 1u) ? a4.x : 0.f; a4.y = (nib & 2u) ? a4.y : 0.f;
                 a4.z = (nib & 4u) ? a4.z : 0.f; a4.w = (nib & 8u) ? a4.w : 0.f;
-                put(t, c4, a4);
+                put(GROUPED == 2 ? r : t, c4, a4);
             }
         }
-        for (int i = tid; i < (rows - n_ne) * G4; i += NT) {          // rows without a routed feature: zero pieces
-            const int r = i / G4, c4 = i - r * G4;
-            put(sRows[n_ne + r], c4, make_float4(0.f, 0.f, 0.f, 0.f));
+        if constexpr (GROUPED == 2) {
+            const int pad = ((n_ne + 15) & ~15) - n_ne;                // image rows behind the last non-empty one, up to a whole tile
+            for (int i = tid; i < pad * G4; i += NT) {
+                const int r = i / G4, c4 = i - r * G4;
+                put(n_ne + r, c4, make_float4(0.f, 0.f, 0.f, 0.f));
+            }
+        } else {
+            for (int i = tid; i < (rows - n_ne) * G4; i += NT) {      // rows without a routed feature: zero pieces
+                const int r = i / G4, c4 = i - r * G4;
+                put(sRows[n_ne + r], c4, make_float4(0.f, 0.f, 0.f, 0.f));
+            }
         }
     } else {
         // work item = (row, 4 channels); three items per round, the first four list entries of each fetched
@@ -640,6 +668,7 @@ __device__ __forceinline__ void cnn_route_rows(const CnnNet& net, const int rows
     }
     PPDE_STAMP(dbg, 63, stamp);
     __syncthreads();
+    return n_rows_routed;                                           // GROUPED: rows that received a feature; else `rows`
 }
 
 // Body of one workgroup = (chain bx of the launch, network ni); shared by k_cnn and the fused experts launch.
@@ -1101,8 +1130,11 @@ __device__ __forceinline__ void cnn_body_bf(const CnnArgs& a_, const int bx, con
     if (!a_shape.want_grad) return;
 
     // ---- route + gate (cnn_route_rows) -> the routed gradient's split planes
-    cnn_route_rows<NT, true, CNN_ROUTE_GROUPED != 0>(net, rows, 0, CP, 0, FP, BW, (float*)sP, sB, sG, sM, sTs, sStart, sList, (int*)(red + 12), a.dbg, first_wg,
-                                                      (uint8_t*)(sX + (size_t)(rows + CNN_MAX_K) * 4));
+    uint8_t* sRows = (uint8_t*)(sX + (size_t)(rows + CNN_MAX_K) * 4);     // [rows] row order of the route + [rows] row -> image row
+    const int n_ne = cnn_route_rows<NT, true, CNN_ROUTE_GROUPED>(net, rows, 0, CP, 0, FP, BW, (float*)sP, sB, sG, sM, sTs, sStart, sList, (int*)(red + 12), a.dbg, first_wg, sRows);
+    // (CNN_ROUTE_GROUPED = 2: the routed gradient's image holds the non-empty rows only, in rtc row tiles)
+    constexpr bool COMPACT = CNN_ROUTE_GROUPED == 2;
+    const int rtc = COMPACT ? __builtin_amdgcn_readfirstlane((n_ne + 15) >> 4) : RT;
     PPDE_STAMP(a.dbg, sb + 5, stamp);
     PPDE_STAMP(a.dbg, sb + 7, stamp);
     PPDE_WG_STAMP(a.dbg, wg_lin, 2);
@@ -1117,7 +1149,8 @@ __device__ __forceinline__ void cnn_body_bf(const CnnArgs& a_, const int bx, con
             else keep[NKEEP - 1][rt] = acc[rt];
         }
     };
-    bf_strips_c<RT>(sP, net.WfB, KS, wave, NT / 64, JP / 16, bwd_epi);
+    if constexpr (COMPACT) bf_strips_rows<RT>(sP, net.WfB, KS, wave, NT / 64, JP / 16, bwd_epi, rtc);
+    else bf_strips_c<RT>(sP, net.WfB, KS, wave, NT / 64, JP / 16, bwd_epi);
     __syncthreads();
     float* sO = (float*)sP;
 #pragma unroll
@@ -1127,6 +1160,7 @@ __device__ __forceinline__ void cnn_body_bf(const CnnArgs& a_, const int bx, con
         if (ct < JP / 16 && j < J) {
 #pragma unroll
             for (int rt = 0; rt < RT; ++rt) {
+                if (rt >= rtc) break;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) sO[(rt * 16 + (lane >> 4) * 4 + q) * OS + j] = keep[i][rt][q];
             }
@@ -1140,12 +1174,18 @@ __device__ __forceinline__ void cnn_body_bf(const CnnArgs& a_, const int bx, con
     for (int it = tid; it < g.L * 5; it += NT) {
         const int p = it / 5, c4 = it - 5 * p;
         float4 x[KT];
+        [[maybe_unused]] int ri[KT];
 #pragma unroll
-        for (int kp = 0; kp < KT; ++kp) x[kp] = *(const float4*)(sO + min(max(p - kp, 0), T - 1) * OS + kp * 20 + 4 * c4);
+        for (int kp = 0; kp < KT; ++kp) {
+            const int t = min(max(p - kp, 0), T - 1);
+            if constexpr (COMPACT) { ri[kp] = sRows[rows + t]; x[kp] = *(const float4*)(sO + (ri[kp] == 255 ? 0 : ri[kp]) * OS + kp * 20 + 4 * c4); }
+            else x[kp] = *(const float4*)(sO + t * OS + kp * 20 + 4 * c4);
+        }
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
         for (int kp = 0; kp < KT; ++kp) {
-            const bool ok = p - kp >= 0 && p - kp < T;
+            bool ok = p - kp >= 0 && p - kp < T;
+            if constexpr (COMPACT) ok = ok && ri[kp] != 255;          // (a row without a routed feature: its O row is +0 in the full form)
             v.x += ok ? x[kp].x : 0.f; v.y += ok ? x[kp].y : 0.f; v.z += ok ? x[kp].z : 0.f; v.w += ok ? x[kp].w : 0.f;
         }
         *(float4*)(out + (size_t)p * 20 + 4 * c4) = v;
@@ -1157,7 +1197,10 @@ __device__ __forceinline__ void cnn_body_bf(const CnnArgs& a_, const int bx, con
 // BF: the split-precision body (bf16 matrix pipe) instead of the exact-fp32 MFMA one
 template <int RT, int KT, int NT = CNN_NT, bool BF = false>
 // (two 512-thread workgroups share a CU up to six row tiles: four waves per SIMD, i.e. at most 128 registers)
-__global__ __launch_bounds__(NT, (RT <= 6 && NT == 512 && KT == 5) ? 4 : 2) void k_cnn(CnnArgs a) {
+#ifndef CNN_BOUNDS_RELAX
+#define CNN_BOUNDS_RELAX 0
+#endif
+__global__ __launch_bounds__(NT, (RT <= 6 && NT == 512 && KT == 5 && !CNN_BOUNDS_RELAX) ? 4 : 2) void k_cnn(CnnArgs a) {
     warm_kernargs<sizeof(CnnArgs)>();
     extern __shared__ unsigned char smem_raw[];
     if constexpr (BF) cnn_body_bf<RT, KT, NT>(a, blockIdx.x, blockIdx.y, gridDim.x, gridDim.y, smem_raw);

@@ -432,7 +432,7 @@ struct ExpertsArgs {
 #define PPDE_EXPERTS_PRIO 0
 #endif
 template <int RT, int NG, bool PABP = false, bool BF = false>
-__global__ __launch_bounds__(CNN_NT, RT <= 6 ? 4 : 2) void k_experts(ExpertsArgs a) {
+__global__ __launch_bounds__(CNN_NT, (RT <= 6 && !CNN_BOUNDS_RELAX) ? 4 : 2) void k_experts(ExpertsArgs a) {
     warm_kernargs<sizeof(ExpertsArgs)>();
 
     extern __shared__ float4 smem_experts[];
