@@ -1461,7 +1461,9 @@ __global__ __launch_bounds__(NT, 2) void k_cnn_bwd_chunk(CnnChunkArgs ca) {
     __syncthreads();
     PPDE_STAMP(a.dbg, 42, stamp);
     // ---- route the features whose arg-max row lies in the window, gate (cnn_route_rows)
-    cnn_route_rows<NT, BF>(net, rows, r0, CP, AS, FP, BW, sD, (uint32_t*)sD, sG, sM, sTs, sStart, sList, sCnt);
+    // (split-precision kernels: row sums over the window's non-empty rows, three pieces per item; the row order in the slack behind sStart)
+    cnn_route_rows<NT, BF, (BF && CNN_ROUTE_GROUPED != 0) ? 1 : 0>(net, rows, r0, CP, AS, FP, BW, sD, (uint32_t*)sD, sG, sM, sTs, sStart, sList, sCnt,
+                                                                   nullptr, false, (uint8_t*)(sStart + rows + 4));
     PPDE_STAMP(a.dbg, 43, stamp);
     // ---- O = dpre1 x Wf on the matrix cores
     if constexpr (BF) {
