@@ -143,13 +143,30 @@ __host__ __device__ inline size_t cnn_bf_lds_bytes(int T, int CP, int FP, int J,
 #ifndef CNN_A_PREFETCH
 #define CNN_A_PREFETCH 1             // 0: the r04 form (a row tile's A fragments read right in front of its MFMAs), for A/B builds
 #endif
+// The first three B fragment sets of a wave's (strip, k step) sequence, loaded ahead of the barrier in front of the contraction
+// (bf_prefill) so that their L2 round trip passes while the workgroup's slower waves finish the previous phase.
+struct BfPre { uint4 x[3], y[3], z[3]; };
+__device__ __forceinline__ void bf_prefill(BfPre& p, const uint4* Bfrag, const int KS, const int ct0, const int ct_step, const int ct_end) {
+    const int lane = threadIdx.x & 63;
+    const int nstr = ct0 < ct_end ? (ct_end - ct0 + ct_step - 1) / ct_step : 0;
+    const int Q = nstr * KS;
+    if (Q == 0) return;
+    const uint4* bp = Bfrag + lane;
+    auto fill = [&](uint4 (&b)[3], int q) {
+        q = min(q, Q - 1);
+        const int i = q / KS, ks = q - i * KS;
+        const size_t at = ((size_t)(ct0 + i * ct_step) * KS + ks) * 192;
+        b[0] = bp[at]; b[1] = bp[at + 64]; b[2] = bp[at + 128];
+    };
+    fill(p.x, 0); fill(p.y, 1); fill(p.z, 2);
+}
 #if CNN_A_PREFETCH
 // RTC <= RT: only the first RTC row tiles hold data and are multiplied (the backward's compacted rows). A compile-time count: with
 // a run-time one the general instantiations of the single-launch kernels produced zeros for every row tile from the third on
 // (any run-time value, reproducibly; the shape-pinned instantiation did not; r05_experiments.md) -- bf_strips_rows dispatches.
-template <int RT, int RTC = RT, typename Epi>
+template <int RT, int RTC = RT, bool PRE = false, typename Epi>
 __device__ __forceinline__ void bf_strips_c(const unsigned char* planes, const uint4* Bfrag, const int KS, const int ct0,
-                                          const int ct_step, const int ct_end, Epi&& epi) {
+                                          const int ct_step, const int ct_end, Epi&& epi, BfPre& pre) {
     static_assert(RTC >= 1 && RTC <= RT, "row tiles to multiply");
     const int lane = threadIdx.x & 63, row = lane & 15, kq = lane >> 4;
     const int nstr = ct0 < ct_end ? (ct_end - ct0 + ct_step - 1) / ct_step : 0;
@@ -157,7 +174,7 @@ __device__ __forceinline__ void bf_strips_c(const unsigned char* planes, const u
     if (Q == 0) return;
     const uint4* bp = Bfrag + lane;
     const int lo0 = (kq * 16 + (row ^ kq)) << 4, lo1 = (kq * 16 + (row ^ kq ^ 4)) << 4;
-    uint4 bx[3], by[3], bz[3];
+    uint4 (&bx)[3] = pre.x, (&by)[3] = pre.y, (&bz)[3] = pre.z;   // the three fragment buffers in rotation ARE the caller's prefilled ones
     f32x4 acc[RT];
     // The A fragments of row tile rt + 1 (at a block's last row tile: of the NEXT block's first) are read from LDS while row tile
     // rt multiplies: two register sets in alternation. Up to r04 a row tile's three reads were issued right in front of its six
@@ -202,7 +219,7 @@ __device__ __forceinline__ void bf_strips_c(const unsigned char* planes, const u
         }
         if (ks == KS - 1) epi(i, ct0 + i * ct_step, acc);
     };
-    fill(bx, 0); fill(by, 1); fill(bz, 2);
+    if constexpr (!PRE) { fill(bx, 0); fill(by, 1); fill(bz, 2); }   // (PRE: the caller's bf_prefill did, ahead of its barrier)
     read_a(aa[0], a_base(0), 0);
     for (int q = 0; q < Q; q += 3) {
         mult(bx, q);
@@ -218,9 +235,9 @@ __device__ __forceinline__ void bf_strips_c(const unsigned char* planes, const u
     }
 }
 #else
-template <int RT, int RTC = RT, typename Epi>
+template <int RT, int RTC = RT, bool PRE = false, typename Epi>
 __device__ __forceinline__ void bf_strips_c(const unsigned char* planes, const uint4* Bfrag, const int KS, const int ct0,
-                                          const int ct_step, const int ct_end, Epi&& epi) {
+                                          const int ct_step, const int ct_end, Epi&& epi, BfPre&) {
     const int lane = threadIdx.x & 63, row = lane & 15, kq = lane >> 4;
     const int nstr = ct0 < ct_end ? (ct_end - ct0 + ct_step - 1) / ct_step : 0;
     const int Q = nstr * KS;
@@ -275,13 +292,13 @@ __device__ __forceinline__ void bf_strips_c(const unsigned char* planes, const u
 }
 #endif
 // bf_strips_c for the first rtc (run-time, 0..RT) row tiles: one instantiation per count
-template <int RT, int R = 1, typename Epi>
+template <int RT, bool PRE, int R = 1, typename Epi>
 __device__ __forceinline__ void bf_strips_rows(const unsigned char* planes, const uint4* Bfrag, const int KS, const int ct0,
-                                               const int ct_step, const int ct_end, Epi&& epi, const int rtc) {
-    if constexpr (R >= RT) bf_strips_c<RT, RT>(planes, Bfrag, KS, ct0, ct_step, ct_end, epi);
+                                               const int ct_step, const int ct_end, Epi&& epi, const int rtc, BfPre& pre) {
+    if constexpr (R >= RT) bf_strips_c<RT, RT, PRE>(planes, Bfrag, KS, ct0, ct_step, ct_end, epi, pre);
     else {
-        if (rtc <= R) bf_strips_c<RT, R>(planes, Bfrag, KS, ct0, ct_step, ct_end, epi);
-        else bf_strips_rows<RT, R + 1>(planes, Bfrag, KS, ct0, ct_step, ct_end, epi, rtc);
+        if (rtc <= R) bf_strips_c<RT, R, PRE>(planes, Bfrag, KS, ct0, ct_step, ct_end, epi, pre);
+        else bf_strips_rows<RT, PRE, R + 1>(planes, Bfrag, KS, ct0, ct_step, ct_end, epi, rtc, pre);
     }
 }
 
@@ -453,7 +470,7 @@ __device__ __forceinline__ void mfma_strip(f32x4 (&acc)[RT], const float* A, int
 #ifndef CNN_ROUTE_GROUPED
 #define CNN_ROUTE_GROUPED 2          // 0: ungrouped row sums; 1: grouped; 2: grouped + the backward over the compacted non-empty rows
 #endif
-template <int NT, bool BF = false, int GROUPED = 0>
+template <int NT, bool BF = false, int GROUPED = 0, bool FINAL_BARRIER = true>
 __device__ __forceinline__ int cnn_route_rows(const CnnNet& net, const int rows, const int r0, const int CP, const int AS,
                                                const int FP, const int BW, float* sD, uint32_t* sB, const uint32_t* sG,
                                                const float* sM, const int* sTs, int* sStart, int* sList, int* sTot,
@@ -667,7 +684,7 @@ __device__ __forceinline__ int cnn_route_rows(const CnnNet& net, const int rows,
         }
     }
     PPDE_STAMP(dbg, 63, stamp);
-    __syncthreads();
+    if constexpr (FINAL_BARRIER) __syncthreads();                    // (else: the caller's, behind whatever it wants in flight across it)
     return n_rows_routed;                                           // GROUPED: rows that received a feature; else `rows`
 }
 
@@ -1017,7 +1034,7 @@ __device__ __forceinline__ void cnn_body_bf(const CnnArgs& a_, const int bx, con
     [[maybe_unused]] uint4 af[KT][3];
     [[maybe_unused]] const ConvUnit cu = conv_unit(wave, NT / 64, CP / 16, RT);
     if constexpr (CONV_MFMA) {
-        if (cu.tile < CP / 16) conv_load_a<KT>(af, net, cu.tile);
+        if constexpr (!PABP) { if (cu.tile < CP / 16) conv_load_a<KT>(af, net, cu.tile); }
         for (int i = tid; i < (rows + KT - 1) * 4; i += NT) {
             const int p = i >> 2;
             const int letter = p < g.L ? min((int)a.idx[(size_t)b * g.Ls + g.sh + p], 19) : 0;
@@ -1032,7 +1049,13 @@ __device__ __forceinline__ void cnn_body_bf(const CnnArgs& a_, const int bx, con
         sM[f] = mine ? net.be[f] : 0.f;
         if (halved) sTs[f] = 0;
     }
-    __syncthreads();
+    // the table fragments go out LAST, behind every load whose value goes through LDS, and the barrier waits for LDS only: the
+    // 15 KB per wave (240 KB per CU through the 64 B/clk path) arrive while the slower waves stage their share
+    // (shape-pinned instantiation; the general ones load them first and wait at a plain barrier)
+    if constexpr (CONV_MFMA && PABP) {
+        if (cu.tile < CP / 16) conv_load_a<KT>(af, net, cu.tile);
+        lds_barrier();
+    } else __syncthreads();
     PPDE_STAMP(a.dbg, sb + 1, stamp);
 
     // ---- h1 = relu(conv). Five taps: on the matrix pipe (conv_onehot_mfma below); other tap counts: the table gather of cnn_body.
@@ -1075,7 +1098,11 @@ __device__ __forceinline__ void cnn_body_bf(const CnnArgs& a_, const int bx, con
             }
         }
     }
-    __syncthreads();
+    // the forward contraction's first B fragments leave before the barrier (which waits for LDS only)
+    // (shape-pinned instantiation only: the general ones have no registers to carry 36 values across the barrier)
+    BfPre pre_f;
+    if constexpr (PABP) { bf_prefill(pre_f, net.WeB, KS, ct_lo + wave, NT / 64, ct_hi); lds_barrier(); }
+    else __syncthreads();
     PPDE_STAMP(a.dbg, sb + 2, stamp);
     // ---- pre2 = h1 We^T + be (six bf16 cross-term MFMAs per block); relu and the running max over t straight from the
     //      accumulators (strict >, rows ascending: the first index wins, like torch.max)
@@ -1101,7 +1128,7 @@ __device__ __forceinline__ void cnn_body_bf(const CnnArgs& a_, const int bx, con
         }
         if (lane < 16) { sM[f] = m; sTs[f] = ts; }
     };
-    bf_strips_c<RT>(sP, net.WeB, KS, ct_lo + wave, NT / 64, ct_hi, fwd_epi);
+    bf_strips_c<RT, RT, PABP>(sP, net.WeB, KS, ct_lo + wave, NT / 64, ct_hi, fwd_epi, pre_f);
     __syncthreads();
 
     PPDE_STAMP(a.dbg, sb + 3, stamp);
@@ -1131,7 +1158,10 @@ __device__ __forceinline__ void cnn_body_bf(const CnnArgs& a_, const int bx, con
 
     // ---- route + gate (cnn_route_rows) -> the routed gradient's split planes
     uint8_t* sRows = (uint8_t*)(sX + (size_t)(rows + CNN_MAX_K) * 4);     // [rows] row order of the route + [rows] row -> image row
-    const int n_ne = cnn_route_rows<NT, true, CNN_ROUTE_GROUPED>(net, rows, 0, CP, 0, FP, BW, (float*)sP, sB, sG, sM, sTs, sStart, sList, (int*)(red + 12), a.dbg, first_wg, sRows);
+    const int n_ne = cnn_route_rows<NT, true, CNN_ROUTE_GROUPED, false>(net, rows, 0, CP, 0, FP, BW, (float*)sP, sB, sG, sM, sTs, sStart, sList, (int*)(red + 12), a.dbg, first_wg, sRows);
+    BfPre pre_b;                                                     // the backward contraction's first B fragments, across the route's closing barrier
+    if constexpr (PABP) { bf_prefill(pre_b, net.WfB, KS, wave, NT / 64, JP / 16); lds_barrier(); }
+    else __syncthreads();
     // (CNN_ROUTE_GROUPED = 2: the routed gradient's image holds the non-empty rows only, in rtc row tiles)
     constexpr bool COMPACT = CNN_ROUTE_GROUPED == 2;
     const int rtc = COMPACT ? __builtin_amdgcn_readfirstlane((n_ne + 15) >> 4) : RT;
@@ -1149,8 +1179,8 @@ __device__ __forceinline__ void cnn_body_bf(const CnnArgs& a_, const int bx, con
             else keep[NKEEP - 1][rt] = acc[rt];
         }
     };
-    if constexpr (COMPACT) bf_strips_rows<RT>(sP, net.WfB, KS, wave, NT / 64, JP / 16, bwd_epi, rtc);
-    else bf_strips_c<RT>(sP, net.WfB, KS, wave, NT / 64, JP / 16, bwd_epi);
+    if constexpr (COMPACT) bf_strips_rows<RT, PABP>(sP, net.WfB, KS, wave, NT / 64, JP / 16, bwd_epi, rtc, pre_b);
+    else bf_strips_c<RT, RT, PABP>(sP, net.WfB, KS, wave, NT / 64, JP / 16, bwd_epi, pre_b);
     __syncthreads();
     float* sO = (float*)sP;
 #pragma unroll
@@ -1480,7 +1510,7 @@ __global__ __launch_bounds__(NT, 2) void k_cnn_bwd_chunk(CnnChunkArgs ca) {
             // (the pipelined form where two workgroups share a CU, GFP: 505 -> 501 us per step; with three, UBE4B, its
             //  registers cost more than they buy: 104.8 -> 108.5)
             if constexpr (SHAPE == 2 && NT == 256) bf_strips<RT, CNN_CHUNK_NB, true>(smem_raw, net.WfB, CP / 32, ct, 1 << 20, JPc / 16, take);
-            else bf_strips_c<RT>(smem_raw, net.WfB, CP / 32, ct, 1 << 20, JPc / 16, take);
+            else { BfPre pb; bf_strips_c<RT>(smem_raw, net.WfB, CP / 32, ct, 1 << 20, JPc / 16, take, pb); }
         };
         grab(keep0, wave);
         if constexpr (NKEEP > 1) grab(keep1, wave + NW);
