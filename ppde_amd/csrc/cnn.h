@@ -481,7 +481,6 @@ __device__ __forceinline__ int cnn_route_rows(const CnnNet& net, const int rows,
     // over ceil(n_ne / 16) row tiles instead of all of them, and its transposed convolution maps rows back.
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int BWF = (FP + 31) / 32;
-    [[maybe_unused]] int row_cnt = 0, ne_rank = 0;                   // GROUPED: this thread's row (tid < rows) across the barrier
     int n_rows_routed = rows;
     for (int f = tid; f < FP; f += NT) {
         const int t = sTs[f] - r0;
@@ -489,6 +488,37 @@ __device__ __forceinline__ int cnn_route_rows(const CnnNet& net, const int rows,
     }
     __syncthreads();
     PPDE_STAMP(dbg, 60, stamp);
+    if constexpr (GROUPED != 0) {
+        // row counts, offsets and the row order in ONE wave (rows <= 128: a lane takes rows lane and lane + 64), prefix sums on DPP:
+        // no cross-wave fix-up, one barrier
+        if (wave == 0) {
+            int c0 = 0, c1 = 0;
+            if (lane < rows)
+                for (int w = 0; w < BWF; ++w) c0 += __builtin_popcount(sB[lane * BWF + w]);
+            if (lane + 64 < rows)
+                for (int w = 0; w < BWF; ++w) c1 += __builtin_popcount(sB[(lane + 64) * BWF + w]);
+            const int i0 = wave_scan_incl_i(c0), i1 = wave_scan_incl_i(c1);
+            const int T0 = __builtin_amdgcn_readlane(i0, 63), T1 = __builtin_amdgcn_readlane(i1, 63);
+            if (lane < rows) sStart[lane] = i0 - c0;
+            if (lane + 64 < rows) sStart[lane + 64] = T0 + i1 - c1;
+            if (lane == 0) sStart[rows] = T0 + T1;
+            const unsigned long long nz0 = __ballot(c0 > 0), nz1 = __ballot(c1 > 0);   // (rows past `rows` count 0)
+            const unsigned long long below = (1ull << lane) - 1ull;
+            const int ne0 = __builtin_popcountll(nz0), ne_all = ne0 + __builtin_popcountll(nz1);
+            const int b0 = __builtin_popcountll(nz0 & below), b1 = ne0 + __builtin_popcountll(nz1 & below);   // non-empty rows in front
+            // sRows: the non-empty rows in ascending order, then the empty ones; GROUPED = 2: and row -> image row behind them
+            if (lane < rows) {
+                sRows[c0 > 0 ? b0 : ne_all + (lane - b0)] = (uint8_t)lane;
+                if constexpr (GROUPED == 2) sRows[rows + lane] = c0 > 0 ? (uint8_t)b0 : (uint8_t)255;
+            }
+            if (lane + 64 < rows) {
+                sRows[c1 > 0 ? b1 : ne_all + (lane + 64 - b1)] = (uint8_t)(lane + 64);
+                if constexpr (GROUPED == 2) sRows[rows + lane + 64] = c1 > 0 ? (uint8_t)b1 : (uint8_t)255;
+            }
+            if (lane == 0) { sTot[2] = ne_all; sTot[3] = 0; }
+        }
+        __syncthreads();
+    } else {
     // row counts and offsets: an exclusive scan inside each group of 64 rows (waves 0 and 1), then the second
     // group is shifted by the first group's total
     if (tid < 128) {
@@ -504,25 +534,11 @@ __device__ __forceinline__ int cnn_route_rows(const CnnNet& net, const int rows,
         if (tid < rows) sStart[tid] = incl - my_cnt;
         if (tid == rows - 1) sStart[rows] = (rows == 64) ? 0 : incl;   // (row index `rows` belongs to the next group iff rows == 64)
         if (lane == 63) sTot[wave] = incl;
-        if constexpr (GROUPED) {                                       // rank of this row among the wave's non-empty rows
-            const unsigned long long nz = __ballot(my_cnt > 0);         // (threads past `rows` hold my_cnt = 0)
-            row_cnt = my_cnt;
-            ne_rank = __builtin_popcountll(nz & ((1ull << lane) - 1ull));
-            if (lane == 0) sTot[2 + wave] = __builtin_popcountll(nz);
-        }
     }
     __syncthreads();
     if (tid >= 64 && tid <= rows) sStart[tid] += sTot[0];
-    if constexpr (GROUPED) {
-        // sRows: the non-empty rows in ascending order, then the empty ones
-        if (tid < rows) {
-            const int ne0 = sTot[2], ne_all = ne0 + sTot[3];
-            const int before = (wave == 1 ? ne0 : 0) + ne_rank;          // non-empty rows in front of this one
-            sRows[row_cnt > 0 ? before : ne_all + (tid - before)] = (uint8_t)tid;
-            if constexpr (GROUPED == 2) sRows[rows + tid] = row_cnt > 0 ? (uint8_t)before : (uint8_t)255;
-        }
-    }
     __syncthreads();
+    }
     PPDE_STAMP(dbg, 61, stamp);
     for (int f = tid; f < FP; f += NT) {
         const int t = sTs[f] - r0, w = f >> 5;

@@ -118,6 +118,17 @@ __device__ __forceinline__ float wave_sum(float v) {
     v += dpp_rows_f<DPP_BCAST31, 0xC>(0.f, v);
     return lane_f(v, 63);
 }
+// inclusive prefix sum over the 64 lanes on DPP: row_shr 1, 2, 4, 8 inside each 16-lane row (lanes shifted in from outside the
+// row read 0), then the totals of rows 0 and 2 onto rows 1 and 3, then the total of rows 0-1 onto rows 2 and 3
+__device__ __forceinline__ int wave_scan_incl_i(int v) {
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, true);     // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xF, 0xF, true);     // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xF, 0xF, true);     // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xF, 0xF, true);     // row_shr:8
+    v += dpp_rows_i<DPP_BCAST15, 0xA>(0, v);
+    v += dpp_rows_i<DPP_BCAST31, 0xC>(0, v);
+    return v;
+}
 template <int CTRL>
 __device__ __forceinline__ double dpp_d(double v) {
     const long long b = __builtin_bit_cast(long long, v);
