@@ -25,10 +25,18 @@ struct CnnNet {
     const float* be;     // [FP]
     const float* wd;     // [FP]
     const float* Wf;     // [CP][JP]      conv weights as [channel] x [kappa*20 + c] (B operand of the backward)
-    const uint4* WeB;    // [FP/16][CP/32][3][64]  We as MFMA B fragments of its exact three-term bf16 split (split-precision path)
-    const uint4* WfB;    // [JP/16][CP/32][3][64]  Wf likewise
-    const uint4* WcA;    // [CP/16][KT][3][64]     conv table as MFMA A fragments of its split: one k step of 32 (20 letters) per tap
+    const uint4* WeB;    // [FP/16][CP/32][BFT][64]  We as MFMA B fragments of its split (split-precision path), scaled (below)
+    const uint4* WfB;    // [JP/16][CP/32][BFT][64]  Wf likewise
+    const uint4* WcA;    // [CP/16][KT][BFT][64]     conv table as MFMA A fragments of its split: one k step of 32 (20 letters) per tap
     float bd;
+    // power-of-two scales of the two-term fp16 split (all 1 with the three-term bf16 split), chosen at upload from static bounds,
+    // one per CHANNEL (the contraction index of both products: D A and D^-1 B, D diagonal, leave the product as it is):
+    const float* sch;    // [CP] h1[.][o] is split as sch[o] * h1 (WcA holds sch[o] * table: the matrix-pipe convolution produces
+                         //      sch[o] * pre1); WeB holds We[f][o] / sch[o] times one scale for the matrix
+    const float* WeG;    // [F][CP] We[f][o] * scg[o]: what the route sums, so that the routed gradient is built scaled per channel
+                         //      (times CnnArgs.gsc); WfB holds Wf[o][j] / scg[o] times one scale
+    float un_f;          // forward accumulators * un_f = h1 We^T          (1 / scale of WeB)
+    float un_b;          // backward accumulators * un_b * CnnArgs.gun = O (1 / scale of WfB)
 };
 
 struct CnnArgs {
@@ -45,6 +53,7 @@ struct CnnArgs {
     int b_off;                      // first chain of this launch
     int want_grad;
     float scale;                    // upstream gradient of every network output: lamda / nets (or 1 / nets)
+    float gsc, gun;                 // 2^-ceil(log2 |scale|) and its reciprocal (two-term split: |scale| * gsc <= 1 keeps the routed gradient in range)
     unsigned long long* dbg;        // stamp buffer (diagnostic build)
     Geom g;
 };
@@ -63,18 +72,66 @@ __host__ __device__ inline size_t cnn_lds_bytes(int T, int CP, int FP, int J, in
     return r0 + r1 + bits + route + (size_t)FP * 8 + 64 + ((L + CNN_MAX_K + 15) & ~15);
 }
 
-// ---- split-precision contractions on the bf16 matrix pipe ---------------------------------------------------------------
-// v_mfma_f32_16x16x4_f32 runs at 1/16 of the bf16 MFMA rate. An fp32 value is EXACTLY the sum of three bf16 values (8 + 8 + 8
-// significant bits, each rounded to nearest even from the remainder of the previous one), and a product of two bf16 values is
-// exact in fp32, so a * b = sum of nine exact cross terms; the six terms a1b1, a1b2, a2b1, a2b2, a1b3, a3b1 leave out
-// a2b3 + a3b2 + a3b3 <= 2^-26 |a b| (a quarter of an fp32 rounding of the product). Six v_mfma_f32_16x16x32_bf16 with fp32
-// accumulation replace eight v_mfma_f32_16x16x4_f32 per 16 x 16 x 32 block: 16 * 6 against 32 * 8 matrix-pipe cycles (2.7x).
+// ---- split-precision contractions on the 16-bit matrix pipe -------------------------------------------------------------
+// v_mfma_f32_16x16x4_f32 runs at 1/16 of the 16-bit MFMA rate. Two splits of an fp32 operand into 16-bit terms whose pairwise
+// products are EXACT in fp32 (accumulation is fp32 either way):
+//  CNN_SPLIT = 3: three bf16 terms (8 + 8 + 8 significant bits: the fp32 value exactly); the six cross terms a1b1, a1b2, a2b1,
+//      a2b2, a1b3, a3b1 leave out <= 2^-26 |a b| (a quarter of an fp32 rounding of the product). Six v_mfma_f32_16x16x32_bf16
+//      per 16 x 16 x 32 block (2.7x the fp32 MFMA's rate). The form of rounds 3-5.
+//  CNN_SPLIT = 2 (default): two fp16 terms of the operand scaled by a power of two (a1 = rn16(s a), a2 = rn16(s a - a1): 11 + 11
+//      significant bits, |s a - a1 - a2| <= 2^-22 |s a|); the three cross terms a1b1, a1b2, a2b1 leave out a2b2 <= 2^-22 |a b|:
+//      every product within 3 * 2^-22 |a b| of the exact one in the worst case -- below the rounding noise of the fp32 sums the
+//      reference itself forms (measured on the trained networks: DESIGN.md section 5). Three v_mfma_f32_16x16x32_f16 per block,
+//      two planes in LDS, two fragments per block from L2. fp16 has 5 exponent bits, hence the scales (ppde_model_set_cnn):
+//      the activation operand is scaled per CHANNEL o (the contraction index) so that a static bound of |A[.][o]| lands at 2^15,
+//      the weight operand by the inverse per channel and then as a whole so that its largest entry lands at 2^15. A weight
+//      entry 2^-k below the largest one keeps full relative precision up to k = 16 and loses absolute precision never (its
+//      second term goes subnormal: its product's error stays <= 2^-22 of the LARGEST product's bound), so every product of the
+//      sum is within 3 * 2^-22 of max_o (bound_o |B'[o][.]|) -- whatever the channels' magnitudes are among themselves.
+//      Scaling by powers of two is exact, so the scaled fp32 sums are the unscaled ones, bit for bit.
 // The weights are split once at upload (ppde_model_set_cnn), the activations when they are written to LDS.
+#ifndef CNN_SPLIT
+#define CNN_SPLIT 2
+#endif
+constexpr int BFT = CNN_SPLIT;                  // terms of an operand = planes of an LDS image = fragments of a block
+constexpr int BF_BLK = BFT * 1024;              // bytes of one (k step, row tile) block of an LDS image
+constexpr int BF_FRAG = BFT * 64;               // uint4 of one (strip, k step) of B fragments (or (tile, tap) of A fragments)
+static_assert(BFT == 2 || BFT == 3, "CNN_SPLIT: 2 (fp16 terms) or 3 (bf16 terms)");
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-// host side of the split (integer round-to-nearest-even: what v_cvt_pk_bf16_f32 does for finite values)
+// one 16 x 16 x 32 block of the split product, small terms first
+__device__ __forceinline__ f32x4 bf_mfma(const uint4& a, const uint4& b, f32x4 c) {
+    if constexpr (BFT == 2) return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+template <typename VA, typename VB>
+__device__ __forceinline__ f32x4 bf_product(f32x4 c, const VA (&a)[BFT], const VB (&b)[BFT]) {
+    auto A = [&](int t) { return __builtin_bit_cast(uint4, a[t]); };
+    auto B = [&](int t) { return __builtin_bit_cast(uint4, b[t]); };
+    if constexpr (BFT == 2) {
+        c = bf_mfma(A(1), B(0), c);
+        c = bf_mfma(A(0), B(1), c);
+        c = bf_mfma(A(0), B(0), c);
+    } else {
+        c = bf_mfma(A(2), B(0), c);
+        c = bf_mfma(A(0), B(2), c);
+        c = bf_mfma(A(1), B(1), c);
+        c = bf_mfma(A(1), B(0), c);
+        c = bf_mfma(A(0), B(1), c);
+        c = bf_mfma(A(0), B(0), c);
+    }
+    return c;
+}
+// the cross terms in issue order, for the forms that issue a block's MFMAs term by term across row tiles
+constexpr int BF_NCROSS = BFT == 2 ? 3 : 6;
+__host__ __device__ constexpr int bf_cross_a(int i) { return BFT == 2 ? (i == 0 ? 1 : 0) : (i == 0 ? 2 : i == 1 ? 0 : i < 4 ? 1 : 0); }
+__host__ __device__ constexpr int bf_cross_b(int i) { return BFT == 2 ? (i == 1 ? 1 : 0) : (i == 0 ? 0 : i == 1 ? 2 : i == 2 ? 1 : i == 3 ? 0 : i == 4 ? 1 : 0); }
+
+// host side of the splits (round to nearest even: what v_cvt_pk_bf16_f32 / v_cvt_pk_f16_f32 do for finite values)
 inline uint16_t bf16_rne_bits(float x) {
     uint32_t u;
     memcpy(&u, &x, 4);
@@ -87,45 +144,76 @@ inline float bf16_bits_to_float(uint16_t h) {
     memcpy(&f, &u, 4);
     return f;
 }
-inline void bf16_split3_host(float a, uint16_t (&t)[3]) {
-    t[0] = bf16_rne_bits(a);
-    const float r1 = a - bf16_bits_to_float(t[0]);
-    t[1] = bf16_rne_bits(r1);
-    const float r2 = r1 - bf16_bits_to_float(t[1]);
-    t[2] = bf16_rne_bits(r2);
+// a (already scaled for the fp16 split) -> its BFT terms
+inline void bf_split_host(float a, uint16_t (&t)[BFT]) {
+    if constexpr (BFT == 2) {
+        const _Float16 h1 = (_Float16)a;
+        const _Float16 h2 = (_Float16)(a - (float)h1);
+        memcpy(&t[0], &h1, 2);
+        memcpy(&t[1], &h2, 2);
+    } else {
+        t[0] = bf16_rne_bits(a);
+        const float r1 = a - bf16_bits_to_float(t[0]);
+        t[1] = bf16_rne_bits(r1);
+        const float r2 = r1 - bf16_bits_to_float(t[1]);
+        t[BFT - 1] = bf16_rne_bits(r2);
+    }
+}
+// the power of two that takes `bound` to [2^14, 2^15] (fp16 split; 1 for the bf16 split or an empty bound)
+inline float bf_scale_for(float bound) {
+    if (BFT != 2 || !(bound > 0.f) || !(bound < 3.0e38f)) return 1.f;
+    int e;
+    frexpf(bound, &e);                                               // bound = m 2^e, m in [0.5, 1)
+    e = 15 - e;
+    return ldexpf(1.f, e > 100 ? 100 : (e < -100 ? -100 : e));       // (the scale and its reciprocal stay finite fp32 values)
 }
 
-// two values -> one dword of two bf16 (v_cvt_pk_bf16_f32); the remainders a - hi are exact in fp32
-__device__ __forceinline__ uint32_t bf16_pk_rem(float& a, float& b) {
-    const bf16x2 h = __builtin_convertvector((f32x2){a, b}, bf16x2);
-    const uint32_t u = __builtin_bit_cast(uint32_t, h);
-    a = a - __uint_as_float(u << 16);
-    b = b - __uint_as_float(u & 0xffff0000u);
-    return u;
+// two values -> one dword of two 16-bit terms; the remainders a - hi are exact in fp32
+__device__ __forceinline__ uint32_t bf_pk_rem(float& a, float& b) {
+    if constexpr (BFT == 2) {
+        const f16x2 h = __builtin_convertvector((f32x2){a, b}, f16x2);
+        a = a - (float)h[0];
+        b = b - (float)h[1];
+        return __builtin_bit_cast(uint32_t, h);
+    } else {
+        const bf16x2 h = __builtin_convertvector((f32x2){a, b}, bf16x2);
+        const uint32_t u = __builtin_bit_cast(uint32_t, h);
+        a = a - __uint_as_float(u << 16);
+        b = b - __uint_as_float(u & 0xffff0000u);
+        return u;
+    }
 }
-// four consecutive k of one row -> their 8 bytes in each of the three planes
-__device__ __forceinline__ void bf16_split3_pack4(float4 x, uint2& p0, uint2& p1, uint2& p2) {
-    p0.x = bf16_pk_rem(x.x, x.y); p0.y = bf16_pk_rem(x.z, x.w);
-    p1.x = bf16_pk_rem(x.x, x.y); p1.y = bf16_pk_rem(x.z, x.w);
-    p2.x = bf16_pk_rem(x.x, x.y); p2.y = bf16_pk_rem(x.z, x.w);
-}
-// LDS image of a split [rows x CP] operand: per (k step of 32, row tile of 16) three 1-KiB blocks (one per plane) in MFMA A
+// LDS image of a split [rows x CP] operand: per (k step of 32, row tile of 16) BFT 1-KiB blocks (one per plane) in MFMA A
 // fragment order, lane (row r, k quarter kq) at 16-byte slot kq * 16 + (r ^ kq ^ 4 * (ks & 1)): a wave's ds_read_b128 is
 // conflict-free (every 16-lane group of the instruction covers 16 distinct slots mod 16), and the XOR spreads the 8-byte stores
 // of the producers (same row, neighbouring k) over the banks.
 __device__ __forceinline__ int bf_plane_off(int RT, int ks, int tile, int kq, int row) {
-    return ((ks * RT + tile) * 3072) + ((kq * 16 + (row ^ kq ^ ((ks & 1) << 2))) << 4);
+    return ((ks * RT + tile) * BF_BLK) + ((kq * 16 + (row ^ kq ^ ((ks & 1) << 2))) << 4);
 }
+// four consecutive k of one row (for the fp16 split: already scaled) -> their 8 bytes in each plane
 __device__ __forceinline__ void bf_store4(unsigned char* planes, int RT, int t, int c4, float4 x) {
-    uint2 p0, p1, p2;
-    bf16_split3_pack4(x, p0, p1, p2);
     const int k0 = 4 * c4;
     unsigned char* d = planes + bf_plane_off(RT, k0 >> 5, t >> 4, (k0 & 31) >> 3, t & 15) + 2 * (k0 & 7);
-    *(uint2*)d = p0; *(uint2*)(d + 1024) = p1; *(uint2*)(d + 2048) = p2;
+#pragma unroll
+    for (int tm = 0; tm < BFT; ++tm) {
+        uint2 p;
+        p.x = bf_pk_rem(x.x, x.y); p.y = bf_pk_rem(x.z, x.w);
+        *(uint2*)(d + tm * 1024) = p;
+    }
+}
+// accumulator of a scaled product back to its own scale, plus a bias: u is a power of two, so the fused form rounds once, exactly
+// where (acc * u) + bias does
+__device__ __forceinline__ float bf_unscaled_plus(float acc, float u, float bias) {
+    if constexpr (BFT == 2) return __builtin_fmaf(acc, u, bias);
+    else return acc + bias;
+}
+__device__ __forceinline__ float4 bf_scaled(float4 x, const float4 s) {
+    if constexpr (BFT == 2) { x.x *= s.x; x.y *= s.y; x.z *= s.z; x.w *= s.w; }
+    return x;
 }
 __host__ __device__ inline size_t cnn_bf_region_bytes(int T, int CP, int J) {
     const size_t rows = cnn_rows(T);
-    const size_t planes = (size_t)3 * (CP / 32) * (rows / 16) * 1024, so = rows * (size_t)J * 4;
+    const size_t planes = (size_t)BFT * (CP / 32) * (rows / 16) * 1024, so = rows * (size_t)J * 4;
     return planes > so ? planes : so;                      // h1 planes, then the routed gradient's, then O [rows][J] fp32
 }
 __host__ __device__ inline size_t cnn_bf_lds_bytes(int T, int CP, int FP, int J, int L) {
@@ -140,27 +228,24 @@ __host__ __device__ inline size_t cnn_bf_lds_bytes(int T, int CP, int FP, int J,
 // One wave: for its strips ct = ct0, ct0 + ct_step, ... < ct_end:  acc[RT] = A [rows x 32 KS] (split planes in LDS) x B strip
 // (split fragments from L2: [ct][ks][term][lane] 16 bytes), then epi(i, ct, acc) with i = the wave's i-th strip. Three fragment
 // buffers in rotation over the sequence of (strip, k step) pairs: while one multiplies, the next two are in flight.
-#ifndef CNN_A_PREFETCH
-#define CNN_A_PREFETCH 1             // 0: the r04 form (a row tile's A fragments read right in front of its MFMAs), for A/B builds
-#endif
 // The first three B fragment sets of a wave's (strip, k step) sequence, loaded ahead of the barrier in front of the contraction
 // (bf_prefill) so that their L2 round trip passes while the workgroup's slower waves finish the previous phase.
-struct BfPre { uint4 x[3], y[3], z[3]; };
+struct BfPre { uint4 x[BFT], y[BFT], z[BFT]; };
 __device__ __forceinline__ void bf_prefill(BfPre& p, const uint4* Bfrag, const int KS, const int ct0, const int ct_step, const int ct_end) {
     const int lane = threadIdx.x & 63;
     const int nstr = ct0 < ct_end ? (ct_end - ct0 + ct_step - 1) / ct_step : 0;
     const int Q = nstr * KS;
     if (Q == 0) return;
     const uint4* bp = Bfrag + lane;
-    auto fill = [&](uint4 (&b)[3], int q) {
+    auto fill = [&](uint4 (&b)[BFT], int q) {
         q = min(q, Q - 1);
         const int i = q / KS, ks = q - i * KS;
-        const size_t at = ((size_t)(ct0 + i * ct_step) * KS + ks) * 192;
-        b[0] = bp[at]; b[1] = bp[at + 64]; b[2] = bp[at + 128];
+        const size_t at = ((size_t)(ct0 + i * ct_step) * KS + ks) * BF_FRAG;
+#pragma unroll
+        for (int tm = 0; tm < BFT; ++tm) b[tm] = bp[at + 64 * tm];
     };
     fill(p.x, 0); fill(p.y, 1); fill(p.z, 2);
 }
-#if CNN_A_PREFETCH
 // RTC <= RT: only the first RTC row tiles hold data and are multiplied (the backward's compacted rows). A compile-time count: with
 // a run-time one the general instantiations of the single-launch kernels produced zeros for every row tile from the third on
 // (any run-time value, reproducibly; the shape-pinned instantiation did not; r05_experiments.md) -- bf_strips_rows dispatches.
@@ -174,48 +259,41 @@ __device__ __forceinline__ void bf_strips_c(const unsigned char* planes, const u
     if (Q == 0) return;
     const uint4* bp = Bfrag + lane;
     const int lo0 = (kq * 16 + (row ^ kq)) << 4, lo1 = (kq * 16 + (row ^ kq ^ 4)) << 4;
-    uint4 (&bx)[3] = pre.x, (&by)[3] = pre.y, (&bz)[3] = pre.z;   // the three fragment buffers in rotation ARE the caller's prefilled ones
+    uint4 (&bx)[BFT] = pre.x, (&by)[BFT] = pre.y, (&bz)[BFT] = pre.z;   // the three fragment buffers in rotation ARE the caller's prefilled ones
     f32x4 acc[RT];
     // The A fragments of row tile rt + 1 (at a block's last row tile: of the NEXT block's first) are read from LDS while row tile
     // rt multiplies: two register sets in alternation. Up to r04 a row tile's three reads were issued right in front of its six
     // MFMAs and waited for there -- 8-10 exposed LDS round trips per block of 36 MFMAs (r05_experiments.md).
-    uint4 aa[2][3];
-    auto a_base = [&](int ks) { return planes + ks * (RT * 3072) + ((ks & 1) ? lo1 : lo0); };
-    auto read_a = [&](uint4 (&a)[3], const unsigned char* ap, int rt) {
-        a[0] = *(const uint4*)(ap + rt * 3072); a[1] = *(const uint4*)(ap + rt * 3072 + 1024); a[2] = *(const uint4*)(ap + rt * 3072 + 2048);
+    uint4 aa[2][BFT];
+    auto a_base = [&](int ks) { return planes + ks * (RT * BF_BLK) + ((ks & 1) ? lo1 : lo0); };
+    auto read_a = [&](uint4 (&a)[BFT], const unsigned char* ap, int rt) {
+#pragma unroll
+        for (int tm = 0; tm < BFT; ++tm) a[tm] = *(const uint4*)(ap + rt * BF_BLK + tm * 1024);
     };
-    auto fill = [&](uint4 (&b)[3], int q) {
+    auto fill = [&](uint4 (&b)[BFT], int q) {
         q = min(q, Q - 1);
         const int i = q / KS, ks = q - i * KS;
-        const size_t at = ((size_t)(ct0 + i * ct_step) * KS + ks) * 192;
-        b[0] = bp[at]; b[1] = bp[at + 64]; b[2] = bp[at + 128];
+        const size_t at = ((size_t)(ct0 + i * ct_step) * KS + ks) * BF_FRAG;
+#pragma unroll
+        for (int tm = 0; tm < BFT; ++tm) b[tm] = bp[at + 64 * tm];
     };
-    auto mult = [&](const uint4 (&b)[3], const int q) {
+    auto mult = [&](const uint4 (&b)[BFT], const int q) {
         const int i = q / KS, ks = q - i * KS;
         if (ks == 0) {
 #pragma unroll
             for (int rt = 0; rt < RT; ++rt) acc[rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
         }
-        const bf16x8 b1 = __builtin_bit_cast(bf16x8, b[0]), b2 = __builtin_bit_cast(bf16x8, b[1]), b3 = __builtin_bit_cast(bf16x8, b[2]);
         const unsigned char* ap = a_base(ks);
         const unsigned char* ap_next = a_base(ks + 1 == KS ? 0 : ks + 1);
 #pragma unroll
         for (int rt = 0; rt < RTC; ++rt) {
             if (rt + 1 < RTC) read_a(aa[(rt + 1) & 1], ap, rt + 1);
             else if (q + 1 < Q) read_a(aa[(rt + 1) & 1], ap_next, 0);
-            const bf16x8 a1 = __builtin_bit_cast(bf16x8, aa[rt & 1][0]), a2 = __builtin_bit_cast(bf16x8, aa[rt & 1][1]),
-                         a3 = __builtin_bit_cast(bf16x8, aa[rt & 1][2]);
-            f32x4 c = acc[rt];                                   // (small terms first)
-            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a3, b1, c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b3, c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2, b2, c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2, b1, c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b2, c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b1, c, 0, 0, 0);
-            acc[rt] = c;
+            acc[rt] = bf_product(acc[rt], aa[rt & 1], b);          // (small terms first)
         }
         if constexpr (RTC & 1) {                                 // (odd tile count: the next block's first set sits in aa[1])
-            aa[0][0] = aa[1][0]; aa[0][1] = aa[1][1]; aa[0][2] = aa[1][2];
+#pragma unroll
+            for (int tm = 0; tm < BFT; ++tm) aa[0][tm] = aa[1][tm];
         }
         if (ks == KS - 1) epi(i, ct0 + i * ct_step, acc);
     };
@@ -234,63 +312,6 @@ __device__ __forceinline__ void bf_strips_c(const unsigned char* planes, const u
         }
     }
 }
-#else
-template <int RT, int RTC = RT, bool PRE = false, typename Epi>
-__device__ __forceinline__ void bf_strips_c(const unsigned char* planes, const uint4* Bfrag, const int KS, const int ct0,
-                                          const int ct_step, const int ct_end, Epi&& epi, BfPre&) {
-    const int lane = threadIdx.x & 63, row = lane & 15, kq = lane >> 4;
-    const int nstr = ct0 < ct_end ? (ct_end - ct0 + ct_step - 1) / ct_step : 0;
-    const int Q = nstr * KS;
-    if (Q == 0) return;
-    const uint4* bp = Bfrag + lane;
-    const int lo0 = (kq * 16 + (row ^ kq)) << 4, lo1 = (kq * 16 + (row ^ kq ^ 4)) << 4;
-    uint4 bx[3], by[3], bz[3];
-    f32x4 acc[RT];
-    auto fill = [&](uint4 (&b)[3], int q) {
-        q = min(q, Q - 1);
-        const int i = q / KS, ks = q - i * KS;
-        const size_t at = ((size_t)(ct0 + i * ct_step) * KS + ks) * 192;
-        b[0] = bp[at]; b[1] = bp[at + 64]; b[2] = bp[at + 128];
-    };
-    auto mult = [&](const uint4 (&b)[3], const int q) {
-        const int i = q / KS, ks = q - i * KS;
-        if (ks == 0) {
-#pragma unroll
-            for (int rt = 0; rt < RT; ++rt) acc[rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        }
-        const bf16x8 b1 = __builtin_bit_cast(bf16x8, b[0]), b2 = __builtin_bit_cast(bf16x8, b[1]), b3 = __builtin_bit_cast(bf16x8, b[2]);
-        const unsigned char* ap = planes + ks * (RT * 3072) + ((ks & 1) ? lo1 : lo0);
-#pragma unroll
-        for (int rt = 0; rt < RT; ++rt) {
-            const bf16x8 a1 = __builtin_bit_cast(bf16x8, *(const uint4*)(ap + rt * 3072));
-            const bf16x8 a2 = __builtin_bit_cast(bf16x8, *(const uint4*)(ap + rt * 3072 + 1024));
-            const bf16x8 a3 = __builtin_bit_cast(bf16x8, *(const uint4*)(ap + rt * 3072 + 2048));
-            f32x4 c = acc[rt];                                   // (small terms first)
-            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a3, b1, c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b3, c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2, b2, c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2, b1, c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b2, c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b1, c, 0, 0, 0);
-            acc[rt] = c;
-        }
-        if (ks == KS - 1) epi(i, ct0 + i * ct_step, acc);
-    };
-    fill(bx, 0); fill(by, 1); fill(bz, 2);
-    for (int q = 0; q < Q; q += 3) {
-        mult(bx, q);
-        if (q + 3 < Q) fill(bx, q + 3);
-        if (q + 1 < Q) {
-            mult(by, q + 1);
-            if (q + 4 < Q) fill(by, q + 4);
-        }
-        if (q + 2 < Q) {
-            mult(bz, q + 2);
-            if (q + 5 < Q) fill(bz, q + 5);
-        }
-    }
-}
-#endif
 // bf_strips_c for the first rtc (run-time, 0..RT) row tiles: one instantiation per count
 template <int RT, bool PRE, int R = 1, typename Epi>
 __device__ __forceinline__ void bf_strips_rows(const unsigned char* planes, const uint4* Bfrag, const int KS, const int ct0,
@@ -324,60 +345,55 @@ __device__ __forceinline__ void bf_strips(const unsigned char* planes, const uin
     const int Q = nstr * KS;
     if (Q == 0) return;
     const int lo0 = (kq * 16 + (row ^ kq)) << 4, lo1 = (kq * 16 + (row ^ kq ^ 4)) << 4;
-    bf_u32x4 bb[NB][3];
-    [[maybe_unused]] bf_u32x4 aa[2][RT][3];
+    bf_u32x4 bb[NB][BFT];
+    [[maybe_unused]] bf_u32x4 aa[2][RT][BFT];
     f32x4 acc[RT];
-    const bf_u32x4* const bp = (const bf_u32x4*)Bfrag + (size_t)ct0 * KS * 192 + lane;
+    const bf_u32x4* const bp = (const bf_u32x4*)Bfrag + (size_t)ct0 * KS * BF_FRAG + lane;
     // elements between the wave's consecutive strips; a caller that wants ONE strip passes a huge step: nstr is 1 then and the
-    // stride is never applied, so it is left at zero instead of overflowing an int (ct_step * KS * 192)
-    const int fstrip = nstr > 1 ? ct_step * KS * 192 : 0;
-    auto fill = [&](bf_u32x4 (&b)[3], const int off) { b[0] = bp[off]; b[1] = bp[off + 64]; b[2] = bp[off + 128]; };
-    auto a_base = [&](int ks) { return planes + ks * (RT * 3072) + ((ks & 1) ? lo1 : lo0); };
-    auto read_a = [&](bf_u32x4 (&a)[RT][3], int ks) {
+    // stride is never applied, so it is left at zero instead of overflowing an int (ct_step * KS * BF_FRAG)
+    const int fstrip = nstr > 1 ? ct_step * KS * BF_FRAG : 0;
+    auto fill = [&](bf_u32x4 (&b)[BFT], const int off) {
+#pragma unroll
+        for (int tm = 0; tm < BFT; ++tm) b[tm] = bp[off + 64 * tm];
+    };
+    auto a_base = [&](int ks) { return planes + ks * (RT * BF_BLK) + ((ks & 1) ? lo1 : lo0); };
+    auto read_a = [&](bf_u32x4 (&a)[RT][BFT], int ks) {
         const unsigned char* ap = a_base(ks);
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
-            for (int t = 0; t < 3; ++t) a[rt][t] = *(const bf_u32x4*)(ap + rt * 3072 + t * 1024);
+            for (int t = 0; t < BFT; ++t) a[rt][t] = *(const bf_u32x4*)(ap + rt * BF_BLK + t * 1024);
     };
-    auto mult = [&](bf_u32x4 (&b)[3], const int mks) {
+    auto mult = [&](bf_u32x4 (&b)[BFT], const int mks) {
         if (mks == 0) {
 #pragma unroll
             for (int rt = 0; rt < RT; ++rt) acc[rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
         }
-        const bf16x8 b1 = __builtin_bit_cast(bf16x8, b[0]), b2 = __builtin_bit_cast(bf16x8, b[1]), b3 = __builtin_bit_cast(bf16x8, b[2]);
         const unsigned char* ap = a_base(mks);
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) {
-            const bf16x8 a1 = __builtin_bit_cast(bf16x8, *(const uint4*)(ap + rt * 3072));
-            const bf16x8 a2 = __builtin_bit_cast(bf16x8, *(const uint4*)(ap + rt * 3072 + 1024));
-            const bf16x8 a3 = __builtin_bit_cast(bf16x8, *(const uint4*)(ap + rt * 3072 + 2048));
-            f32x4 c = acc[rt];                                   // (small terms first)
-            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a3, b1, c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b3, c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2, b2, c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2, b1, c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b2, c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b1, c, 0, 0, 0);
-            acc[rt] = c;
+            uint4 a[BFT];
+#pragma unroll
+            for (int tm = 0; tm < BFT; ++tm) a[tm] = *(const uint4*)(ap + rt * BF_BLK + tm * 1024);
+            acc[rt] = bf_product(acc[rt], a, b);                   // (small terms first)
         }
     };
-    auto mult_pipe = [&](bf_u32x4 (&b)[3], bf_u32x4 (&a)[RT][3], bf_u32x4 (&an)[RT][3], const bool more, const int mks) {
+    auto mult_pipe = [&](bf_u32x4 (&b)[BFT], bf_u32x4 (&a)[RT][BFT], bf_u32x4 (&an)[RT][BFT], const bool more, const int mks) {
         if (mks == 0) {
 #pragma unroll
             for (int rt = 0; rt < RT; ++rt) acc[rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
         }
         if (more) read_a(an, mks + 1 == KS ? 0 : mks + 1);
-        const bf16x8 b1 = __builtin_bit_cast(bf16x8, b[0]), b2 = __builtin_bit_cast(bf16x8, b[1]), b3 = __builtin_bit_cast(bf16x8, b[2]);
-#define BF_TERM(AT, BT) _Pragma("unroll") for (int rt = 0; rt < RT; ++rt) \
-            acc[rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[rt][AT]), BT, acc[rt], 0, 0, 0);
-        BF_TERM(2, b1) BF_TERM(0, b3) BF_TERM(1, b2) BF_TERM(1, b1) BF_TERM(0, b2) BF_TERM(0, b1)     // (small terms first)
-#undef BF_TERM
+#pragma unroll
+        for (int i = 0; i < BF_NCROSS; ++i)                         // (small terms first; term by term across the row tiles)
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt)
+                acc[rt] = bf_mfma(__builtin_bit_cast(uint4, a[rt][bf_cross_a(i)]), __builtin_bit_cast(uint4, b[bf_cross_b(i)]), acc[rt]);
     };
     // (strip, k step) of the next block to fill (as an element offset) and of the next block to multiply, advanced in the loop
     // body itself (as state captured by the lambdas it went to scratch memory)
     int foff = 0, fks = 0, mi = 0, mks = 0;
-#define BF_FILL(B) { fill(B, foff); foff += 192; if (++fks == KS) { fks = 0; foff += fstrip - KS * 192; } }
+#define BF_FILL(B) { fill(B, foff); foff += BF_FRAG; if (++fks == KS) { fks = 0; foff += fstrip - KS * BF_FRAG; } }
 #pragma unroll
     for (int u = 0; u < NB; ++u)
         if (u < Q) BF_FILL(bb[u])
@@ -554,7 +570,7 @@ __device__ __forceinline__ int cnn_route_rows(const CnnNet& net, const int rows,
         const int n_ne = sTot[2] + sTot[3];
         n_rows_routed = n_ne;
         const int last = max(sStart[rows] - 1, 0);
-        const float4* We4 = (const float4*)net.We;                   // [FP][G4]
+        const float4* We4 = (const float4*)(BF ? net.WeG : net.We);  // [FP][G4] (split-precision kernels: scaled per channel)
         auto put = [&](int t, int c4, float4 acc) {
             if constexpr (BF) bf_store4((unsigned char*)sD, rows / 16, t, c4, acc);   // split planes (AS unused)
             else {
@@ -633,7 +649,7 @@ __device__ __forceinline__ int cnn_route_rows(const CnnNet& net, const int rows,
         // unconditionally (clamped index, zero coefficient past the row's end): 12 independent L2 loads in flight
         const int G4 = CP / 4, items = rows * G4;
         const int last = max(sStart[rows] - 1, 0);
-        const float4* We4 = (const float4*)net.We;                   // [FP][G4]
+        const float4* We4 = (const float4*)(BF ? net.WeG : net.We);  // [FP][G4] (split-precision kernels: scaled per channel)
         for (int item0 = tid; item0 < items; item0 += NT * 3) {
             int t[3], c4[3], rs[3], kk[3];
             float4 v[3][4];
@@ -781,6 +797,7 @@ __device__ __forceinline__ void cnn_body(const CnnArgs& a_, const int bx, const 
         const int g4 = tid % G4, tr = tid / G4;
         if (tr < RPR) {
             const float4 bias4 = *(const float4*)(net.bc + 4 * g4);
+            [[maybe_unused]] const float4 sch4 = *(const float4*)(net.sch + 4 * g4);
             for (int t0 = tr; t0 < rows; t0 += 2 * RPR) {
                 float4 wv[2][KT];
 #pragma unroll
@@ -941,7 +958,7 @@ __host__ __device__ inline size_t cnn_conv_x_bytes(int T) { return (size_t)(cnn_
 // the lane's share of the one-hot fragments of position p: letters 8 kq .. 8 kq + 7
 __device__ __forceinline__ uint4 conv_x_fragment(int letter, int kq) {
     const unsigned d = (unsigned)(letter - 8 * kq);
-    const uint32_t one = 0x3F80u << (16 * (d & 1u));                // bf16 1.0 in the half the letter selects
+    const uint32_t one = (BFT == 2 ? 0x3C00u : 0x3F80u) << (16 * (d & 1u));   // 1.0 (fp16 / bf16) in the half the letter selects
     const unsigned sel = d < 8u ? (d >> 1) : 4u;
     return make_uint4(sel == 0u ? one : 0u, sel == 1u ? one : 0u, sel == 2u ? one : 0u, sel == 3u ? one : 0u);
 }
@@ -956,29 +973,28 @@ __device__ __forceinline__ ConvUnit conv_unit(int wave, int NW, int NTILE, int R
     return ConvUnit{tile, sub * RT / nsub, (sub + 1) * RT / nsub};
 }
 template <int KT>
-__device__ __forceinline__ void conv_load_a(uint4 (&af)[KT][3], const CnnNet& net, int tile) {
+__device__ __forceinline__ void conv_load_a(uint4 (&af)[KT][BFT], const CnnNet& net, int tile) {
     const int lane = threadIdx.x & 63;
 #pragma unroll
     for (int kp = 0; kp < KT; ++kp)
 #pragma unroll
-        for (int tm = 0; tm < 3; ++tm) af[kp][tm] = net.WcA[(((size_t)tile * KT + kp) * 3 + tm) * 64 + lane];
+        for (int tm = 0; tm < BFT; ++tm) af[kp][tm] = net.WcA[(((size_t)tile * KT + kp) * BFT + tm) * 64 + lane];
 }
 template <int RT, int KT>
-__device__ __forceinline__ void conv_tile_rows(const uint4 (&af)[KT][3], const CnnNet& net, const uint4* sX, unsigned char* sP, uint32_t* sG,
+__device__ __forceinline__ void conv_tile_rows(const uint4 (&af)[KT][BFT], const CnnNet& net, const uint4* sX, unsigned char* sP, uint32_t* sG,
                                                const int tile, const int rt_lo, const int rt_hi, const int T, const int BW) {
     const int lane = threadIdx.x & 63, n = lane & 15, kq = lane >> 4;
     const int g4 = tile * 4 + kq;                                    // the lane's 4 channels: 4 g4 .. 4 g4 + 3
-    const float4 bias4 = *(const float4*)(net.bc + 4 * g4);
+    const float4 bias4 = bf_scaled(*(const float4*)(net.bc + 4 * g4), *(const float4*)(net.sch + 4 * g4));   // (the table fragments hold sch[o] * table)
     for (int rt = rt_lo; rt < rt_hi; ++rt) {
         const int t = rt * 16 + n;
         const uint4* xp = sX + (size_t)t * 4 + kq;                   // fragment of tap kp: position t + kp
         f32x4 acc = {bias4.x, bias4.y, bias4.z, bias4.w};
 #pragma unroll
         for (int kp = 0; kp < KT; ++kp) {
-            const bf16x8 xb = __builtin_bit_cast(bf16x8, xp[4 * kp]);
-            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af[kp][2]), xb, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af[kp][1]), xb, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af[kp][0]), xb, acc, 0, 0, 0);
+            const uint4 xb = xp[4 * kp];
+#pragma unroll
+            for (int tm = BFT - 1; tm >= 0; --tm) acc = bf_mfma(af[kp][tm], xb, acc);   // (small terms first)
         }
         const bool live = t < T;
         float4 x;
@@ -1019,7 +1035,7 @@ __device__ __forceinline__ void cnn_body_bf(const CnnArgs& a_, const int bx, con
     const int FT = FP / 16, ct_mid = (FT + 1) / 2;
     const int ct_lo = (halved && part == a_shape.n_nets) ? ct_mid : 0, ct_hi = (halved && part < a_shape.n_nets) ? ct_mid : FT;
     unsigned char* sP = smem_raw;                                   // split planes of h1, later of the routed gradient; O
-    const size_t region = PABP ? (size_t)3 * 3 * RT * 1024 : cnn_bf_region_bytes(T, CP, J);
+    const size_t region = PABP ? cnn_bf_region_bytes(92, 96, 100) : cnn_bf_region_bytes(T, CP, J);
     uint32_t* sG = (uint32_t*)(smem_raw + region);                  // [rows][BW] bit o of word: h1[t][o] > 0
     const int BWF = (FP + 31) / 32;
     uint32_t* sB = (uint32_t*)sP;                                   // [rows][BWF] route bitmap (in the region: h1 is dead by then)
@@ -1047,7 +1063,7 @@ __device__ __forceinline__ void cnn_body_bf(const CnnArgs& a_, const int bx, con
     for (int l = tid; l < g.L + CNN_MAX_K; l += NT) sSt[l] = l < g.L ? min((int)a.idx[(size_t)b * g.Ls + g.sh + l], 19) : 0;
     // the convolution's operands: the wave's table fragments (independent of the state: in flight while the letters land) and the
     // one-hot fragment of every position p < rows + KT - 1 (positions past the sequence: letter 0, their rows are dead)
-    [[maybe_unused]] uint4 af[KT][3];
+    [[maybe_unused]] uint4 af[KT][BFT];
     [[maybe_unused]] const ConvUnit cu = conv_unit(wave, NT / 64, CP / 16, RT);
     if constexpr (CONV_MFMA) {
         if constexpr (!PABP) { if (cu.tile < CP / 16) conv_load_a<KT>(af, net, cu.tile); }
@@ -1088,6 +1104,7 @@ __device__ __forceinline__ void cnn_body_bf(const CnnArgs& a_, const int bx, con
         const int g4 = tid % G4, tr = tid / G4;
         if (tr < RPR) {
             const float4 bias4 = *(const float4*)(net.bc + 4 * g4);
+            [[maybe_unused]] const float4 sch4 = *(const float4*)(net.sch + 4 * g4);
             for (int t0 = tr; t0 < rows; t0 += 2 * RPR) {
                 float4 wv[2][KT];
 #pragma unroll
@@ -1108,7 +1125,7 @@ __device__ __forceinline__ void cnn_body_bf(const CnnArgs& a_, const int bx, con
                     x.x = live ? fmaxf(x.x, 0.f) : 0.f; x.y = live ? fmaxf(x.y, 0.f) : 0.f;
                     x.z = live ? fmaxf(x.z, 0.f) : 0.f; x.w = live ? fmaxf(x.w, 0.f) : 0.f;
                     const uint32_t nib = (x.x > 0.f ? 1u : 0u) | (x.y > 0.f ? 2u : 0u) | (x.z > 0.f ? 4u : 0u) | (x.w > 0.f ? 8u : 0u);
-                    bf_store4(sP, RT, t, g4, x);
+                    bf_store4(sP, RT, t, g4, bf_scaled(x, sch4));
                     if (nib) atomicOr(&sG[t * BW + (g4 >> 3)], nib << (4 * (g4 & 7)));
                 }
             }
@@ -1122,6 +1139,7 @@ __device__ __forceinline__ void cnn_body_bf(const CnnArgs& a_, const int bx, con
     PPDE_STAMP(a.dbg, sb + 2, stamp);
     // ---- pre2 = h1 We^T + be (six bf16 cross-term MFMAs per block); relu and the running max over t straight from the
     //      accumulators (strict >, rows ascending: the first index wins, like torch.max)
+    const float un_f = net.un_f;
     auto fwd_epi = [&](int, int ct, const f32x4 (&acc)[RT]) {
         const int f = ct * 16 + (lane & 15);
         const float bias = sM[f];
@@ -1132,7 +1150,7 @@ __device__ __forceinline__ void cnn_body_bf(const CnnArgs& a_, const int bx, con
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int t = rt * 16 + (lane >> 4) * 4 + j;
-                const float v = fmaxf(acc[rt][j] + bias, 0.f);
+                const float v = fmaxf(bf_unscaled_plus(acc[rt][j], un_f, bias), 0.f);
                 if (t < T && v > m) { m = v; ts = t; }
             }
         }
@@ -1148,7 +1166,8 @@ __device__ __forceinline__ void cnn_body_bf(const CnnArgs& a_, const int bx, con
     __syncthreads();
 
     PPDE_STAMP(a.dbg, sb + 3, stamp);
-    // ---- out = bd + wd . m  (fixed tree); routing coefficients replace m in LDS (as cnn_body)
+    // ---- out = bd + wd . m  (fixed tree); routing coefficients replace m in LDS (as cnn_body; two-term split: scaled by g_sc)
+    const float g_sc = BFT == 2 ? a.gsc : 1.f, g_un = BFT == 2 ? net.un_b * a.gun : 1.f;
     {
         float s = 0.f;
         float cf[2] = {0.f, 0.f};
@@ -1159,7 +1178,7 @@ __device__ __forceinline__ void cnn_body_bf(const CnnArgs& a_, const int bx, con
             if (f >= FP) break;
             const float wv = f < F ? wdf[k] : 0.f, mf = sM[f];
             s += wv * mf;
-            cf[k] = (f < F && mf > 0.f) ? a.scale * wv : 0.f;
+            cf[k] = (f < F && mf > 0.f) ? (a.scale * wv) * g_sc : 0.f;
         }
         if (a_shape.want_grad)
             for (int w = tid; w < rows * BWF; w += NT) sB[w] = 0u;  // route bitmap (every wave has left the h1 planes)
@@ -1208,7 +1227,7 @@ __device__ __forceinline__ void cnn_body_bf(const CnnArgs& a_, const int bx, con
             for (int rt = 0; rt < RT; ++rt) {
                 if (rt >= rtc) break;
 #pragma unroll
-                for (int q = 0; q < 4; ++q) sO[(rt * 16 + (lane >> 4) * 4 + q) * OS + j] = keep[i][rt][q];
+                for (int q = 0; q < 4; ++q) sO[(rt * 16 + (lane >> 4) * 4 + q) * OS + j] = BFT == 2 ? keep[i][rt][q] * g_un : keep[i][rt][q];
             }
         }
     }
@@ -1280,11 +1299,11 @@ __host__ __device__ inline size_t cnn_fwd_chunk_lds(int CP) { return (size_t)CNN
 __host__ __device__ inline int cnn_bf_fwd_rt(int CP) { return CP <= 128 ? 4 : 3; }
 __host__ __device__ inline size_t cnn_bf_fwd_chunk_lds(int CP, int FP) {
     const size_t RT = cnn_bf_fwd_rt(CP);
-    return RT * 3 * (CP / 32) * 1024 + RT * 16 * ((CP + 31) / 32) * 4 + 256 + (size_t)FP * 4;     // (+ letters, + the second layer's bias)
+    return RT * BFT * (CP / 32) * 1024 + RT * 16 * ((CP + 31) / 32) * 4 + 256 + (size_t)FP * 4;     // (+ letters, + the second layer's bias)
 }
 __host__ __device__ inline size_t cnn_bf_bwd_chunk_lds(int CP, int FP, int J) {
     const size_t rows = CNN_BCH_RT * 16;
-    const size_t planes = (size_t)CNN_BCH_RT * 3 * (CP / 32) * 1024, so = rows * J * 4;
+    const size_t planes = (size_t)CNN_BCH_RT * BFT * (CP / 32) * 1024, so = rows * J * 4;
     return (planes > so ? planes : so) + rows * ((CP + 31) / 32) * 4 + (size_t)FP * 12 + 512;
 }
 __host__ __device__ inline size_t cnn_bwd_chunk_lds(int CP, int FP, int J) {
@@ -1311,6 +1330,8 @@ __device__ __forceinline__ void cnn_build_rows(const CnnNet& net, const uint8_t*
         const int tr = tid / G4;
         if (G4 < NTB && tr >= RPR) continue;
         const float4 bias4 = *(const float4*)(net.bc + 4 * g4);
+        [[maybe_unused]] float4 sch4 = make_float4(1.f, 1.f, 1.f, 1.f);
+        if constexpr (WANT_H && BF) sch4 = *(const float4*)(net.sch + 4 * g4);
         for (int r0 = (G4 < NTB ? tr : 0); r0 < rows; r0 += 2 * RPR) {
             float4 wv[2][KT];
 #pragma unroll
@@ -1332,7 +1353,7 @@ __device__ __forceinline__ void cnn_build_rows(const CnnNet& net, const uint8_t*
                 const bool live = t >= 0 && t < T;
                 x.x = live ? fmaxf(x.x, 0.f) : 0.f; x.y = live ? fmaxf(x.y, 0.f) : 0.f;
                 x.z = live ? fmaxf(x.z, 0.f) : 0.f; x.w = live ? fmaxf(x.w, 0.f) : 0.f;
-                if constexpr (WANT_H && BF) bf_store4((unsigned char*)sH, rows / 16, r, g4, x);   // split planes (AS unused)
+                if constexpr (WANT_H && BF) bf_store4((unsigned char*)sH, rows / 16, r, g4, bf_scaled(x, sch4));   // split planes (AS unused)
                 else if constexpr (WANT_H) {
                     float* hp = sH + r * AS + 4 * g4;
                     *(float2*)hp = make_float2(x.x, x.y);
@@ -1369,7 +1390,7 @@ __global__ __launch_bounds__(NT, 2) void k_cnn_fwd_chunk(CnnChunkArgs ca) {
     const int AS = cnn_astride(CP), KSP = CP / 4;
     const int BW = (CP + 31) / 32;
     float* sH = (float*)smem_raw;                                    // h1 [rows][AS] fp32, or its three bf16 planes (BF)
-    uint32_t* sG = BF ? (uint32_t*)(smem_raw + (size_t)RT * 3 * (CP / 32) * 1024)
+    uint32_t* sG = BF ? (uint32_t*)(smem_raw + (size_t)RT * BFT * (CP / 32) * 1024)
                       : (uint32_t*)(sH + (size_t)rows * AS);         // [rows][BW] gate bits of this chunk's rows
     uint8_t* sSt = (uint8_t*)(sG + (size_t)rows * BW);               // letters t0 .. t0 + rows + KT (relative index)
     [[maybe_unused]] float* sBe = (float*)(sSt + 256);               // (BF) [FP] the second layer's bias: bf_strips' epilogue may not load from global memory
@@ -1405,7 +1426,7 @@ __global__ __launch_bounds__(NT, 2) void k_cnn_fwd_chunk(CnnChunkArgs ca) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int t = t0 + rt * 16 + (lane >> 4) * 4 + j;
-                const float v = fmaxf(acc[rt][j] + bias, 0.f);
+                const float v = BF ? fmaxf(bf_unscaled_plus(acc[rt][j], net.un_f, bias), 0.f) : fmaxf(acc[rt][j] + bias, 0.f);
                 if (t < T && v > m) { m = v; ts = t; }
             }
         }
@@ -1451,7 +1472,7 @@ __global__ __launch_bounds__(NT, 2) void k_cnn_bwd_chunk(CnnChunkArgs ca) {
     const int J = SHAPE ? SH::J : a.J, JP = SHAPE ? SH::JP : a.JP, AS = cnn_astride(CP), KSP = CP / 4;
     const int OS = J, BW = (CP + 31) / 32;
     float* sD = (float*)smem_raw;                                     // [rows][AS] routed gradient (BF: its three bf16 planes)
-    const size_t bf_planes = (size_t)RT * 3 * (CP / 32) * 1024, bf_o = (size_t)rows * OS * 4, bf_region = bf_planes > bf_o ? bf_planes : bf_o;
+    const size_t bf_planes = (size_t)RT * BFT * (CP / 32) * 1024, bf_o = (size_t)rows * OS * 4, bf_region = bf_planes > bf_o ? bf_planes : bf_o;
     float* sO = BF ? sD : sD + (size_t)rows * AS;                     // [rows][J] (BF: in the planes' storage, once they are dead)
     uint32_t* sG = BF ? (uint32_t*)(smem_raw + bf_region) : (uint32_t*)(sO + (size_t)rows * OS);               // [rows][BW]
     float* sM = (float*)(sG + (size_t)rows * BW);                     // [FP] coefficients
@@ -1480,7 +1501,7 @@ __global__ __launch_bounds__(NT, 2) void k_cnn_bwd_chunk(CnnChunkArgs ca) {
         }
         const float wdf = f < F ? net.wd[f] : 0.f;
         part += wdf * m;
-        sM[f] = (f < F && m > 0.f) ? a.scale * wdf : 0.f;
+        sM[f] = (f < F && m > 0.f) ? ((BF && BFT == 2) ? (a.scale * wdf) * a.gsc : a.scale * wdf) : 0.f;
         sTs[f] = ts;
     }
     float tot;
@@ -1538,7 +1559,7 @@ __global__ __launch_bounds__(NT, 2) void k_cnn_bwd_chunk(CnnChunkArgs ca) {
 #pragma unroll
                 for (int rt = 0; rt < RT; ++rt) {
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) sO[(rt * 16 + (lane >> 4) * 4 + q) * OS + j] = kp[rt][q];
+                    for (int q = 0; q < 4; ++q) sO[(rt * 16 + (lane >> 4) * 4 + q) * OS + j] = BFT == 2 ? kp[rt][q] * (net.un_b * a.gun) : kp[rt][q];
                 }
             }
         };

@@ -310,6 +310,20 @@ static int ensure_cnn_scratch(ppde_model* m, int n) {
     return PPDE_OK;
 }
 
+// gsc = 2^-ceil(log2 |scale|) and its reciprocal: |scale| * gsc <= 1, so the static bound behind CnnNet.sc_g (taken at |scale| = 1)
+// holds for the routed gradient of this launch (cnn.h, two-term split)
+static void cnn_grad_scale(float scale, float* gsc, float* gun) {
+    const float a = fabsf(scale);
+    int e = 0;
+    if (a > 0.f && a < 3.0e38f) {
+        const float mnt = frexpf(a, &e);                              // a = mnt 2^e, mnt in [0.5, 1)
+        if (mnt == 0.5f) --e;                                         // (a power of two: a * 2^-(e-1) = 1)
+    }
+    e = e > 100 ? 100 : (e < -100 ? -100 : e);
+    *gsc = ldexpf(1.f, -e);
+    *gun = ldexpf(1.f, e);
+}
+
 static int launch_cnn(const ppde_model* m, const States& st, int n, const EvalTargets& t, int want_grad,
                       float scale, hipStream_t s, int b_off = 0, int n_sub = -1) {
     if (n_sub < 0) n_sub = n;
@@ -319,6 +333,7 @@ static int launch_cnn(const ppde_model* m, const States& st, int n, const EvalTa
     a.n_nets = m->n_nets; a.n_parts = cnn_parts(m); a.C = m->C; a.CP = m->CP; a.K = m->K; a.KT = m->KT; a.F = m->F; a.FP = m->FP; a.T = m->T; a.J = m->J; a.JP = m->JP;
     a.idx = st.rows; a.gradC = t.gradC; a.fitC = t.fitC;
     a.slot = t.slot; a.n = n; a.want_grad = want_grad; a.scale = scale;
+    cnn_grad_scale(scale, &a.gsc, &a.gun);
     a.g = m->g;
     if (!cnn_single_launch(m)) {
         // long sequences: forward chunks, then merge + backward chunks
@@ -482,6 +497,7 @@ static int launch_experts_fused(const ppde_model* m, const States& st, int n, co
     c.n_nets = m->n_nets; c.n_parts = cnn_parts(m); c.C = m->C; c.CP = m->CP; c.K = m->K; c.KT = m->KT; c.F = m->F; c.FP = m->FP; c.T = m->T; c.J = m->J; c.JP = m->JP;
     c.idx = st.rows; c.gradC = t.gradC; c.fitC = t.fitC;
     c.slot = t.slot; c.n = n; c.want_grad = 1; c.scale = scale;
+    cnn_grad_scale(scale, &c.gsc, &c.gun);
     c.g = m->g;
     PottsArgs& p = a.p;
     p.b_off = b_off; p.n_sub = n_sub; p.dbg = t.dbg; p.dbg_wg_base = 1024;
@@ -871,18 +887,55 @@ int ppde_model_set_cnn(ppde_model* m, int n_nets, int C, int K, int F, const flo
         if ((rc = up(be, &p))) return rc; nt.be = p;
         if ((rc = up(wd, &p))) return rc; nt.wd = p;
         if ((rc = up(Wf, &p))) return rc; nt.Wf = p;
-        // the same two matrices as MFMA B fragments of their exact three-term bf16 split (cnn.h bf_strips):
-        // [strip of 16 columns][k step of 32][term][lane] x 8 bf16, lane = (column l & 15, k = 8 (l >> 4) + j)
+        // static bounds per channel o -> the power-of-two scales of the two-term fp16 split (cnn.h; all 1 with the bf16 split):
+        //   |pre1[t][o]| <= |bc[o]| + sum_tap max_letter |Wc[o][letter][tap]|                            -> sch[o]
+        //   |routed gradient[t][o]| <= |scale| sum_f |wd[f] We[f][o]|  (every feature in one row)         -> scg[o] (times CnnArgs.gsc)
+        // and, with the inverse channel scales folded in, one scale per weight matrix from its largest entry
+        std::vector<float> sch(CP, 1.f), scg(CP, 1.f), WeG((size_t)FP * CP, 0.f);
+        double we_max = 0.0, wf_max = 0.0;
+        for (int o = 0; o < C; ++o) {
+            float hb = fabsf(conv_b[k][o]), wc = 0.f, gb = 0.f, we = 0.f;
+            for (int kp = 0; kp < K; ++kp) {
+                float mx = 0.f;
+                for (int c = 0; c < 20; ++c) mx = fmaxf(mx, fabsf(conv_w[k][((size_t)o * 20 + c) * K + kp]));
+                hb += mx;
+                wc = fmaxf(wc, mx);
+            }
+            for (int f = 0; f < F; ++f) {
+                const float w = lin_w[k][(size_t)f * C + o];
+                gb += fabsf(dec_w[k][f] * w);
+                we = fmaxf(we, fabsf(w));
+            }
+            sch[o] = bf_scale_for(hb);
+            scg[o] = bf_scale_for(gb);
+            we_max = fmax(we_max, (double)we / sch[o]);
+            wf_max = fmax(wf_max, (double)wc / scg[o]);
+            for (int f = 0; f < F; ++f) WeG[(size_t)f * CP + o] = We[(size_t)f * CP + o] * scg[o];
+        }
+        const float sc_we = bf_scale_for((float)we_max), sc_wf = bf_scale_for((float)wf_max);
+        nt.un_f = 1.f / sc_we;
+        nt.un_b = 1.f / sc_wf;
+        if ((rc = up(sch, &p))) return rc; nt.sch = p;
+        if (BFT == 2) { if ((rc = up(WeG, &p))) return rc; nt.WeG = p; }
+        else nt.WeG = nt.We;
+        // the contraction operands with the inverse channel scales and the matrix's own scale applied (exact: powers of two)
+        std::vector<float> WeTs(WeT), Wfs(Wf);
+        for (int o = 0; o < C; ++o) {
+            for (int f = 0; f < FP; ++f) WeTs[(size_t)o * FP + f] = (float)((double)WeT[(size_t)o * FP + f] / sch[o] * sc_we);
+            for (int j = 0; j < JP; ++j) Wfs[(size_t)o * JP + j] = (float)((double)Wf[(size_t)o * JP + j] / scg[o] * sc_wf);
+        }
+        // those two matrices as MFMA B fragments of their split (cnn.h bf_strips):
+        // [strip of 16 columns][k step of 32][term][lane] x 8 values of 16 bits, lane = (column l & 15, k = 8 (l >> 4) + j)
         auto frags = [&](const std::vector<float>& W, int ldw, int ncols, const uint4** out) -> int {   // W[k][col], k < CP
             const int KS = CP / 32, NS = ncols / 16;
-            std::vector<uint16_t> fr((size_t)NS * KS * 3 * 64 * 8, 0);
+            std::vector<uint16_t> fr((size_t)NS * KS * BFT * 64 * 8, 0);
             for (int ct = 0; ct < NS; ++ct)
                 for (int ks = 0; ks < KS; ++ks)
                     for (int l = 0; l < 64; ++l)
                         for (int j = 0; j < 8; ++j) {
-                            uint16_t t3[3];
-                            bf16_split3_host(W[(size_t)(ks * 32 + 8 * (l >> 4) + j) * ldw + ct * 16 + (l & 15)], t3);
-                            for (int t = 0; t < 3; ++t) fr[((((size_t)ct * KS + ks) * 3 + t) * 64 + l) * 8 + j] = t3[t];
+                            uint16_t tt[BFT];
+                            bf_split_host(W[(size_t)(ks * 32 + 8 * (l >> 4) + j) * ldw + ct * 16 + (l & 15)], tt);
+                            for (int t = 0; t < BFT; ++t) fr[((((size_t)ct * KS + ks) * BFT + t) * 64 + l) * 8 + j] = tt[t];
                         }
             uint16_t* d = nullptr;
             HIPCHK(dalloc(&d, fr.size()));
@@ -891,23 +944,24 @@ int ppde_model_set_cnn(ppde_model* m, int n_nets, int C, int K, int F, const flo
             *out = (const uint4*)d;
             return PPDE_OK;
         };
-        if ((rc = frags(WeT, FP, FP, &nt.WeB))) return rc;
-        if ((rc = frags(Wf, JP, JP, &nt.WfB))) return rc;
+        if ((rc = frags(WeTs, FP, FP, &nt.WeB))) return rc;
+        if ((rc = frags(Wfs, JP, JP, &nt.WfB))) return rc;
         {
-            // the convolution table as MFMA A fragments of its three-term bf16 split (cnn.h conv_onehot_mfma: the convolution of a
-            // one-hot input as [channels x (tap, letter)] x [(tap, letter) x rows], one k step of 32 per tap, letters 20..31 zero):
-            // [channel tile of 16][tap][term][lane] x 8 bf16, lane = (channel ct * 16 + (l & 15), letters 8 (l >> 4) + j)
+            // the convolution table as MFMA A fragments of its split, row o scaled by sch[o]: the matrix-pipe convolution produces sch[o] * pre1
+            // (cnn.h conv_tile_rows: the convolution of a one-hot input as [channels x (tap, letter)] x [(tap, letter) x rows], one k
+            // step of 32 per tap, letters 20..31 zero):
+            // [channel tile of 16][tap][term][lane] x 8 values, lane = (channel ct * 16 + (l & 15), letters 8 (l >> 4) + j)
             const int NT16 = CP / 16;
-            std::vector<uint16_t> fr((size_t)NT16 * KT * 3 * 64 * 8, 0);
+            std::vector<uint16_t> fr((size_t)NT16 * KT * BFT * 64 * 8, 0);
             for (int ct = 0; ct < NT16; ++ct)
                 for (int kp = 0; kp < K; ++kp)
                     for (int l = 0; l < 64; ++l)
                         for (int j = 0; j < 8; ++j) {
                             const int o = ct * 16 + (l & 15), c = 8 * (l >> 4) + j;
                             if (o >= C || c >= 20) continue;
-                            uint16_t t3[3];
-                            bf16_split3_host(conv_w[k][((size_t)o * 20 + c) * K + kp], t3);
-                            for (int t = 0; t < 3; ++t) fr[((((size_t)ct * KT + kp) * 3 + t) * 64 + l) * 8 + j] = t3[t];
+                            uint16_t tt[BFT];
+                            bf_split_host(sch[o] * conv_w[k][((size_t)o * 20 + c) * K + kp], tt);
+                            for (int t = 0; t < BFT; ++t) fr[((((size_t)ct * KT + kp) * BFT + t) * 64 + l) * 8 + j] = tt[t];
                         }
             uint16_t* d = nullptr;
             HIPCHK(dalloc(&d, fr.size()));

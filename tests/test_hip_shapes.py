@@ -76,6 +76,56 @@ def test_cnn_other_kernel_size(L, K):
     assert observed(f"cnn_L{L}_K{K}:grad", np.abs(g.cpu().numpy() - go.numpy()).max(), 2e-6 * max(1.0, float(go.abs().max()))) <= 1.0
 
 
+def _rescaled(cnn, enc, emb, dec, spread=0):
+    """the synthetic networks with their layers multiplied by enc / emb / dec, and (spread > 0) channel c of the first layer by
+    2^e_c with the second layer's column c by 2^-e_c, e_c cycling through -spread .. spread: the same function, operands of very
+    different magnitudes from channel to channel"""
+    out = []
+    for st in cnn:
+        st = {k: np.array(v, dtype=np.float32) for k, v in st.items()}
+        C = st["encoder.weight"].shape[0]
+        ec = (np.arange(C) % (2 * spread + 1)) - spread if spread else np.zeros(C)
+        sc = np.exp2(ec).astype(np.float32)
+        st["encoder.weight"] = st["encoder.weight"] * np.float32(enc) * sc[:, None, None]
+        st["encoder.bias"] = st["encoder.bias"] * np.float32(enc) * sc
+        st["embedding.0.weight"] = st["embedding.0.weight"] * np.float32(emb) / sc[None, :]
+        st["embedding.0.bias"] = st["embedding.0.bias"] * np.float32(enc * emb)
+        st["decoder.weight"] = st["decoder.weight"] * np.float32(dec)
+        out.append(st)
+    return out
+
+
+@pytest.mark.parametrize("L", [96, 150])             # single launch (matrix-pipe convolution) / chunked (table gather)
+@pytest.mark.parametrize("enc,emb,dec,spread", [(1e-3, 1.0, 1.0, 0), (40.0, 1e-2, 100.0, 0), (1e3, 1e3, 1e-5, 0), (1e-4, 1e-3, 1e6, 0),
+                                                (1.0, 1.0, 1.0, 6), (1.0, 1.0, 1.0, 12)])
+def test_cnn_weight_magnitudes(L, enc, emb, dec, spread):
+    """The split-precision contractions scale their operands by powers of two from static bounds (fp16 terms have five exponent
+    bits): networks whose layers sit orders of magnitude away from the trained ones', and whose channels differ by up to 2^24 in
+    magnitude among themselves, against the oracle, errors relative to the outputs' own scale."""
+    from ppde_amd.energy import HipModel
+    rng = np.random.default_rng(7)
+    wt = rng.integers(0, 20, L).astype(np.uint8)
+    cnn = _rescaled([synthetic.make_cnn_state(L, s) for s in range(3)], enc, emb, dec, spread)
+    J, h = synthetic.make_potts(30, seed=3, symmetric=True)
+    m = HipModel(wt, "cuda:0")
+    m.set_potts(J, h, 10)
+    m.set_cnn(cnn)
+    m.set_lamda(2.0)
+    en = oracle_energy(J, h, 10, wt, cnn, 2.0)
+    idx = rng.integers(0, 20, (24, L)).astype(np.uint8)
+    e, f, g = m.energy_grad(torch.as_tensor(idx).cuda(), 2)
+    fo, go = en.cnn.fit_grad(torch.as_tensor(idx.astype(np.int64)))
+    fo_, go_ = fo.numpy(), go.numpy()
+    tag = f"magnitudes_L{L}_{enc:g}_{emb:g}_{dec:g}_s{spread}"
+    fscale = max(float(np.abs(fo_).max()), 1e-30)
+    gscale = max(float(np.abs(go_).max()), 1e-30)
+    assert observed(tag + ":fit", np.abs(f.cpu().numpy() - fo_), 5e-6 * fscale) <= 1.0
+    dg = np.abs(g.cpu().numpy() - go_).reshape(idx.shape[0], -1).max(1)
+    tied = [b for b in np.nonzero(dg > 4e-6 * gscale)[0] if smallest_argmax_gap(cnn, idx[b:b + 1]) < 5e-6]
+    keep = np.setdiff1d(np.arange(idx.shape[0]), tied)
+    assert len(tied) <= 2 and observed(tag + ":grad", dg[keep], 4e-6 * gscale) <= 1.0, (dg / gscale, tied)
+
+
 @pytest.mark.parametrize("L,Lp,i0,n,with_cnn", [(237, 237, 0, 24, False), (237, 237, 0, 6, True), (104, 76, 23, 20, True),
                                                  (40, 7, 31, 1, True), (300, 120, 50, 6, False)])
 def test_sampler_vs_oracle_shapes(L, Lp, i0, n, with_cnn):
