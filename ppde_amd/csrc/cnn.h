@@ -1288,15 +1288,22 @@ __global__ __launch_bounds__(NT, (RT <= 6 && NT == 512 && KT == 5 && !CNN_BOUNDS
 #define CNN_CHUNK_NB 4                                // B fragment buffers of the chunk kernels' bf_strips
 #endif
 #define CNN_FCH_RT 4                                  // forward: 64 rows per chunk
-#define CNN_BCH_RT 3                                  // backward: 48-row windows
+#ifndef CNN_BCH_RT
+#define CNN_BCH_RT 4                                  // backward, split-precision kernels: 64-row windows (60 output positions each at five taps)
+#endif
+#define CNN_BCH_RT_F32 3                              // backward, exact-fp32 kernels: 48-row windows (two workgroups per CU at GFP's width)
+#ifndef CNN_WIDE_FRT
+#define CNN_WIDE_FRT 4                                // forward row tiles per chunk above 128 channels
+#endif
 __host__ __device__ inline int cnn_fwd_chunks(int T, int RT = CNN_FCH_RT) { return (T + RT * 16 - 1) / (RT * 16); }
-__host__ __device__ inline int cnn_bwd_out_per_chunk(int KT) { return CNN_BCH_RT * 16 - (KT - 1); }
-__host__ __device__ inline int cnn_bwd_chunks(int L, int KT) { return (L + cnn_bwd_out_per_chunk(KT) - 1) / cnn_bwd_out_per_chunk(KT); }
+__host__ __device__ inline int cnn_bwd_out_per_chunk(int KT, bool bf) { return (bf ? CNN_BCH_RT : CNN_BCH_RT_F32) * 16 - (KT - 1); }
+__host__ __device__ inline int cnn_bwd_chunks(int L, int KT, bool bf) { return (L + cnn_bwd_out_per_chunk(KT, bf) - 1) / cnn_bwd_out_per_chunk(KT, bf); }
 __host__ __device__ inline size_t cnn_fwd_chunk_lds(int CP) { return (size_t)CNN_FCH_RT * 16 * (cnn_astride(CP) + (CP + 31) / 32) * 4 + 256; }
-// split-precision forms (bf_strips): the chunk's rows as three-plane bf16 images. Forward: 64-row chunks while two workgroups fit
-// a CU (up to 128 padded channels: 48 KB), 48-row chunks beyond (GFP, 256 channels: 72 KB). Backward: the routed gradient's planes,
+// split-precision forms (bf_strips): the chunk's rows as split images (BFT planes). Forward: 64-row chunks (GFP, 256 channels, two
+// planes: 68 KB, two workgroups per CU; with the three-plane bf16 split it was 48 rows beyond 128 channels). Backward: 64-row
+// windows (GFP: four windows instead of six of 48 rows, 342 -> 314 us per step with both, A/B); the routed gradient's planes,
 // O takes their storage once every wave has read them (as cnn_body_bf).
-__host__ __device__ inline int cnn_bf_fwd_rt(int CP) { return CP <= 128 ? 4 : 3; }
+__host__ __device__ inline int cnn_bf_fwd_rt(int CP) { return CP <= 128 ? 4 : CNN_WIDE_FRT; }
 __host__ __device__ inline size_t cnn_bf_fwd_chunk_lds(int CP, int FP) {
     const size_t RT = cnn_bf_fwd_rt(CP);
     return RT * BFT * (CP / 32) * 1024 + RT * 16 * ((CP + 31) / 32) * 4 + 256 + (size_t)FP * 4;     // (+ letters, + the second layer's bias)
@@ -1307,7 +1314,7 @@ __host__ __device__ inline size_t cnn_bf_bwd_chunk_lds(int CP, int FP, int J) {
     return (planes > so ? planes : so) + rows * ((CP + 31) / 32) * 4 + (size_t)FP * 12 + 512;
 }
 __host__ __device__ inline size_t cnn_bwd_chunk_lds(int CP, int FP, int J) {
-    const size_t rows = CNN_BCH_RT * 16;
+    const size_t rows = CNN_BCH_RT_F32 * 16;
     return rows * cnn_astride(CP) * 4 + rows * J * 4 + rows * ((CP + 31) / 32) * 4 + (size_t)FP * 12 + 512;   // (+ offsets, sums)
 }
 
@@ -1463,7 +1470,7 @@ __global__ __launch_bounds__(NT, 2) void k_cnn_bwd_chunk(CnnChunkArgs ca) {
     extern __shared__ unsigned char smem_raw[];
     const CnnArgs& a = ca.a;
     const Geom g = a.g;
-    constexpr int RT = CNN_BCH_RT, rows = RT * 16;
+    constexpr int RT = BF ? CNN_BCH_RT : CNN_BCH_RT_F32, rows = RT * 16;
     const int b = a.b_off + blockIdx.x, ni = blockIdx.y, c = blockIdx.z, tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const CnnNet net = a.net[ni];
@@ -1482,7 +1489,7 @@ __global__ __launch_bounds__(NT, 2) void k_cnn_bwd_chunk(CnnChunkArgs ca) {
     int* sCnt = (int*)(red + 16);
     int* sStart = sCnt + 4;                                           // [rows + 1] list offsets of the window's rows (+ 3 pad)
     [[maybe_unused]] int phase = 0;
-    const int PO = cnn_bwd_out_per_chunk(KT);
+    const int PO = cnn_bwd_out_per_chunk(KT, BF);
     const int p0 = c * PO, r0 = p0 - (KT - 1);                        // window rows r0 .. r0 + rows
     const int slot = a.slot;
 

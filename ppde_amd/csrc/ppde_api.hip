@@ -344,7 +344,7 @@ static int launch_cnn(const ppde_model* m, const States& st, int n, const EvalTa
         const size_t lds_b = bf ? cnn_bf_bwd_chunk_lds(m->CP, m->FP, m->J) : cnn_bwd_chunk_lds(m->CP, m->FP, m->J);
         ARGCHK(lds_f <= 160 * 1024 && lds_b <= 160 * 1024, "sequence too long for the chunked CNN kernels");
         CnnChunkArgs ca{a, t.cmax, t.carg, t.cgate, cnn_fwd_chunks(m->T, frt), frt * 16};
-        const dim3 gf(n_sub, m->n_nets, ca.NCH), gb(n_sub, m->n_nets, want_grad ? cnn_bwd_chunks(m->L, m->KT) : 1);
+        const dim3 gf(n_sub, m->n_nets, ca.NCH), gb(n_sub, m->n_nets, want_grad ? cnn_bwd_chunks(m->L, m->KT, bf) : 1);
         // the two long real proteins have instantiations with their network shape pinned (cnn.h CnnChunkShape)
         static const bool shape_spec = []() { const char* e = getenv("PPDE_CNN_SPEC"); return !e || atoi(e) != 0; }();   // tuning knob
         const bool five = m->KT == 5 && m->K == 5 && m->J == 100 && m->JP == 112;
@@ -352,7 +352,7 @@ static int launch_cnn(const ppde_model* m, const States& st, int n, const EvalTa
                           : (m->T == 100 && m->CP == 128 && m->F == 208 && m->FP == 208) ? 1
                           : (m->T == 233 && m->CP == 256 && m->F == 474 && m->FP == 480) ? 2 : 0;
         if (bf) {
-            // split-precision chunks (bf16 matrix pipe): forward chunks of 64 rows (<= 128 channels) or 48 rows
+            // split-precision chunks (16-bit matrix pipe): forward chunks and backward windows of 64 rows
             // Networks of more than 128 channels (GFP: two chunk workgroups per CU by LDS) run the chunk kernels with 512 threads:
             // four waves per SIMD hide what a block's instruction stream costs better than the second A register set of the
             // 256-thread form (GFP + CNN 505 -> 446 us per step, A/B on one box); up to 128 channels three 256-thread workgroups
@@ -360,8 +360,8 @@ static int launch_cnn(const ppde_model* m, const States& st, int n, const EvalTa
             static const bool allow512 = []() { const char* e = getenv("PPDE_CNN_CHUNK_512"); return !e || atoi(e) != 0; }();
             const bool wide = allow512 && m->CP > 128;
             if (wide) {
-                if (m->KT == 5) hipLaunchKernelGGL((k_cnn_fwd_chunk<5, 0, 3, true, 512>), gf, dim3(512), lds_f, s, ca);
-                else hipLaunchKernelGGL((k_cnn_fwd_chunk<CNN_MAX_K, 0, 3, true, 512>), gf, dim3(512), lds_f, s, ca);
+                if (m->KT == 5) hipLaunchKernelGGL((k_cnn_fwd_chunk<5, 0, CNN_WIDE_FRT, true, 512>), gf, dim3(512), lds_f, s, ca);
+                else hipLaunchKernelGGL((k_cnn_fwd_chunk<CNN_MAX_K, 0, CNN_WIDE_FRT, true, 512>), gf, dim3(512), lds_f, s, ca);
                 if (shape == 2) hipLaunchKernelGGL((k_cnn_bwd_chunk<5, 2, true, 512>), gb, dim3(512), lds_b, s, ca);
                 else if (m->KT == 5) hipLaunchKernelGGL((k_cnn_bwd_chunk<5, 0, true, 512>), gb, dim3(512), lds_b, s, ca);
                 else hipLaunchKernelGGL((k_cnn_bwd_chunk<CNN_MAX_K, 0, true, 512>), gb, dim3(512), lds_b, s, ca);
@@ -446,8 +446,11 @@ struct ExpertsArgs {
 #ifndef PPDE_EXPERTS_PRIO
 #define PPDE_EXPERTS_PRIO 0
 #endif
+#ifndef PPDE_EXPERTS_WAVES
+#define PPDE_EXPERTS_WAVES 4                      // waves per SIMD the shape-pinned split-precision instantiation is compiled for (tuning builds: 6 = three workgroups per CU)
+#endif
 template <int RT, int NG, bool PABP = false, bool BF = false>
-__global__ __launch_bounds__(CNN_NT, (RT <= 6 && !CNN_BOUNDS_RELAX) ? 4 : 2) void k_experts(ExpertsArgs a) {
+__global__ __launch_bounds__(CNN_NT, (PABP && BF) ? PPDE_EXPERTS_WAVES : ((RT <= 6 && !CNN_BOUNDS_RELAX) ? 4 : 2)) void k_experts(ExpertsArgs a) {
     warm_kernargs<sizeof(ExpertsArgs)>();
 
     extern __shared__ float4 smem_experts[];
