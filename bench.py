@@ -216,13 +216,14 @@ def also_poe(args, device, rank, protein="PABP", lamda=5.0, steps=200, warm=40, 
             out.update(value=steps / dt, unit="steps/s", ms_per_step=dt / steps * 1e3, steps=steps, warmup=warm,
                        timed_blocks={"repeats": reps, "statistic": "median", "ms_per_block": [round(x * 1e3, 3) for x in dts]},
                        workload=f"{pname} Potts + supervised CNN product of experts (lamda={lamda:g}), L={L}, L'={Lp}, {n} chains, "
-                                f"pas_length={args.pas}, device Philox RNG, hipGraph replay ({what})", dtype="f32 (CNN contractions: exact 3-term bf16 split on the bf16 matrix pipe, fp32 accumulate)",
+                                f"pas_length={args.pas}, device Philox RNG, hipGraph replay ({what})", dtype="f32 (CNN contractions: operands as two fp16 terms, three cross-term MFMAs per block on the fp16 matrix pipe, fp32 accumulate)",
                        roofline={"kernel": "k_experts (Potts tiles + 3-network CNN forward/backward in one launch)" if single else
                                            "all experts of one evaluation (Potts ring kernel + CNN forward chunks + CNN backward chunks)",
                                  "bound": "mfma", "achieved": fl / (us * 1e-6) / 1e12, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
                                  "frac": fl / (us * 1e-6) / 1e12 / MFMA_F32_PEAK_TF, "traffic": None,
-                                 "peak_note": "priced against the dense fp32 matrix peak the arithmetic is specified in (the kernels issue six "
-                                              "bf16 MFMAs per fp32 block: 6/16 of the bf16 pipe's time, so this fraction can exceed the fp32 pipe's)",
+                                 "peak_note": "priced against the dense fp32 matrix peak the arithmetic is specified in (the kernels issue three "
+                                              "fp16 MFMAs per fp32 block: 3/16 of the time the fp32 MFMA would take, so this fraction can exceed 1)",
+                                 "frac_of_f16_pipe_issued": 3.0 * fl / (us * 1e-6) / 1e12 / MFMA_BF16_PEAK_TF,
                                  "algorithmic_flops_per_launch": fl, "avg_launch_us": us, "launches_timed": 200 if protein == "PABP" else 50,
                                  "committed_profile": committed_profile("config3" if single else "gfp_cnn", "k_experts" if single else "k_cnn_fwd_chunk",
                                                                         fl if single else None, MFMA_F32_PEAK_TF * 1e12, us if single else None)})

@@ -13,6 +13,7 @@
 // conflict-free), B operands stream from L2 in [k][n] layout. Arithmetic per chain does not depend on the batch.
 #pragma once
 #include <string.h>
+#include <type_traits>
 #include "common.h"
 
 typedef __attribute__((ext_vector_type(4))) float f32x4;
@@ -483,6 +484,9 @@ __device__ __forceinline__ void mfma_strip(f32x4 (&acc)[RT], const float* A, int
 // and one work item is a row and three consecutive 4-channel pieces, so that the row's extent, its first four list entries and
 // their coefficients are fetched once for three pieces (the same 12 L2 loads in flight per item as the ungrouped form has per
 // thread and round). A piece's sum still runs over its row's entries in list order: the same bits (CNN_ROUTE_GROUPED=0: A/B builds).
+#ifndef CNN_ROUTE_PIECES
+#define CNN_ROUTE_PIECES 3            // 4-channel pieces per work item of the grouped row sums
+#endif
 #ifndef CNN_ROUTE_GROUPED
 #define CNN_ROUTE_GROUPED 2          // 0: ungrouped row sums; 1: grouped; 2: grouped + the backward over the compacted non-empty rows
 #endif
@@ -566,7 +570,8 @@ __device__ __forceinline__ int cnn_route_rows(const CnnNet& net, const int rows,
     __syncthreads();
     PPDE_STAMP(dbg, 62, stamp);
     if constexpr (GROUPED) {
-        const int G4 = CP / 4, TR = (G4 + 2) / 3;                      // pieces per row, items per row
+        constexpr int NP = CNN_ROUTE_PIECES;                            // 4-channel pieces per work item
+        const int G4 = CP / 4, TR = (G4 + NP - 1) / NP;                 // pieces per row, items per row
         const int n_ne = sTot[2] + sTot[3];
         n_rows_routed = n_ne;
         const int last = max(sStart[rows] - 1, 0);
@@ -583,9 +588,9 @@ __device__ __forceinline__ int cnn_route_rows(const CnnNet& net, const int rows,
             const int r = u / TR, k = u - r * TR;
             const int t = sRows[r];
             const int rs = sStart[t], kk = sStart[t + 1] - rs;
-            int f[4], c4c[3];
+            int f[4], c4c[NP];
             float cq[4];
-            float4 v[3][4];
+            float4 v[NP][4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) f[q] = min((unsigned)sList[min(rs + q, last)], (unsigned)(FP - 1));
 #pragma unroll
@@ -595,14 +600,14 @@ __device__ __forceinline__ int cnn_route_rows(const CnnNet& net, const int rows,
                 cq[q] = q < kk ? cm : 0.f;                           //  which puts a wait in front of every entry)
             }
 #pragma unroll
-            for (int j = 0; j < 3; ++j) {
-                c4c[j] = min(3 * k + j, G4 - 1);
+            for (int j = 0; j < NP; ++j) {
+                c4c[j] = min(NP * k + j, G4 - 1);
 #pragma unroll
                 for (int q = 0; q < 4; ++q) v[j][q] = We4[(size_t)f[q] * G4 + c4c[j]];
             }
-            float4 acc[3];
+            float4 acc[NP];
 #pragma unroll
-            for (int j = 0; j < 3; ++j) {
+            for (int j = 0; j < NP; ++j) {
                 acc[j] = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
@@ -613,17 +618,17 @@ __device__ __forceinline__ int cnn_route_rows(const CnnNet& net, const int rows,
             for (int q = 4; q < kk; ++q) {                           // rows with more than four routed features
                 const int fq = sList[rs + q];
                 const float cf = sM[fq];
-                float4 w[3];
+                float4 w[NP];
 #pragma unroll
-                for (int j = 0; j < 3; ++j) w[j] = We4[(size_t)fq * G4 + c4c[j]];
+                for (int j = 0; j < NP; ++j) w[j] = We4[(size_t)fq * G4 + c4c[j]];
 #pragma unroll
-                for (int j = 0; j < 3; ++j) {
+                for (int j = 0; j < NP; ++j) {
                     acc[j].x += cf * w[j].x; acc[j].y += cf * w[j].y; acc[j].z += cf * w[j].z; acc[j].w += cf * w[j].w;
                 }
             }
 #pragma unroll
-            for (int j = 0; j < 3; ++j) {
-                const int c4 = 3 * k + j;
+            for (int j = 0; j < NP; ++j) {
+                const int c4 = NP * k + j;
                 if (c4 >= G4) continue;
                 const uint32_t nib = (sG[t * BW + (c4 >> 3)] >> (4 * (c4 & 7))) & 0xFu;   // gate by relu'(pre1)
                 float4 a4 = acc[j];
@@ -954,6 +959,9 @@ __device__ __forceinline__ void cnn_body(const CnnArgs& a_, const int bx, const 
 #ifndef CNN_CONV_MFMA
 #define CNN_CONV_MFMA 1
 #endif
+#ifndef CNN_CONV_ROWS
+#define CNN_CONV_ROWS 1             // row tiles a wave convolves at a time
+#endif
 __host__ __device__ inline size_t cnn_conv_x_bytes(int T) { return (size_t)(cnn_rows(T) + CNN_MAX_K) * 64; }
 // the lane's share of the one-hot fragments of position p: letters 8 kq .. 8 kq + 7
 __device__ __forceinline__ uint4 conv_x_fragment(int letter, int kq) {
@@ -986,24 +994,38 @@ __device__ __forceinline__ void conv_tile_rows(const uint4 (&af)[KT][BFT], const
     const int lane = threadIdx.x & 63, n = lane & 15, kq = lane >> 4;
     const int g4 = tile * 4 + kq;                                    // the lane's 4 channels: 4 g4 .. 4 g4 + 3
     const float4 bias4 = bf_scaled(*(const float4*)(net.bc + 4 * g4), *(const float4*)(net.sch + 4 * g4));   // (the table fragments hold sch[o] * table)
-    for (int rt = rt_lo; rt < rt_hi; ++rt) {
-        const int t = rt * 16 + n;
-        const uint4* xp = sX + (size_t)t * 4 + kq;                   // fragment of tap kp: position t + kp
-        f32x4 acc = {bias4.x, bias4.y, bias4.z, bias4.w};
+    // CNN_CONV_ROWS row tiles at a time: their accumulator chains are independent, so the matrix pipe does not wait out one
+    // chain's latency per instruction (a tile's 5 * BFT MFMAs all go into one accumulator)
+    auto tiles = [&](const int rt0, auto nrt_c) {
+        constexpr int NR = decltype(nrt_c)::value;
+        f32x4 acc[NR];
+#pragma unroll
+        for (int u = 0; u < NR; ++u) acc[u] = (f32x4){bias4.x, bias4.y, bias4.z, bias4.w};
 #pragma unroll
         for (int kp = 0; kp < KT; ++kp) {
-            const uint4 xb = xp[4 * kp];
+            uint4 xb[NR];
 #pragma unroll
-            for (int tm = BFT - 1; tm >= 0; --tm) acc = bf_mfma(af[kp][tm], xb, acc);   // (small terms first)
+            for (int u = 0; u < NR; ++u) xb[u] = sX[(size_t)((rt0 + u) * 16 + n) * 4 + kq + 4 * kp];   // fragment of tap kp: position t + kp
+#pragma unroll
+            for (int tm = BFT - 1; tm >= 0; --tm)                    // (small terms first)
+#pragma unroll
+                for (int u = 0; u < NR; ++u) acc[u] = bf_mfma(af[kp][tm], xb[u], acc[u]);
         }
-        const bool live = t < T;
-        float4 x;
-        x.x = live ? fmaxf(acc[0], 0.f) : 0.f; x.y = live ? fmaxf(acc[1], 0.f) : 0.f;
-        x.z = live ? fmaxf(acc[2], 0.f) : 0.f; x.w = live ? fmaxf(acc[3], 0.f) : 0.f;
-        const uint32_t nib = (x.x > 0.f ? 1u : 0u) | (x.y > 0.f ? 2u : 0u) | (x.z > 0.f ? 4u : 0u) | (x.w > 0.f ? 8u : 0u);
-        bf_store4(sP, RT, t, g4, x);
-        if (nib) atomicOr(&sG[t * BW + (g4 >> 3)], nib << (4 * (g4 & 7)));
-    }
+#pragma unroll
+        for (int u = 0; u < NR; ++u) {
+            const int t = (rt0 + u) * 16 + n;
+            const bool live = t < T;
+            float4 x;
+            x.x = live ? fmaxf(acc[u][0], 0.f) : 0.f; x.y = live ? fmaxf(acc[u][1], 0.f) : 0.f;
+            x.z = live ? fmaxf(acc[u][2], 0.f) : 0.f; x.w = live ? fmaxf(acc[u][3], 0.f) : 0.f;
+            const uint32_t nib = (x.x > 0.f ? 1u : 0u) | (x.y > 0.f ? 2u : 0u) | (x.z > 0.f ? 4u : 0u) | (x.w > 0.f ? 8u : 0u);
+            bf_store4(sP, RT, t, g4, x);
+            if (nib) atomicOr(&sG[t * BW + (g4 >> 3)], nib << (4 * (g4 & 7)));
+        }
+    };
+    int rt = rt_lo;
+    for (; rt + CNN_CONV_ROWS <= rt_hi; rt += CNN_CONV_ROWS) tiles(rt, std::integral_constant<int, CNN_CONV_ROWS>{});
+    for (; rt < rt_hi; ++rt) tiles(rt, std::integral_constant<int, 1>{});
 }
 
 // The same workgroup with both dense contractions on the bf16 matrix pipe (split-precision, see bf_strips): h1 and the routed
