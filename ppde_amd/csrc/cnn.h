@@ -212,6 +212,51 @@ __device__ __forceinline__ float4 bf_scaled(float4 x, const float4 s) {
     if constexpr (BFT == 2) { x.x *= s.x; x.y *= s.y; x.z *= s.z; x.w *= s.w; }
     return x;
 }
+// The epilogue of a forward strip: relu(acc * u + bias) maximised over the rows the lane holds (row tiles rt0 .. rt0 + NR - 1 of
+// the image, absolute row = t_first + 16 rt + j for the lane's j-th row of tile rt), first index on ties, then across the four
+// lane groups of the wave. The ReLU is not applied per value: the running maximum starts at 0 and is replaced on a strict >, which
+// is max_t relu(v_t) with its first arg-max whenever that maximum is positive, and (0, first row) otherwise -- a feature whose
+// maximum is 0 is not routed, its row is never read. The winner is carried as the compile-time index 4 rt + j and decoded once;
+// the two values of a pair go through one packed fma. Rows at or beyond T are skipped (a uniform branch per row tile: only the
+// last tile of a sequence compares).
+template <int NR>
+__device__ __forceinline__ void bf_rows_max(const f32x4 (&acc)[NR], const float u, const float bias, const int t_first, const int T,
+                                            float& m_out, int& ts_out) {
+    const int lane = threadIdx.x & 63;
+    const int t_lane = t_first + (lane >> 4) * 4;
+    const int left = T - t_lane;                                     // rows from the lane's first one to the end of the sequence
+    const int left_u = __builtin_amdgcn_readfirstlane(T - t_first);  // (uniform: the same for the wave's first lane group)
+    float m = 0.f;
+    int kb = 0;
+#pragma unroll
+    for (int rt = 0; rt < NR; ++rt) {
+        float v[4];
+#pragma unroll
+        for (int j = 0; j < 4; j += 2) {
+            f32x2 p = {acc[rt][j], acc[rt][j + 1]};
+            if constexpr (BFT == 2) p = __builtin_elementwise_fma(p, (f32x2){u, u}, (f32x2){bias, bias});
+            else p = p + (f32x2){bias, bias};
+            v[j] = p[0]; v[j + 1] = p[1];
+        }
+        if (16 * rt + 16 <= left_u) {                                // every lane's rows of this tile lie inside the sequence
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (v[j] > m) { m = v[j]; kb = 4 * rt + j; }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (16 * rt + j < left && v[j] > m) { m = v[j]; kb = 4 * rt + j; }
+        }
+    }
+    int ts = t_lane + (kb >> 2) * 16 + (kb & 3);
+#pragma unroll
+    for (int o = 16; o < 64; o <<= 1) {
+        const float om = __shfl_xor(m, o);
+        const int ot = __shfl_xor(ts, o);
+        if (om > m || (om == m && ot < ts)) { m = om; ts = ot; }
+    }
+    m_out = m; ts_out = ts;
+}
 __host__ __device__ inline size_t cnn_bf_region_bytes(int T, int CP, int J) {
     const size_t rows = cnn_rows(T);
     const size_t planes = (size_t)BFT * (CP / 32) * (rows / 16) * 1024, so = rows * (size_t)J * 4;
@@ -490,6 +535,13 @@ __device__ __forceinline__ void mfma_strip(f32x4 (&acc)[RT], const float* A, int
 #ifndef CNN_ROUTE_GROUPED
 #define CNN_ROUTE_GROUPED 2          // 0: ungrouped row sums; 1: grouped; 2: grouped + the backward over the compacted non-empty rows
 #endif
+// acc += c * v, one rounding per term (explicit fma: the build runs with -ffp-contract=off), two components per packed instruction
+__device__ __forceinline__ void route_fma(float4& acc, const float c, const float4 v) {
+    const f32x2 cc = {c, c};
+    const f32x2 lo = __builtin_elementwise_fma(cc, (f32x2){v.x, v.y}, (f32x2){acc.x, acc.y});
+    const f32x2 hi = __builtin_elementwise_fma(cc, (f32x2){v.z, v.w}, (f32x2){acc.z, acc.w});
+    acc = make_float4(lo[0], lo[1], hi[0], hi[1]);
+}
 template <int NT, bool BF = false, int GROUPED = 0, bool FINAL_BARRIER = true>
 __device__ __forceinline__ int cnn_route_rows(const CnnNet& net, const int rows, const int r0, const int CP, const int AS,
                                                const int FP, const int BW, float* sD, uint32_t* sB, const uint32_t* sG,
@@ -610,10 +662,7 @@ __device__ __forceinline__ int cnn_route_rows(const CnnNet& net, const int rows,
             for (int j = 0; j < NP; ++j) {
                 acc[j] = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    acc[j].x += cq[q] * v[j][q].x; acc[j].y += cq[q] * v[j][q].y;
-                    acc[j].z += cq[q] * v[j][q].z; acc[j].w += cq[q] * v[j][q].w;
-                }
+                for (int q = 0; q < 4; ++q) route_fma(acc[j], cq[q], v[j][q]);
             }
             for (int q = 4; q < kk; ++q) {                           // rows with more than four routed features
                 const int fq = sList[rs + q];
@@ -622,9 +671,7 @@ __device__ __forceinline__ int cnn_route_rows(const CnnNet& net, const int rows,
 #pragma unroll
                 for (int j = 0; j < NP; ++j) w[j] = We4[(size_t)fq * G4 + c4c[j]];
 #pragma unroll
-                for (int j = 0; j < NP; ++j) {
-                    acc[j].x += cf * w[j].x; acc[j].y += cf * w[j].y; acc[j].z += cf * w[j].z; acc[j].w += cf * w[j].w;
-                }
+                for (int j = 0; j < NP; ++j) route_fma(acc[j], cf, w[j]);
             }
 #pragma unroll
             for (int j = 0; j < NP; ++j) {
@@ -679,16 +726,13 @@ __device__ __forceinline__ int cnn_route_rows(const CnnNet& net, const int rows,
             for (int j = 0; j < 3; ++j) {
                 float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    acc.x += c[j][q] * v[j][q].x; acc.y += c[j][q] * v[j][q].y;
-                    acc.z += c[j][q] * v[j][q].z; acc.w += c[j][q] * v[j][q].w;
-                }
+                for (int q = 0; q < 4; ++q) route_fma(acc, c[j][q], v[j][q]);
 #if CNN_ROUTE_TAIL == 1
                 for (int q = 4; q < kk[j]; ++q) {                    // rows with more than four routed features
                     const int f = sList[rs[j] + q];
                     const float cq = sM[f];
                     const float4 w = We4[(size_t)f * G4 + c4[j]];
-                    acc.x += cq * w.x; acc.y += cq * w.y; acc.z += cq * w.z; acc.w += cq * w.w;
+                    route_fma(acc, cq, w);
                 }
 #else
                 for (int q0 = 4; q0 < kk[j]; q0 += CNN_ROUTE_TAIL) {  // rows with more than four routed features: batches, in order
@@ -701,9 +745,7 @@ __device__ __forceinline__ int cnn_route_rows(const CnnNet& net, const int rows,
                         cq[u] = q0 + u < kk[j] ? sM[f] : 0.f;
                     }
 #pragma unroll
-                    for (int u = 0; u < CNN_ROUTE_TAIL; ++u) {
-                        acc.x += cq[u] * w[u].x; acc.y += cq[u] * w[u].y; acc.z += cq[u] * w[u].z; acc.w += cq[u] * w[u].w;
-                    }
+                    for (int u = 0; u < CNN_ROUTE_TAIL; ++u) route_fma(acc, cq[u], w[u]);
                 }
 #endif
                 const uint32_t nib = (sG[t[j] * BW + (c4[j] >> 3)] >> (4 * (c4[j] & 7))) & 0xFu;   // gate by relu'(pre1)
@@ -1014,10 +1056,10 @@ __device__ __forceinline__ void conv_tile_rows(const uint4 (&af)[KT][BFT], const
 #pragma unroll
         for (int u = 0; u < NR; ++u) {
             const int t = (rt0 + u) * 16 + n;
-            const bool live = t < T;
+            // (rows at or beyond T -- the padding of the last row tile -- are not zeroed: their letters are staged as 0, so they
+            //  hold finite values; the forward's max skips them, the route never lands a feature there and overwrites the image)
             float4 x;
-            x.x = live ? fmaxf(acc[u][0], 0.f) : 0.f; x.y = live ? fmaxf(acc[u][1], 0.f) : 0.f;
-            x.z = live ? fmaxf(acc[u][2], 0.f) : 0.f; x.w = live ? fmaxf(acc[u][3], 0.f) : 0.f;
+            x.x = fmaxf(acc[u][0], 0.f); x.y = fmaxf(acc[u][1], 0.f); x.z = fmaxf(acc[u][2], 0.f); x.w = fmaxf(acc[u][3], 0.f);
             const uint32_t nib = (x.x > 0.f ? 1u : 0u) | (x.y > 0.f ? 2u : 0u) | (x.z > 0.f ? 4u : 0u) | (x.w > 0.f ? 8u : 0u);
             bf_store4(sP, RT, t, g4, x);
             if (nib) atomicOr(&sG[t * BW + (g4 >> 3)], nib << (4 * (g4 & 7)));
@@ -1164,24 +1206,9 @@ __device__ __forceinline__ void cnn_body_bf(const CnnArgs& a_, const int bx, con
     const float un_f = net.un_f;
     auto fwd_epi = [&](int, int ct, const f32x4 (&acc)[RT]) {
         const int f = ct * 16 + (lane & 15);
-        const float bias = sM[f];
-        float m = -INFINITY;
-        int ts = 0;
-#pragma unroll
-        for (int rt = 0; rt < RT; ++rt) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int t = rt * 16 + (lane >> 4) * 4 + j;
-                const float v = fmaxf(bf_unscaled_plus(acc[rt][j], un_f, bias), 0.f);
-                if (t < T && v > m) { m = v; ts = t; }
-            }
-        }
-#pragma unroll
-        for (int o = 16; o < 64; o <<= 1) {
-            const float om = __shfl_xor(m, o);
-            const int ot = __shfl_xor(ts, o);
-            if (om > m || (om == m && ot < ts)) { m = om; ts = ot; }
-        }
+        float m;
+        int ts;
+        bf_rows_max<RT>(acc, un_f, sM[f], 0, T, m, ts);
         if (lane < 16) { sM[f] = m; sTs[f] = ts; }
     };
     bf_strips_c<RT, RT, PABP>(sP, net.WeB, KS, ct_lo + wave, NT / 64, ct_hi, fwd_epi, pre_f);
@@ -1450,20 +1477,23 @@ __global__ __launch_bounds__(NT, 2) void k_cnn_fwd_chunk(CnnChunkArgs ca) {
         const float bias = BF ? sBe[f] : net.be[f];
         float m = -INFINITY;
         int ts = 0;
+        if constexpr (BF) bf_rows_max<RT>(acc, net.un_f, bias, t0, T, m, ts);
+        else {
 #pragma unroll
-        for (int rt = 0; rt < RT; ++rt) {
+            for (int rt = 0; rt < RT; ++rt) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int t = t0 + rt * 16 + (lane >> 4) * 4 + j;
-                const float v = BF ? fmaxf(bf_unscaled_plus(acc[rt][j], net.un_f, bias), 0.f) : fmaxf(acc[rt][j] + bias, 0.f);
-                if (t < T && v > m) { m = v; ts = t; }
+                for (int j = 0; j < 4; ++j) {
+                    const int t = t0 + rt * 16 + (lane >> 4) * 4 + j;
+                    const float v = fmaxf(acc[rt][j] + bias, 0.f);
+                    if (t < T && v > m) { m = v; ts = t; }
+                }
             }
-        }
 #pragma unroll
-        for (int o = 16; o < 64; o <<= 1) {
-            const float om = __shfl_xor(m, o);
-            const int ot = __shfl_xor(ts, o);
-            if (om > m || (om == m && ot < ts)) { m = om; ts = ot; }
+            for (int o = 16; o < 64; o <<= 1) {
+                const float om = __shfl_xor(m, o);
+                const int ot = __shfl_xor(ts, o);
+                if (om > m || (om == m && ot < ts)) { m = om; ts = ot; }
+            }
         }
         if (lane < 16) {
             const size_t at = ((((size_t)ni * a.n + b) * ca.NCH) + c) * FP + f;
