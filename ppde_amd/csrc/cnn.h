@@ -1204,14 +1204,17 @@ __device__ __forceinline__ void cnn_body_bf(const CnnArgs& a_, const int bx, con
     // ---- pre2 = h1 We^T + be (six bf16 cross-term MFMAs per block); relu and the running max over t straight from the
     //      accumulators (strict >, rows ascending: the first index wins, like torch.max)
     const float un_f = net.un_f;
-    auto fwd_epi = [&](int, int ct, const f32x4 (&acc)[RT]) {
+    auto fwd_epi = [&]([[maybe_unused]] int i, int ct, const f32x4 (&acc)[RT]) {
+        PPDE_STAMP(a.dbg, 52 + 2 * min(i, 1), first_wg);           // (diagnostic build: the strip's MFMAs are issued)
         const int f = ct * 16 + (lane & 15);
         float m;
         int ts;
         bf_rows_max<RT>(acc, un_f, sM[f], 0, T, m, ts);
         if (lane < 16) { sM[f] = m; sTs[f] = ts; }
+        PPDE_STAMP(a.dbg, 53 + 2 * min(i, 1), first_wg);
     };
     bf_strips_c<RT, RT, PABP>(sP, net.WeB, KS, ct_lo + wave, NT / 64, ct_hi, fwd_epi, pre_f);
+    PPDE_STAMP(a.dbg, 56, first_wg);                                 // (before the barrier: wave 0's own share is done)
     __syncthreads();
 
     PPDE_STAMP(a.dbg, sb + 3, stamp);

@@ -22,7 +22,7 @@ from ppde_amd.sampler import Chains
 WORK = "potts+cnn" if "--cnn" in sys.argv else "potts"
 PROT = [a.split("=")[1] for a in sys.argv if a.startswith("--protein=")]
 m, wt, J, h, i0, Lp, cnn = build_model(WORK, "cuda:0", PROT[0] if PROT else "PABP")
-n = 128
+n = ([int(a.split("=")[1]) for a in sys.argv if a.startswith("--chains=")] or [128])[0]
 pas = 2
 ch = Chains(m, n, 64, pas, 0, False, i0, i0 + Lp - 1, 3 if cnn else 1, 1, reuse_grad=False, use_graph=False, seed=1)
 ch.init(torch.as_tensor(np.tile(wt, (n, 1))).cuda())
@@ -38,14 +38,15 @@ NAMES = {0: "potts entry", 1: "potts DMAs issued", 2: "potts states landed+barri
          29: "accept end", 30: "accept row loads issued", 31: "accept prefetch issued", 32: "accept path staged",
          33: "accept row committed", 40: "cnn entry", 41: "cnn letters staged", 42: "cnn h1 built", 43: "cnn forward contraction + max",
          44: "cnn output written", 45: "cnn route bitmap built", 47: "cnn routed + gated", 48: "cnn backward contraction",
-         49: "cnn end", 60: "route: bitmap built", 61: "route: row offsets", 62: "route: list sorted", 63: "route: rows summed (wave 0)"}
+         49: "cnn end", 52: "fwd: strip 0 multiplied (wave 0)", 53: "fwd: strip 0 epilogue done", 54: "fwd: strip 1 multiplied",
+         55: "fwd: strip 1 epilogue done", 56: "fwd: wave 0 at the barrier", 60: "route: bitmap built", 61: "route: row offsets", 62: "route: list sorted", 63: "route: rows summed (wave 0)"}
 acc = {}
 for rep in range(20):
     ch.run(1)
     out = np.zeros(128, dtype=np.uint64)
     _hip.check(lib.ppde_debug_read_stamps(ch.handle, out.ctypes.data))
     st = out.reshape(64, 2)
-    for grp in ((0, 1, 2, 3, 4, 5), (8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19), (24, 30, 31, 32, 33, 25, 26, 27, 28, 29), (40, 41, 42, 43, 44, 60, 61, 62, 63, 45, 46, 47, 48, 49), (50, 51, 52, 53, 54, 55, 56, 57, 58, 59)):
+    for grp in ((0, 1, 2, 3, 4, 5), (8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19), (24, 30, 31, 32, 33, 25, 26, 27, 28, 29), (40, 41, 42, 52, 53, 54, 55, 56, 43, 44, 60, 61, 62, 63, 45, 46, 47, 48, 49), (50, 51, 52, 53, 54, 55, 56, 57, 58, 59)):
         prev = None
         for k in grp:
             if st[k, 0] == 0:
