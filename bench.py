@@ -303,6 +303,8 @@ def paper_protocol(rng, n_iters, protein="PABP_YEAST_Fields2013", lamda=5.0, tim
     out.update({k: v for k, v in t.items()})
     if t.get("sampler_s"):
         out["log_share_of_sampler"] = t["log_s"] / t["sampler_s"]
+        if t.get("log_calls", 0) > 1 and "log_first_s" in t:      # the periodic lines without the first one's one-time costs
+            out["log_ms_per_periodic_line"] = (t["log_s"] - t["log_first_s"]) / (t["log_calls"] - 1) * 1e3
         out["setup_share_of_sampler"] = t["setup_s"] / t["sampler_s"]
     out["command"] = " ".join(c if c not in (root, res) else "<tmp>" for c in cmd[1:])
     return out

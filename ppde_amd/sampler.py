@@ -291,6 +291,8 @@ class PPDE_PAS(BaseSampler):
             f_hist = f_hist.reshape(-1)
             if (energy_function.which & 7) == 2:
                 e_hist, best_e, best_f = e_hist.reshape(-1), best_e.reshape(()), best_f.reshape(())
-        self.timings = {"setup_s": t_setup, "iterations_s": t_run, "log_s": t_log0 + t_log, "log_calls": 1 + (num_steps // log_every if log_every > 0 else 0),
+        # (log_first_s: the line of iteration 0, which in a fresh process carries the first use of the oracle's torch kernels)
+        self.timings = {"setup_s": t_setup, "iterations_s": t_run, "log_s": t_log0 + t_log, "log_first_s": t_log0,
+                        "log_calls": 1 + (num_steps // log_every if log_every > 0 else 0),
                         "collect_s": time.perf_counter() - t0, "graph": chains.graph_stats()}
         return (best_x, best_e, best_f, e_hist, f_hist, random_traj)
