@@ -13,5 +13,8 @@ echo "const char ${SYM:-__hip_fatbin_unused}[64] = {0};" > "$B/fatbin_stub.c"
 $HIPCC $FLAGS --cuda-host-only -x hip -c "$HERE/hipmock.cpp" -o "$B/hipmock.o"
 g++ -O1 -g -std=c++17 -fno-omit-frame-pointer -c "$HERE/driver.cpp" -o "$B/driver.o"
 gcc -c "$B/fatbin_stub.c" -o "$B/fatbin_stub.o"
+# the split-precision helpers of cnn.h (scales, two-term fp16 split, cross-term error bound): host-only, no runtime calls
+$HIPCC -O1 -std=c++17 -w --cuda-host-only -x hip "$HERE/splitcheck.cpp" -o "$B/splitcheck" -L/opt/rocm/lib -lamdhip64
+"$B/splitcheck"
 /opt/rocm/lib/llvm/bin/clang++ -fsanitize=address "$B/api.o" "$B/hipmock.o" "$B/driver.o" "$B/fatbin_stub.o" -o "$B/hostcheck" -lpthread -ldl
 ASAN_OPTIONS=detect_leaks=1:abort_on_error=0 "$B/hostcheck" "$@"

@@ -251,3 +251,7 @@ def test_host_layer_under_address_sanitizer():
     m = re.search(r"hostcheck ok: (\d+) fallible runtime calls per sequence, (\d+) injected failures handled", r.stdout)
     assert m and int(m.group(1)) > 100 and m.group(1) == m.group(2), r.stdout
     assert "AddressSanitizer" not in r.stderr and "LeakSanitizer" not in r.stderr, r.stderr[-4000:]
+    # the same script checks the split-precision helpers of cnn.h on the host (tests/hostcheck/splitcheck.cpp): the power-of-two
+    # scales, the two-term fp16 split of an operand (within 2^-22) and a product from its three cross terms (within 3 * 2^-22)
+    sp = re.search(r"splitcheck ok: split within ([0-9.]+) x 2\^-22, product within ([0-9.]+) x 2\^-22", r.stdout)
+    assert sp and float(sp.group(1)) <= 1.0 and float(sp.group(2)) <= 3.0, r.stdout[-2000:]
