@@ -44,7 +44,11 @@ __device__ __forceinline__ int opaque_zero() {
 // Workgroup barrier that waits for this wave's LDS operations only (__syncthreads() also waits for every global load in
 // flight, which is exactly what a phase that has just issued the NEXT phase's operand loads does not want). Use only where the
 // data handed over at the barrier went through LDS.
+#ifdef PPDE_LDS_BARRIER_FULL                 // (diagnostic builds: every LDS-only barrier as a full one)
+__device__ __forceinline__ void lds_barrier() { __syncthreads(); }
+#else
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+#endif
 
 // Make a prefetched value opaque at its point of use: without it hipcc hoists speculatable arithmetic on a loaded
 // value (a conversion, a select) up into the block that issued the load and waits for the load there.
