@@ -685,7 +685,11 @@ __device__ __forceinline__ int cnn_route_rows(const CnnNet& net, const int rows,
             }
         }
         if constexpr (GROUPED == 2) {
+#ifdef CNN_COMPACT_MIN_TILES                 // (diagnostic builds: never fewer than this many row tiles in the compacted image)
+            const int pad = min(rows, max((n_ne + 15) & ~15, 16 * CNN_COMPACT_MIN_TILES)) - n_ne;
+#else
             const int pad = ((n_ne + 15) & ~15) - n_ne;                // image rows behind the last non-empty one, up to a whole tile
+#endif
             for (int i = tid; i < pad * G4; i += NT) {
                 const int r = i / G4, c4 = i - r * G4;
                 put(n_ne + r, c4, make_float4(0.f, 0.f, 0.f, 0.f));
@@ -1251,7 +1255,11 @@ __device__ __forceinline__ void cnn_body_bf(const CnnArgs& a_, const int bx, con
     else __syncthreads();
     // (CNN_ROUTE_GROUPED = 2: the routed gradient's image holds the non-empty rows only, in rtc row tiles)
     constexpr bool COMPACT = CNN_ROUTE_GROUPED == 2;
+#ifdef CNN_COMPACT_MIN_TILES
+    const int rtc = COMPACT ? __builtin_amdgcn_readfirstlane(min(RT, max((n_ne + 15) >> 4, CNN_COMPACT_MIN_TILES))) : RT;
+#else
     const int rtc = COMPACT ? __builtin_amdgcn_readfirstlane((n_ne + 15) >> 4) : RT;
+#endif
     PPDE_STAMP(a.dbg, sb + 5, stamp);
     PPDE_STAMP(a.dbg, sb + 7, stamp);
     PPDE_WG_STAMP(a.dbg, wg_lin, 2);
