@@ -1565,9 +1565,26 @@ __global__ __launch_bounds__(NT, 2) void k_cnn_bwd_chunk(CnnChunkArgs ca) {
         const size_t base = (((size_t)ni * a.n + b) * ca.NCH) * FP + f;
         float m = -INFINITY;
         int ts = 0;
-        for (int k = 0; k < ca.NCH; ++k) {
-            const float v = ca.cmax[base + (size_t)k * FP];
-            if (v > m) { m = v; ts = ca.carg[base + (size_t)k * FP]; }
+        constexpr int MCH = 8;
+        if (ca.NCH <= MCH) {
+            // every chunk's maximum and row requested before the first comparison: one L2 round trip instead of up to two per chunk
+            // (the row was loaded only behind a winning comparison); the comparisons and their order are unchanged
+            float v[MCH];
+            int t[MCH];
+#pragma unroll
+            for (int k = 0; k < MCH; ++k) {
+                const size_t at = base + (size_t)min(k, ca.NCH - 1) * FP;
+                v[k] = ca.cmax[at];
+                t[k] = ca.carg[at];
+            }
+#pragma unroll
+            for (int k = 0; k < MCH; ++k)
+                if (k < ca.NCH && v[k] > m) { m = v[k]; ts = t[k]; }
+        } else {
+            for (int k = 0; k < ca.NCH; ++k) {
+                const float v = ca.cmax[base + (size_t)k * FP];
+                if (v > m) { m = v; ts = ca.carg[base + (size_t)k * FP]; }
+            }
         }
         const float wdf = f < F ? net.wd[f] : 0.f;
         part += wdf * m;
