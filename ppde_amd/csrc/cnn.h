@@ -529,6 +529,9 @@ __device__ __forceinline__ void mfma_strip(f32x4 (&acc)[RT], const float* A, int
 // and one work item is a row and three consecutive 4-channel pieces, so that the row's extent, its first four list entries and
 // their coefficients are fetched once for three pieces (the same 12 L2 loads in flight per item as the ungrouped form has per
 // thread and round). A piece's sum still runs over its row's entries in list order: the same bits (CNN_ROUTE_GROUPED=0: A/B builds).
+#ifndef CNN_ROUTE_GROUPED_TAIL
+#define CNN_ROUTE_GROUPED_TAIL 4       // 1: entries beyond a row's first four one by one (A/B builds)
+#endif
 #ifndef CNN_ROUTE_PIECES
 #define CNN_ROUTE_PIECES 3            // 4-channel pieces per work item of the grouped row sums
 #endif
@@ -664,6 +667,7 @@ __device__ __forceinline__ int cnn_route_rows(const CnnNet& net, const int rows,
 #pragma unroll
                 for (int q = 0; q < 4; ++q) route_fma(acc[j], cq[q], v[j][q]);
             }
+#if CNN_ROUTE_GROUPED_TAIL == 1
             for (int q = 4; q < kk; ++q) {                           // rows with more than four routed features
                 const int fq = sList[rs + q];
                 const float cf = sM[fq];
@@ -673,6 +677,28 @@ __device__ __forceinline__ int cnn_route_rows(const CnnNet& net, const int rows,
 #pragma unroll
                 for (int j = 0; j < NP; ++j) route_fma(acc[j], cf, w[j]);
             }
+#else
+            // rows with more than four routed features (the trained networks route 20-40 into a row): further entries four at a
+            // time, exactly as the first four -- one L2 round trip per four entries instead of one per entry; same terms, same order
+            for (int q0 = 4; q0 < kk; q0 += 4) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) f[q] = min((unsigned)sList[min(rs + q0 + q, last)], (unsigned)(FP - 1));
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float cm = sM[f[q]];
+                    use_here(cm);
+                    cq[q] = q0 + q < kk ? cm : 0.f;
+                }
+#pragma unroll
+                for (int j = 0; j < NP; ++j)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) v[j][q] = We4[(size_t)f[q] * G4 + c4c[j]];
+#pragma unroll
+                for (int j = 0; j < NP; ++j)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) route_fma(acc[j], cq[q], v[j][q]);
+            }
+#endif
 #pragma unroll
             for (int j = 0; j < NP; ++j) {
                 const int c4 = NP * k + j;
