@@ -183,7 +183,7 @@ def cnn_useful_flops(n, L, nets=3, K=5):
     return nets * 2.0 * n * T * C * (F + K * 20)
 
 
-def also_poe(args, device, rank, protein="PABP", lamda=5.0, steps=200, warm=40, reps=3, what="BASELINE configs[2]"):
+def also_poe(args, device, rank, protein="PABP", lamda=5.0, steps=200, warm=40, reps=3, what="BASELINE configs[2]", trained=False):
     """A Potts + supervised CNN product of experts in a few short blocks, for the N = 1 line: BASELINE configs[2] (PABP, lamda = 5,
     128 chains) and the per-GPU share of configs[3] as the reference would run it (GFP, 128 chains, lamda = 15: energy.py:104
     evaluates the CNN whatever lamda is, README.md:65-72 recommends 15 for GFP)."""
@@ -191,6 +191,13 @@ def also_poe(args, device, rank, protein="PABP", lamda=5.0, steps=200, warm=40, 
     from ppde_amd.sampler import Chains
     from bench_transformer import rocprof_frac
     m, wt, J, h, i0, Lp, cnn = build_model("potts+cnn", device, protein, lamda)
+    if trained:
+        # the VALUES of the reference's shipped checkpoints (frozen for the parity tests: tests/golden/real_<protein>_cnn.npz) instead
+        # of seeded random networks: trained networks route 20-40 features into one row, seeded ones 2-3
+        fx = np.load(os.path.join(REPO, "tests", "golden", f"real_{protein.lower()}_cnn.npz"))
+        names = ("encoder.weight", "encoder.bias", "embedding.0.weight", "embedding.0.bias", "decoder.weight", "decoder.bias")
+        cnn = [{k: fx[f"net{i}.{k}"] for k in names} for i in range(3)]
+        m.set_cnn(cnn)
     n, L = 128, wt.shape[0]
     pname = {"PABP": "PABP_YEAST", "UBE4B": "UBE4B_MOUSE", "GFP": "GFP_AEQVI"}[protein]
     out = {}
@@ -231,7 +238,7 @@ def also_poe(args, device, rank, protein="PABP", lamda=5.0, steps=200, warm=40, 
         else:
             out["value_reuse_grad"] = steps / dt
         del ch
-    if not args.no_cpu_baseline and protein == "PABP":
+    if not args.no_cpu_baseline and protein == "PABP" and not trained:
         a2 = argparse.Namespace(**{**vars(args), "cpu_seconds": 8.0, "lamda": lamda})
         out["cpu_baseline"] = cpu_baseline(a2, wt, J, h, i0, Lp, cnn, n)
     return out
@@ -546,6 +553,12 @@ def main():
                 out["cpu_baseline"]["value_with_cnn"] = also["config3"]["cpu_baseline"]["value"]
                 out["cpu_baseline"]["sample"] += (" With the supervised CNN evaluated as the reference does (timed for also.config3, lamda = 5: "
                                                   "the same work as lamda = 0): value_with_cnn.")
+            # the same workload with the trained networks' values (what a user of the shipped checkpoints runs)
+            if os.path.exists(os.path.join(REPO, "tests", "golden", "real_pabp_cnn.npz")):
+                tw = also_poe(args, device, rank, reps=2, trained=True)
+                also["config3"]["trained_weights"] = {**{k: tw[k] for k in ("value", "unit", "ms_per_step", "value_reuse_grad") if k in tw},
+                                                      "k_experts_us": tw.get("roofline", {}).get("avg_launch_us"),
+                                                      "source": "tests/golden/real_pabp_cnn.npz: the values of the reference's shipped PABP checkpoints"}
             also["config4_share"] = also_poe(args, device, rank, "GFP", 15.0, steps=60, warm=20, reps=3,
                                              what="the per-GPU share of BASELINE configs[3] as the reference would run it")
             also["config5"] = also_config5(args, rank, local)
